@@ -73,7 +73,7 @@ def load_synth_weights(module, seed):
     sd = module.state_dict()
     new = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed)
     module.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()}, strict=False)
-    return sorted(new.keys())
+    return {k: list(v.shape) for k, v in sorted(new.items())}
 
 
 def save(name, **arrays):
@@ -284,7 +284,7 @@ def feats_summary(prefix, feats, out, full=False):
             out[f"{prefix}.{key}.sums"] = np.array([float(tf.double().sum()), float((tf.double() ** 2).sum())])
         else:
             tf = t.reshape(-1).double()
-            idx = torch.linspace(0, tf.numel() - 1, 64).long()
+            idx = (torch.arange(64, dtype=torch.int64) * (tf.numel() - 1)) // 63
             out[f"{prefix}.{key}.probe"] = tf[idx].float().numpy()
             out[f"{prefix}.{key}.sums"] = np.array([float(tf.sum()), float((tf * tf).sum())])
         out[f"{prefix}.{key}.shape"] = np.array(t.shape, np.int64)
