@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- event-image pairs/s (extract + match, 346x260, 1024 keypoints) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config sp_mnn|silk_mnn|sp_lg] [--batch B]
+
+A step = one pass of the hot path (EIM.forward: event extractor + image extractor + matcher) over
+one batch of synthetic pairs already resident in HBM.  Default workload = BASELINE.json configs[1]:
+batch 32, 5-bin event voxel + gray image, SuperPoint-shaped extractors + MNN matcher.
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); pairs are independent, so ranks
+shard them with NO data-path collective; the only RCCL traffic is the all-reduce of the metric
+accumulators (weak scaling: the per-GPU batch is fixed).
+Prints ONE JSON line (rank 0) with the driver contract plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "sp_mnn": ("SP_MNN", "B32 346x260 5-bin event voxel + gray image, VGG(event)+SuperPoint(image) extractors, MNN matcher, k=1024"),
+    "silk_mnn": ("SiLK_MNN", "B32 346x260, VGG_NP(event)+SiLK(image) extractors, MNN matcher, k=1024"),
+    "sp_lg": ("SP_LG", "B64 346x260, VGG(event)+SuperPoint(image) extractors, LightGlue matcher, k=1024"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="sp_mnn", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (default 32; 64 for sp_lg)")
+    ap.add_argument("--log-assignment", action="store_true", help="also materialise log_assignment (reference-complete matcher dict)")
+    ap.add_argument("--dense", action="store_true", help="also materialise the dense descriptor maps (reference-complete dict)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=8)
+    return ap.parse_args()
+
+
+def conv_layer_flops(cin, cout, ks, H, W):
+    return 2.0 * cin * cout * ks * ks * H * W
+
+
+def sp_pair_flops(ce):
+    """algorithmic FLOPs of the two SuperPoint-shaped encoders + heads for one pair."""
+    def net(c0):
+        f = conv_layer_flops(c0, 64, 3, 264, 352) + conv_layer_flops(64, 64, 3, 264, 352)
+        f += 2 * conv_layer_flops(64, 64, 3, 132, 176)
+        f += conv_layer_flops(64, 128, 3, 66, 88) + conv_layer_flops(128, 128, 3, 66, 88)
+        f += 2 * conv_layer_flops(128, 128, 3, 33, 44)
+        f += 2 * conv_layer_flops(128, 256, 3, 33, 44) + conv_layer_flops(256, 65, 1, 33, 44) + conv_layer_flops(256, 256, 1, 33, 44)
+        return f
+    return net(ce) + net(1)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pkg = importlib.import_module("ei-nexus_official_amd")
+    synth = pkg.synth
+    cfg_name, wl_desc = WORKLOADS[args.config]
+    B = args.batch or (64 if args.config == "sp_lg" else 32)
+    ce = 5
+    cfg = pkg.default_config(cfg_name, event_channels=ce)
+    model = pkg.EIM(cfg, device=dev).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=11)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = bool(args.dense)
+    model.matcher.matcher.want_log_assignment = bool(args.log_assignment)
+
+    # synthetic pairs: each rank gets its own shard of the global pair index space
+    ev_np, mask_np = synth.synth_events(10_000 + rank * B, B, ce)
+    img_np = synth.synth_image(10_000 + rank * B, B)
+    ev = torch.from_numpy(ev_np).to(dev)
+    mask = torch.from_numpy(mask_np).to(dev)
+    img_src = torch.from_numpy(img_np).to(dev)
+    img = torch.empty_like(img_src)
+
+    acc = torch.zeros(4, dtype=torch.float64, device=dev)  # pairs, keypoints(ev), keypoints(im), matches
+
+    def step(accumulate=False):
+        img.copy_(img_src)  # SuperPoint scales its input in place (reference quirk), so refresh it
+        ef, imf, m = model(ev, img, mask)
+        if accumulate:
+            acc[0] += B
+            acc[1] += sum(int(p.shape[0]) for p in ef["sparse_positions"])
+            acc[2] += sum(int(p.shape[0]) for p in imf["sparse_positions"])
+            acc[3] += sum(int(t.shape[0]) for t in m["matched_kpts0"])
+        return ef, imf, m
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(accumulate=True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)  # the one collective of the job: metric accumulators over RCCL
+    elapsed = float(t.item())
+    pairs_total = float(acc[0].item())
+    value = pairs_total / elapsed
+
+    # ---- roofline of the dominant kernel: conv_block_kernel<3,8,32,4,pool> = conv1b 64->64 @264x352 ------
+    roofline = None
+    if rank == 0 and args.config != "silk_mnn":
+        eng = model.image_extractor.extractor.engine()
+        l0, l1 = eng.backbone[0], eng.backbone[1]
+        x1 = l0(img_src, fold=(2, 3, 264, 352))
+        reps = 10
+        for _ in range(2):
+            l1(x1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            l1(x1)
+        e1.record()
+        torch.cuda.synchronize()
+        dur = e0.elapsed_time(e1) * 1e-3 / reps
+        flops = conv_layer_flops(64, 64, 3, 264, 352) * B
+        ach = flops / dur / 1e12
+        roofline = {"kernel": "conv_block_kernel<3,8,32,4,pool> (conv1b 64->64 @264x352)", "bound": "mfma", "achieved": round(ach, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launch_ms": round(dur * 1e3, 4), "flop_per_launch": flops,
+                    "pipeline_conv_tflops": round(sp_pair_flops(ce) * value / max(world, 1) / 1e12, 2)}
+
+    # ---- CPU baseline: the oracle (a port, not the reference files) on the host cores, bounded sample ----
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        nb = args.cpu_pairs
+        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
+        et, it = cfg.event_extractor.type, cfg.image_extractor.type
+        escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
+        tc = time.perf_counter()
+        oe = orc.extractor_forward(et, sub("event_extractor.extractor."), ev_np[:nb].copy(), mask_np[:nb], top_k=1024, scale=escale)
+        oi = orc.extractor_forward(it, sub("image_extractor.extractor."), img_np[:nb].copy(), None, top_k=1024, scale=iscale)
+        nmatch = 0
+        for b in range(nb):
+            if cfg.matcher.type == "MNN":
+                r = orc.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=args.log_assignment)
+            else:
+                r = orc.lightglue(sub("matcher.matcher."), oe["sparse_positions"][b], oe["sparse_descriptors"][b],
+                                  oi["sparse_positions"][b], oi["sparse_descriptors"][b])
+            nmatch += int((r["matches0"] > -1).sum())
+        cpu_s = time.perf_counter() - tc
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        cpu_baseline = {"value": round(nb / cpu_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+                        "sample": f"{nb} pairs of the same workload through oracle/ (C, OpenMP on all host cores), {cpu_s:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": "event-image pairs/s (extract+match, 346x260, 1024 kpts)",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_desc, "pairs_per_gpu_per_step": B, "global_batch": B * world, "event_bins": ce,
+                       "parallelism": f"dp{world} (pairs sharded, metric all-reduce only)", "log_assignment": bool(args.log_assignment),
+                       "dense_outputs": bool(args.dense),
+                       "mean_keypoints": [round(float(acc[1].item()) / pairs_total, 1), round(float(acc[2].item()) / pairs_total, 1)],
+                       "mean_matches": round(float(acc[3].item()) / pairs_total, 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

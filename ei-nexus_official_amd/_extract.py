@@ -1,0 +1,145 @@
+"""Batched extractor engine shared by the four extractor front-ends (VGGExtractor,
+VGGExtractorNP, SuperPointv1, SiLKModel).  Everything stays on the device and on the current
+stream; nothing here synchronises with the host.  `BatchedFeats.materialize()` turns the device
+result into the reference's output dict once the per-image keypoint counts are on the host.
+
+Reference behaviour mirrored (file:line): core/modules/event_extractors/EventExtractors.py:517-624
+and :331-434, core/modules/image_extractors/superpoint_extractor.py:345-480,
+core/modules/image_extractors/silk_extractor.py:177-257.
+"""
+import torch
+
+from . import _native as N
+
+
+class FeatsDict(dict):
+    """The reference's feature dict plus a handle on the device-side batch (`_batched`) so that the
+    matcher can consume it without re-packing the per-image lists."""
+    _batched = None
+
+
+class BatchedFeats:
+    def __init__(self):
+        self.kind = None
+        self.cell = 8
+        self.B = 0
+        self.image_size = None  # (H, W)
+        self.pads = None  # (w0, w1, h0, h1)
+        self.padded = None  # (Hp, Wp)
+        self.feats = self.logits = self.raw = self.prob = self.score = None
+        self.det = None
+        self.sparse_desc = None
+        self.coarse = None
+        self.normalized = None
+        self.scale = 1.0
+        self.ordering = "yx"
+        self.dense = False
+
+    # ------------------------------------------------------------------ device handles
+    @property
+    def counts(self):
+        return self.det.counts
+
+    @property
+    def positions(self):
+        return self.det.positions
+
+    def materialize(self, counts_host):
+        """counts_host: python ints per image (already clamped by the caller's sync)."""
+        H, W = self.image_size
+        w0, w1, h0, h1 = self.pads
+        Hp, Wp = self.padded
+        dev = self.score.device
+        size_t = torch.tensor([H, W], device=dev)
+        out = FeatsDict()
+        out["image_size"] = [size_t] * self.B
+        out["backbone_feats"] = self.feats
+        out["logits"] = self.logits
+        out["raw_descriptors"] = self.raw
+        out["probability"] = self.prob
+        out["score"] = self.score[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+        out["nms"] = self.det.nms
+        if self.cell == 8:
+            out["coarse_descriptors"] = self.coarse
+        if self.dense:
+            nd = self.normalized
+            out["normalized_descriptors"] = nd
+            C = nd.shape[1]
+            out["dense_descriptors"] = [nd[b].permute(1, 2, 0).reshape(-1, C) for b in range(self.B)]
+            ys = torch.arange(H, device=dev, dtype=torch.float32) + 0.5
+            xs = torch.arange(W, device=dev, dtype=torch.float32) + 0.5
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            first, second = (gy, gx) if self.ordering == "yx" else (gx, gy)
+            sc = out["score"]
+            out["dense_positions"] = [torch.stack([first, second, sc[b, 0]], -1).reshape(-1, 3) for b in range(self.B)]
+        cap = self.det.cap
+        ns = [min(int(c), cap) for c in counts_host]
+        out["sparse_descriptors"] = [self.sparse_desc[b, :ns[b]] for b in range(self.B)]
+        out["sparse_positions"] = [self.det.positions[b, :ns[b]] for b in range(self.B)]
+        out._batched = self
+        return out
+
+
+class ExtractorEngine:
+    """Holds the kernel-native layer images of one network and runs the batched forward."""
+
+    def __init__(self, kind, *, top_k, radius, border, det_thr, ordering, cell):
+        self.kind = kind
+        self.cell = cell
+        self.top_k, self.radius, self.border, self.det_thr, self.ordering = top_k, radius, border, det_thr, ordering
+        self.backbone = []  # ConvLayer list
+        self.det_head = []
+        self.desc_head = []
+        self.nms_iters = 8
+
+    def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None):
+        if x.dim() != 4:
+            raise ValueError(f"Expected 4D tensor, got {x.dim()}D tensor instead.")
+        if x.dtype != torch.float32:
+            raise TypeError("einx extractors compute in fp32; pass a float32 tensor")
+        if x.device.type != "cuda":
+            raise RuntimeError("einx: input must be on a HIP device (no CPU path)")
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        pads = N.padder_pads(H, W, self.cell)
+        w0, w1, h0, h1 = pads
+        Hp, Wp = H + h0 + h1, W + w0 + w1
+        t = x
+        first = True
+        for layer in self.backbone:
+            t = layer(t, fold=(h0, w0, Hp, Wp) if first else None)
+            first = False
+        feats = t
+        d = feats
+        for layer in self.det_head:
+            d = layer(d)
+        logits = d
+        d = feats
+        for layer in self.desc_head:
+            d = layer(d)
+        raw = d
+        prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
+        det = N.detect(score, top_k=self.top_k, radius=self.radius, det_thr=self.det_thr, pads=pads, ordering=self.ordering,
+                       nms_iters=nms_iters or self.nms_iters)
+        bf = BatchedFeats()
+        bf.kind, bf.cell, bf.B = self.kind, self.cell, B
+        bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
+        bf.feats, bf.logits, bf.raw, bf.prob, bf.score, bf.det = feats, logits, raw, prob, score, det
+        bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
+        if det.cap > 8192:
+            # unbounded-capacity configuration (no top-k or detection_threshold < 1): size the
+            # descriptor buffer from the real counts (one extra sync, never on the default path)
+            cmax = max(int(det.counts.max().item()), 1)
+            det.positions = det.positions[:, :cmax].contiguous()
+            det.indices = det.indices[:, :cmax].contiguous()
+            det.cap = cmax
+        bf.sparse_desc = N.desc_sample(raw, det.indices, det.counts, (Hp, Wp), bilinear=(self.cell == 8), scale=scale)
+        if self.cell == 8:
+            bf.coarse = N.normalize_map(raw, scale)
+        if dense:
+            if self.cell == 8:
+                bf.normalized = N.upsample_normalize(raw, (Hp, Wp), pads, scale)
+            else:
+                nd = N.normalize_map(raw, scale)
+                bf.normalized = nd[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+        return bf

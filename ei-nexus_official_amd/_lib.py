@@ -1,0 +1,100 @@
+"""ctypes binding of libeinx_hip.so (C ABI: include/einx.h).
+
+The library is the product: if it is missing or a symbol is absent this module raises --
+there is no Python/torch fallback for any kernel.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeinx_hip.so")
+
+c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("w_native", c_void_p), ("bias", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("ks", ctypes.c_int32), ("relu", ctypes.c_int32),
+                ("pool", ctypes.c_int32)]
+
+
+class DetectParams(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("Hp", ctypes.c_int32), ("Wp", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("W", ctypes.c_int32), ("h0", ctypes.c_int32), ("w0", ctypes.c_int32), ("radius", ctypes.c_int32),
+                ("top_k", ctypes.c_int32), ("det_thr", c_float), ("ordering_xy", ctypes.c_int32), ("cap", ctypes.c_int32),
+                ("nms_iters", ctypes.c_int32)]
+
+
+class LgLayer(ctypes.Structure):
+    _names = ("Wqkv", "bqkv", "Wo", "bo", "sf0_w", "sf0_b", "sln_g", "sln_b", "sf3_w", "sf3_b",
+              "Wqk", "bqk", "Wv", "bv", "Wco", "bco", "cf0_w", "cf0_b", "cln_g", "cln_b", "cf3_w", "cf3_b")
+    _fields_ = [(n, c_void_p) for n in _names]
+
+
+class LgWeights(ctypes.Structure):
+    _fields_ = [("in_w", c_void_p), ("in_b", c_void_p), ("Wr", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
+                ("match_w", c_void_p), ("match_b", c_void_p), ("n_layers", ctypes.c_int32), ("heads", ctypes.c_int32),
+                ("d", ctypes.c_int32), ("input_dim", ctypes.c_int32), ("filter_threshold", c_float),
+                ("layers", ctypes.POINTER(LgLayer))]
+
+
+# name -> (restype, argtypes); every symbol include/einx.h declares
+SIGNATURES = {
+    "einx_version": (c_char_p, []),
+    "einx_last_error": (c_char_p, []),
+    "einx_device_count": (c_int, []),
+    "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
+    "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "einx_conv_block": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
+    "einx_div_inplace": (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
+    "einx_score_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                               c_void_p, c_void_p]),
+    "einx_remove_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "einx_detect_ws_bytes": (c_size_t, [ctypes.POINTER(DetectParams)]),
+    "einx_detect": (c_int, [c_void_p, ctypes.POINTER(DetectParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+    "einx_desc_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
+                                 c_void_p, c_void_p]),
+    "einx_normalize_map": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "einx_upsample_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_void_p, c_void_p]),
+    "einx_mnn_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "einx_mnn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                         c_void_p, c_void_p, c_void_p]),
+    "einx_gather_matches": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "einx_lg_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "einx_lightglue": (c_int, [ctypes.POINTER(LgWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                               c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class EinxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libeinx_hip.so; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the product and has no fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C ei-nexus_official_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().einx_last_error().decode(errors="replace")
+        raise EinxError(f"{what} failed ({status}): {msg}")

@@ -1,0 +1,239 @@
+"""Torch-tensor front door of the C ABI: validates device/dtype/contiguity, allocates outputs
+and workspaces with torch (caching allocator, stream ordered) and enqueues the HIP kernels on the
+current stream.  No arithmetic happens here; PyTorch is memory + stream plumbing only.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, DetectParams, check
+
+F32 = torch.float32
+
+
+def lib():
+    return _lib.load()
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "einx: tensors must live on a HIP device (torch device type 'cuda'); there is no CPU path. "
+                f"Got a tensor on {t.device}.")
+        if not t.is_contiguous():
+            raise RuntimeError("einx: tensors must be contiguous")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def padder_pads(h, w, p):
+    """Padder.__init__ arithmetic (reference core/modules/utils/util.py:6-15) -> (w0, w1, h0, h1)."""
+    hp = (((h // p) + 1) * p - h) % p
+    wp = (((w // p) + 1) * p - w) % p
+    return (wp // 2, wp - wp // 2, hp // 2, hp - hp // 2)
+
+
+def topk_ranks(N, k):
+    """Indices torch.quantile(q,'midpoint') gathers, in the reference's fp32 arithmetic."""
+    q = np.float32(N - k) / np.float32(N)
+    rank = np.float32(q * np.float32(N - 1))
+    return int(math.floor(float(rank))), int(math.ceil(float(rank)))
+
+
+def topk_capacity(N, top_k, det_thr):
+    if not top_k or top_k >= N or det_thr < 1.0:
+        return N
+    lo, _ = topk_ranks(N, int(top_k))
+    return N - 1 - lo
+
+
+# ------------------------------------------------------------------------------ conv
+class ConvLayer:
+    """Kernel-native image of one conv block: weights repacked on device, BN(eval) folded into a
+    per-channel (scale, shift) on the host with the same fp32 ops the oracle uses."""
+
+    def __init__(self, weight, bias, bn=None, relu=True, pool=False):
+        _dev_check(weight)
+        cout, cin, ks, _ = weight.shape
+        self.cin, self.cout, self.ks, self.relu, self.pool = cin, cout, ks, relu, pool
+        L = lib()
+        w = weight.detach().to(F32).contiguous()
+        self.w_native = torch.empty(L.einx_conv_weight_elems(cin, cout, ks), dtype=F32, device=w.device)
+        check(L.einx_conv_repack(_ptr(w), cin, cout, ks, _ptr(self.w_native), _stream(w)), "einx_conv_repack")
+        self.bias = None if bias is None else bias.detach().to(F32).contiguous()
+        self.scale = self.shift = None
+        if bn is not None:
+            g, b, mean, var, eps = [t.detach().to("cpu", F32) if torch.is_tensor(t) else t for t in bn]
+            scale = g / torch.sqrt(var + eps)
+            shift = b - mean * scale
+            self.scale = scale.to(w.device).contiguous()
+            self.shift = shift.to(w.device).contiguous()
+        self.desc = ConvDesc(self.w_native.data_ptr(), 0 if self.bias is None else self.bias.data_ptr(),
+                             0 if self.scale is None else self.scale.data_ptr(), 0 if self.shift is None else self.shift.data_ptr(),
+                             cin, cout, ks, int(relu), int(pool))
+        self._keep = w  # repack reads it asynchronously
+
+    def __call__(self, x, fold=None):
+        """x [B,cin,Hs,Ws]; fold = (h0, w0, H, W) applies replicate padding on the fly."""
+        _dev_check(x)
+        B, C, Hs, Ws = x.shape
+        if C != self.cin:
+            raise ValueError(f"conv expects {self.cin} input channels, got {C}")
+        h0, w0, H, W = fold if fold is not None else (0, 0, Hs, Ws)
+        Ho, Wo = (H // 2, W // 2) if self.pool else (H, W)
+        out = torch.empty((B, self.cout, Ho, Wo), dtype=F32, device=x.device)
+        check(lib().einx_conv_block(_ptr(x), B, Hs, Ws, h0, w0, H, W, ctypes.byref(self.desc), _ptr(out), _stream(x)), "einx_conv_block")
+        return out
+
+
+def bn_tuple(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def div_inplace(x, divisor):
+    _dev_check(x)
+    check(lib().einx_div_inplace(_ptr(x), x.numel(), float(divisor), _stream(x)), "einx_div_inplace")
+    return x
+
+
+# ------------------------------------------------------------------------------ detector
+def score_map(logits, mask=None, pads=(0, 0, 0, 0), dilate=False, border=0):
+    """-> (probability [B,C,hc,wc], score [B,1,Hp,Wp])."""
+    _dev_check(logits, mask)
+    B, C, hc, wc = logits.shape
+    cell = 8 if C == 65 else 1
+    Hp, Wp = hc * cell, wc * cell
+    w0, w1, h0, h1 = pads
+    H, W = Hp - h0 - h1, Wp - w0 - w1
+    prob = torch.empty_like(logits)
+    score = torch.empty((B, 1, Hp, Wp), dtype=F32, device=logits.device)
+    m8 = None
+    if mask is not None:
+        if tuple(mask.shape[-2:]) != (H, W):
+            raise ValueError(f"mask spatial size {tuple(mask.shape[-2:])} does not match the image ({H},{W})")
+        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+    check(lib().einx_score_map(_ptr(logits), B, C, hc, wc, _ptr(m8), H, W, h0, w0, int(dilate), int(border), _ptr(prob), _ptr(score),
+                               _stream(logits)), "einx_score_map")
+    return prob, score
+
+
+def remove_border(score, border):
+    _dev_check(score)
+    B = score.shape[0]
+    Hp, Wp = score.shape[-2:]
+    check(lib().einx_remove_border(_ptr(score), int(score.numel() // (Hp * Wp)), Hp, Wp, int(border), _stream(score)), "einx_remove_border")
+    return score
+
+
+class Detection:
+    """Device-side result of einx_detect for a batch."""
+    __slots__ = ("positions", "indices", "counts", "thr", "not_converged", "nms", "cap", "padded", "pads")
+
+
+def detect(score, *, top_k, radius, det_thr, pads=(0, 0, 0, 0), ordering="yx", cap=None, nms_iters=8, want_nms=True):
+    """score [B,1,Hp,Wp] or [B,Hp,Wp] (already masked/border-zeroed)."""
+    _dev_check(score)
+    B = score.shape[0]
+    Hp, Wp = score.shape[-2:]
+    w0, w1, h0, h1 = pads
+    H, W = Hp - h0 - h1, Wp - w0 - w1
+    N = Hp * Wp
+    if cap is None:
+        cap = topk_capacity(N, top_k, det_thr)
+    cap = max(int(cap), 1)
+    p = DetectParams(B, Hp, Wp, H, W, h0, w0, int(radius), int(top_k or 0), float(det_thr), int(ordering == "xy"), cap, int(nms_iters))
+    L = lib()
+    dev = score.device
+    ws = torch.empty(L.einx_detect_ws_bytes(ctypes.byref(p)), dtype=torch.uint8, device=dev)
+    d = Detection()
+    d.positions = torch.empty((B, cap, 3), dtype=F32, device=dev)
+    d.indices = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    d.counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    d.thr = torch.empty((B,), dtype=F32, device=dev)
+    d.not_converged = torch.empty((B,), dtype=torch.int32, device=dev)
+    d.nms = torch.empty((B, H, W), dtype=F32, device=dev) if want_nms else None
+    d.cap, d.padded, d.pads = cap, (Hp, Wp), pads
+    check(L.einx_detect(_ptr(score), ctypes.byref(p), _ptr(ws), _ptr(d.nms), _ptr(d.positions), _ptr(d.indices), _ptr(d.counts),
+                        _ptr(d.thr), _ptr(d.not_converged), _stream(score)), "einx_detect")
+    return d
+
+
+# ------------------------------------------------------------------------------ descriptors
+def desc_sample(raw, indices, counts, padded_size, bilinear, scale):
+    _dev_check(raw, indices, counts)
+    B, D, hc, wc = raw.shape
+    cap = indices.shape[1]
+    out = torch.empty((B, cap, D), dtype=F32, device=raw.device)
+    check(lib().einx_desc_sample(_ptr(raw), B, D, hc, wc, int(padded_size[0]), int(padded_size[1]), int(bilinear), _ptr(indices),
+                                 _ptr(counts), cap, float(scale), _ptr(out), _stream(raw)), "einx_desc_sample")
+    return out
+
+
+def normalize_map(raw, scale):
+    _dev_check(raw)
+    B, D = raw.shape[:2]
+    P = int(raw.numel() // (B * D))
+    out = torch.empty_like(raw)
+    check(lib().einx_normalize_map(_ptr(raw), B, D, P, float(scale), _ptr(out), _stream(raw)), "einx_normalize_map")
+    return out
+
+
+def upsample_normalize(raw, padded_size, pads, scale):
+    _dev_check(raw)
+    B, D, hc, wc = raw.shape
+    Hp, Wp = int(padded_size[0]), int(padded_size[1])
+    w0, w1, h0, h1 = pads
+    H, W = Hp - h0 - h1, Wp - w0 - w1
+    out = torch.empty((B, D, H, W), dtype=F32, device=raw.device)
+    check(lib().einx_upsample_normalize(_ptr(raw), B, D, hc, wc, Hp, Wp, h0, w0, H, W, float(scale), _ptr(out), _stream(raw)),
+          "einx_upsample_normalize")
+    return out
+
+
+# ------------------------------------------------------------------------------ matching
+class MatchResult:
+    __slots__ = ("matches0", "matches1", "scores0", "scores1", "la", "mk0", "mk1", "nmatch", "ref0", "ref1")
+
+
+def mnn(desc0, n, desc1, m, want_la=True):
+    _dev_check(desc0, desc1, n, m)
+    B, cap0, D = desc0.shape
+    cap1 = desc1.shape[1]
+    L = lib()
+    dev = desc0.device
+    ws = torch.empty(L.einx_mnn_ws_bytes(B, cap0, cap1), dtype=torch.uint8, device=dev)
+    r = MatchResult()
+    r.matches0 = torch.empty((B, cap0), dtype=torch.int64, device=dev)
+    r.matches1 = torch.empty((B, cap1), dtype=torch.int64, device=dev)
+    r.scores0 = torch.empty((B, cap0), dtype=F32, device=dev)
+    r.scores1 = torch.empty((B, cap1), dtype=F32, device=dev)
+    r.la = torch.empty((B, cap0 + 1, cap1 + 1), dtype=F32, device=dev) if want_la else None
+    r.ref0 = r.ref1 = None
+    check(L.einx_mnn(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, _ptr(ws), _ptr(r.matches0), _ptr(r.matches1),
+                     _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _stream(desc0)), "einx_mnn")
+    return r
+
+
+def gather_matches(r, kpts0, kpts1, n, cols):
+    _dev_check(kpts0, kpts1, n)
+    B, cap0, _ = kpts0.shape
+    cap1 = kpts1.shape[1]
+    dev = kpts0.device
+    r.mk0 = torch.empty((B, cap0, cols), dtype=F32, device=dev)
+    r.mk1 = torch.empty((B, cap0, cols), dtype=F32, device=dev)
+    r.nmatch = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(lib().einx_gather_matches(_ptr(kpts0), _ptr(kpts1), _ptr(r.matches0), _ptr(n), cap0, cap1, B, cols, _ptr(r.mk0), _ptr(r.mk1),
+                                    _ptr(r.nmatch), _stream(kpts0)), "einx_gather_matches")
+    return r

@@ -1,0 +1,68 @@
+"""EIM: event extractor + image extractor + matcher (reference core/modules/EIM.py:13-100).
+
+Same constructor, checkpoint-prefix loading and `forward` contract.  The difference is the
+schedule: both extractors and the matcher are enqueued for the whole batch on the current HIP
+stream, and the host synchronises exactly once (to read the keypoint / match counts that shape
+the returned Python lists)."""
+import torch
+from torch import nn
+
+from .Extractors import EventKeypointsExtractor, ImageKeypointsExtractor
+from .Matchers import Matcher
+
+
+class EIM(nn.Module):
+    def __init__(self, config, device="cuda", logger=None):
+        super().__init__()
+        self.device = device
+        self.config = config
+        self.logger = logger
+        self.event_extractor = EventKeypointsExtractor(config, logger, device=device)
+        self.image_extractor = ImageKeypointsExtractor(config, logger, device=device)
+        self.matcher = Matcher(config, logger, device=device)
+        if config.pretrain_stage1.model_path is not None:
+            m = torch.load(config.pretrain_stage1.model_path, map_location=device)
+            self.event_extractor.load_state_dict({k[16:]: v for k, v in m.items() if "event_extractor" in k})
+            if logger is not None:
+                logger.log_info(f"Loaded pretrain_stage1 model from {config.pretrain_stage1.model_path}")
+        if config.pretrain_stage2.model_path is not None:
+            m = torch.load(config.pretrain_stage2.model_path, map_location=device)
+            self.matcher.load_state_dict({k[8:]: v for k, v in m.items() if "matcher" in k})
+            if logger is not None:
+                logger.log_info(f"Loaded pretrain_stage2 model from {config.pretrain_stage2.model_path}")
+
+    def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False):
+        """Enqueue the whole pipeline; returns device-side results without synchronising."""
+        ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
+        im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
+        mr = None
+        if self.matcher.matcher is not None:
+            if not self.matcher.freeze:
+                raise NotImplementedError("einx: set matcher.freeze: true (the trainable matcher branch is out of scope)")
+            mr = self.matcher.match_batched(ev, im)
+        return ev, im, mr
+
+    def forward(self, events, image, events_mask=None, image_mask=None):
+        iters, prepared = None, False
+        while True:
+            ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, nms_iters=iters, prepared=prepared)
+            rows = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
+            if mr is not None:
+                rows.append(mr.nmatch)
+            host = torch.stack(rows).cpu()  # the one host synchronisation of the forward pass
+            if not bool(host[2].any() or host[3].any()):
+                break
+            iters = 4 * (iters or 8)  # NMS fix-point needed more passes than enqueued: redo
+            prepared = True  # inputs were already scaled in place (SuperPoint's image /= 255)
+        n, m = host[0].tolist(), host[1].tolist()
+        events_feats = ev.materialize(n)
+        image_feats = im.materialize(m)
+        matches = None
+        if mr is not None:
+            n = [min(v, ev.det.cap) for v in n]
+            m = [min(v, im.det.cap) for v in m]
+            matches = self.matcher.materialize(mr, n, m, host[4].tolist())
+        return events_feats, image_feats, matches
+
+    def count_parameters(self, model):
+        return sum(p.numel() for p in model.parameters() if p.requires_grad)

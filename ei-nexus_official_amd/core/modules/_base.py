@@ -1,0 +1,87 @@
+"""Common machinery of the native extractor front-ends."""
+import torch
+from torch import nn
+
+from ... import _native as N
+from ..._extract import ExtractorEngine
+from .net.vgg import block_spec
+
+
+class NativeExtractor(nn.Module):
+    """nn.Module shell: owns the parameters (reference state_dict names), builds the kernel-native
+    layer images lazily, and exposes both the reference `forward` (dict, one host sync) and
+    `extract_batched` (device-side result, no sync)."""
+
+    kind = None
+    cell_size = 8
+    uses_batchnorm = True
+    dilate_mask = False
+
+    def _init_common(self, nms_radius, detection_top_k, detection_threshold, remove_borders, ordering, descriptor_scale_factor,
+                     learnable_descriptor_scale_factor):
+        if ordering not in ("xy", "yx"):
+            raise AssertionError(ordering)
+        self.nms_radius = nms_radius
+        self.detection_top_k = detection_top_k
+        self.detection_threshold = detection_threshold
+        self.remove_borders = remove_borders
+        self.ordering = ordering
+        self.descriptor_scale_factor = nn.parameter.Parameter(torch.tensor(float(descriptor_scale_factor)),
+                                                              requires_grad=learnable_descriptor_scale_factor)
+        self.dense_outputs = True  # reference-complete dict; set False to skip the 92 MB/image dense maps
+        self._engine = None
+
+    # -- cache invalidation: anything that moves or replaces parameters drops the native images
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def refresh(self):
+        """Call after editing parameters in place."""
+        self._engine = None
+
+    def _layer(self, block, pool=False):
+        conv, bn, relu, pool = block_spec(block, pool)
+        return N.ConvLayer(conv.weight, conv.bias, None if bn is None else N.bn_tuple(bn), relu=relu, pool=pool)
+
+    def _stacks(self):
+        """-> (backbone blocks [(block, pool)], detector blocks, descriptor blocks)"""
+        raise NotImplementedError
+
+    def engine(self):
+        if self._engine is None:
+            eng = ExtractorEngine(self.kind, top_k=self.detection_top_k, radius=self.nms_radius, border=self.remove_borders,
+                                  det_thr=self.detection_threshold, ordering=self.ordering, cell=self.cell_size)
+            bb, det, desc = self._stacks()
+            eng.backbone = [self._layer(b, p) for b, p in bb]
+            eng.det_head = [self._layer(b) for b in det]
+            eng.desc_head = [self._layer(b) for b in desc]
+            self._engine = eng
+        return self._engine
+
+    def _prepare_input(self, x):
+        return x
+
+    def extract_batched(self, x, score_mask=None, nms_iters=None, dense=None, prepared=False):
+        """prepared=True: `x` already went through _prepare_input (retry after an NMS overflow)."""
+        if self.training and self.uses_batchnorm:
+            raise RuntimeError("the native path implements eval-mode BatchNorm (running statistics) only; call .eval() first")
+        if not prepared:
+            x = self._prepare_input(x)
+        scale = float(self.descriptor_scale_factor.detach())
+        return self.engine().run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask,
+                                 dense=self.dense_outputs if dense is None else dense, nms_iters=nms_iters)
+
+    def forward(self, x, score_mask=None, **kwargs):
+        iters = None
+        x = self._prepare_input(x)
+        while True:
+            bf = self.extract_batched(x, score_mask, nms_iters=iters, prepared=True)
+            host = torch.stack([bf.det.counts, bf.det.not_converged]).cpu()
+            if not bool(host[1].any()):
+                return bf.materialize(host[0].tolist())
+            iters = 4 * (iters or self.engine().nms_iters)  # NMS fix-point needs more passes: redo

@@ -1,0 +1,81 @@
+"""Device-side batching helpers shared by the native matchers."""
+import torch
+
+from ...._extract import FeatsDict
+
+
+class PairBatch:
+    """Keypoints/descriptors of B images packed as [B,cap,*] with device-side counts."""
+    __slots__ = ("kpts", "desc", "counts", "cap", "B", "image_size", "counts_host")
+
+
+def from_batched(bf):
+    pb = PairBatch()
+    pb.kpts, pb.desc, pb.counts = bf.det.positions, bf.sparse_desc, bf.det.counts
+    pb.cap, pb.B, pb.image_size = bf.det.cap, bf.B, bf.image_size
+    pb.counts_host = None
+    return pb
+
+
+def from_feats(feats):
+    """Accepts the reference-style dict (lists of per-image tensors, or stacked tensors)."""
+    if isinstance(feats, FeatsDict) and feats._batched is not None:
+        pb = from_batched(feats._batched)
+        pb.counts_host = [int(p.shape[0]) for p in feats["sparse_positions"]]
+        return pb
+    pos, desc = feats["sparse_positions"], feats["sparse_descriptors"]
+    if torch.is_tensor(pos):
+        pos, desc = list(pos), list(desc)
+    B = len(pos)
+    cap = max([int(p.shape[0]) for p in pos] + [1])
+    dev, D = desc[0].device, int(desc[0].shape[-1])
+    pb = PairBatch()
+    pb.kpts = torch.zeros((B, cap, 3), dtype=torch.float32, device=dev)
+    pb.desc = torch.zeros((B, cap, D), dtype=torch.float32, device=dev)
+    pb.counts_host = [int(p.shape[0]) for p in pos]
+    for b in range(B):
+        n = pb.counts_host[b]
+        if n:
+            pb.kpts[b, :n, :pos[b].shape[1]] = pos[b]
+            pb.desc[b, :n] = desc[b]
+    pb.counts = torch.tensor(pb.counts_host, dtype=torch.int32, device=dev)
+    size = feats["image_size"][0]
+    pb.image_size = (int(size[0]), int(size[1]))
+    pb.cap, pb.B = cap, B
+    return pb
+
+
+def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None):
+    """MatchResult (device, padded) -> the reference's per-pair lists (Matchers.py:168-203).
+    Reproduces the empty-input dict (MNN.py:63-86 / lightglue.py:569-591) and the zero-match
+    `torch.stack([])` failure (MNN.py:126-127) of the reference."""
+    keys = ("matches0", "matches1", "matching_scores0", "matching_scores1", "matched_kpts0", "matched_kpts1", "log_assignment")
+    out = {k: [] for k in keys}
+    if extra:
+        for k in extra:
+            out[k] = []
+    B = len(n_host)
+    for b in range(B):
+        n, m = n_host[b], m_host[b]
+        if n == 0 or m == 0:
+            print("No keypoints found in either image")
+            f = r.scores0
+            out["matches0"].append(f.new_full((1, n), -1))
+            out["matches1"].append(f.new_full((1, m), -1))
+            out["matching_scores0"].append(f.new_zeros((1, n)))
+            out["matching_scores1"].append(f.new_zeros((1, m)))
+            out["matched_kpts0"].append(f.new_zeros((0, 3)))
+            out["matched_kpts1"].append(f.new_zeros((0, 3)))
+            out["log_assignment"].append(f.new_zeros((1, n + 1, m + 1)))
+            continue
+        M = nmatch_host[b]
+        if M == 0:
+            raise RuntimeError("stack expects a non-empty TensorList")  # what torch.stack([]) raises in the reference
+        out["matches0"].append(r.matches0[b, :n][None])
+        out["matches1"].append(r.matches1[b, :m][None])
+        out["matching_scores0"].append(r.scores0[b, :n][None])
+        out["matching_scores1"].append(r.scores1[b, :m][None])
+        out["matched_kpts0"].append(r.mk0[b, :M, :cols])
+        out["matched_kpts1"].append(r.mk1[b, :M, :cols])
+        out["log_assignment"].append(None if r.la is None else r.la[b, :n + 1, :m + 1][None])
+    return out

@@ -1,0 +1,190 @@
+"""LightGlue matcher, native on MI355X (csrc/lightglue.hip).
+
+Drop-in for LightGlue (reference core/modules/matchers/lightglue.py:421-716), inference path:
+same `conf` handling (merged over `default_conf`), same parameter tree (`posenc.Wr`,
+`transformers.{i}.self_attn|cross_attn.*`, `log_assignment.{i}.*`, `token_confidence.{i}.*`,
+optional `input_proj`) and the same output dict.  Training-only members (loss, NLLLoss,
+matcher_metrics, token-confidence loss; :17-133, :190-203, :751-800) are out of scope.
+Early stopping / point pruning are commented out in the reference (:606-652) and absent here.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .... import _lib
+from .... import _native as N
+from ._batched import from_feats, materialize_matches
+
+
+class _Conf(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _merge(base, over):
+    out = _Conf(base)
+    for k in (over.keys() if hasattr(over, "keys") else []):
+        out[k] = over[k]
+    return out
+
+
+class LearnableFourierPositionalEncoding(nn.Module):
+    def __init__(self, M, dim, F_dim=None, gamma=1.0):
+        super().__init__()
+        F_dim = F_dim if F_dim is not None else dim
+        self.gamma = gamma
+        self.Wr = nn.Linear(M, F_dim // 2, bias=False)
+        nn.init.normal_(self.Wr.weight.data, mean=0, std=self.gamma ** -2)
+
+
+def _ffn(d):
+    return nn.Sequential(nn.Linear(2 * d, 2 * d), nn.LayerNorm(2 * d, elementwise_affine=True), nn.GELU(), nn.Linear(2 * d, d))
+
+
+class SelfBlock(nn.Module):
+    def __init__(self, embed_dim, num_heads, flash=False, bias=True):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.ffn = _ffn(embed_dim)
+
+
+class CrossBlock(nn.Module):
+    def __init__(self, embed_dim, num_heads, flash=False, bias=True):
+        super().__init__()
+        self.heads = num_heads
+        self.to_qk = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.to_v = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.to_out = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.ffn = _ffn(embed_dim)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.self_attn = SelfBlock(*args, **kwargs)
+        self.cross_attn = CrossBlock(*args, **kwargs)
+
+
+class MatchAssignment(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.matchability = nn.Linear(dim, 1, bias=True)
+        self.final_proj = nn.Linear(dim, dim, bias=True)
+
+
+class TokenConfidence(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.token = nn.Sequential(nn.Linear(dim, 1), nn.Sigmoid())
+
+
+class LightGlue(nn.Module):
+    default_conf = {
+        "name": "lightglue", "input_dim": 256, "add_scale_ori": False, "descriptor_dim": 256, "n_layers": 9, "num_heads": 4,
+        "flash": False, "mp": False, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0,
+        "checkpointed": False, "weights": "superpoint", "weights_from_version": "v0.1_arxiv",
+        "loss": {"gamma": 1.0, "fn": "nll", "nll_balancing": 0.5},
+    }
+
+    def __init__(self, conf):
+        super().__init__()
+        self.conf = conf = _merge(self.default_conf, conf)
+        if conf.add_scale_ori:
+            raise NotImplementedError("einx LightGlue: add_scale_ori is not used by EI-Nexus")
+        if conf.num_heads * 64 != conf.descriptor_dim:
+            raise NotImplementedError("einx LightGlue kernels are built for 64-wide heads")
+        if conf.input_dim != conf.descriptor_dim:
+            self.input_proj = nn.Linear(conf.input_dim, conf.descriptor_dim, bias=True)
+        else:
+            self.input_proj = nn.Identity()
+        head_dim = conf.descriptor_dim // conf.num_heads
+        self.posenc = LearnableFourierPositionalEncoding(2, head_dim, head_dim)
+        h, n, d = conf.num_heads, conf.n_layers, conf.descriptor_dim
+        self.transformers = nn.ModuleList([TransformerLayer(d, h, conf.flash) for _ in range(n)])
+        self.log_assignment = nn.ModuleList([MatchAssignment(d) for _ in range(n)])
+        self.token_confidence = nn.ModuleList([TokenConfidence(d) for _ in range(n - 1)])
+        self.want_log_assignment = True
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def refresh(self):
+        self._packed = None
+
+    def _pack(self):
+        """ctypes image of the parameter pointers (weights stay in their nn.Parameter storage)."""
+        if self._packed is not None:
+            return self._packed
+        c = self.conf
+        keep = []
+
+        def p(t):
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
+                raise RuntimeError("einx LightGlue: parameters must be contiguous fp32 tensors on a HIP device")
+            keep.append(t)
+            return t.data_ptr()
+
+        layers = (_lib.LgLayer * c.n_layers)()
+        for i, tl in enumerate(self.transformers):
+            s, x, L = tl.self_attn, tl.cross_attn, layers[i]
+            L.Wqkv, L.bqkv, L.Wo, L.bo = p(s.Wqkv.weight), p(s.Wqkv.bias), p(s.out_proj.weight), p(s.out_proj.bias)
+            L.sf0_w, L.sf0_b, L.sln_g, L.sln_b = p(s.ffn[0].weight), p(s.ffn[0].bias), p(s.ffn[1].weight), p(s.ffn[1].bias)
+            L.sf3_w, L.sf3_b = p(s.ffn[3].weight), p(s.ffn[3].bias)
+            L.Wqk, L.bqk, L.Wv, L.bv = p(x.to_qk.weight), p(x.to_qk.bias), p(x.to_v.weight), p(x.to_v.bias)
+            L.Wco, L.bco = p(x.to_out.weight), p(x.to_out.bias)
+            L.cf0_w, L.cf0_b, L.cln_g, L.cln_b = p(x.ffn[0].weight), p(x.ffn[0].bias), p(x.ffn[1].weight), p(x.ffn[1].bias)
+            L.cf3_w, L.cf3_b = p(x.ffn[3].weight), p(x.ffn[3].bias)
+        w = _lib.LgWeights()
+        if isinstance(self.input_proj, nn.Linear):
+            w.in_w, w.in_b = p(self.input_proj.weight), p(self.input_proj.bias)
+        else:
+            w.in_w, w.in_b = None, None
+        la = self.log_assignment[c.n_layers - 1]
+        w.Wr = p(self.posenc.Wr.weight)
+        w.proj_w, w.proj_b = p(la.final_proj.weight), p(la.final_proj.bias)
+        w.match_w, w.match_b = p(la.matchability.weight), p(la.matchability.bias)
+        w.n_layers, w.heads, w.d, w.input_dim = c.n_layers, c.num_heads, c.descriptor_dim, c.input_dim
+        w.filter_threshold = float(c.filter_threshold)
+        w.layers = ctypes.cast(layers, ctypes.POINTER(_lib.LgLayer))
+        self._packed = (w, layers, keep)
+        return self._packed
+
+    def match_batched(self, pb0, pb1):
+        if pb0.desc.shape[-1] != self.conf.input_dim or pb1.desc.shape[-1] != self.conf.input_dim:
+            raise AssertionError("descriptor dimension does not match conf.input_dim")
+        w = self._pack()[0]
+        r = N.lightglue(w, pb0, pb1, want_la=self.want_log_assignment, want_ref=True)
+        return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 2)
+
+    @torch.no_grad()
+    def forward(self, feats0, feats1):
+        pb0, pb1 = from_feats(feats0), from_feats(feats1)
+        r = self.match_batched(pb0, pb1)
+        nm = r.nmatch.cpu().tolist()
+        n = pb0.counts_host or pb0.counts.cpu().tolist()
+        m = pb1.counts_host or pb1.counts.cpu().tolist()
+        lists = materialize_matches(r, n, m, nm, 2)
+        if pb0.B != 1:
+            raise NotImplementedError("einx LightGlue.forward mirrors the reference's per-pair (B=1) call; use Matcher for batches")
+        out = {k: v[0] for k, v in lists.items()}
+        if n[0] and m[0]:
+            d = self.conf.descriptor_dim
+            out["ref_descriptors0"] = r.ref0[0, :n[0]][None, None]
+            out["ref_descriptors1"] = r.ref1[0, :m[0]][None, None]
+            out["prune0"] = torch.ones_like(out["matching_scores0"]) * self.conf.n_layers
+            out["prune1"] = torch.ones_like(out["matching_scores1"]) * self.conf.n_layers
+        return out

@@ -1,0 +1,388 @@
+// conv.hip -- fused convolution blocks for the SuperPoint / VGG / SiLK encoders on gfx950.
+//
+// One kernel = Conv2d(3x3 pad 1 | 1x1) + bias -> [ReLU] -> [BN(eval) affine] -> [MaxPool 2x2],
+// as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+//   M = output channels (A operand = weights), N = pixels of a TH x TW spatial tile
+//   (B operand = im2col patches read straight out of an LDS halo tile), K = (ci>>1, tap, ci&1).
+// K is walked in that single fixed order with ONE accumulator chain per output, so every output
+// is bit-for-bit the k-ordered fmaf chain of oracle/einx_oracle.c::orc_conv_block.
+//
+// Why this shape (see DESIGN.md "K1"): fp32 MFMA issues every 64 cycles per SIMD, so one
+// ds_read_b32 per operand per MFMA is far below the LDS roof; pixels sit on the MFMA column
+// (= lane) index so NCHW stores are 128-byte coalesced; the next chunk's global loads are
+// issued into registers before the current chunk's 144 MFMAs (issue-early / write-late).
+//
+// Replaces (reference file:line): core/modules/net/vgg.py:34-38, net/backbone.py:105-128,
+// net/detector_head.py:42-48, net/descriptor_head.py:40-43,
+// image_extractors/superpoint_extractor.py:388-406, silk/backbones/superpoint/vgg.py:284-290,
+// utils/util.py:17-32 (replicate pad folded into the first layer's addressing).
+#include "einx_common.h"
+
+namespace {
+
+constexpr int kCoutTile = 64;  // output channels per workgroup (2 MFMA M-tiles)
+constexpr int kMT = 2;
+constexpr int kNT = 2;
+
+struct ConvArgs {
+  const float* in;
+  const float* w;  // native [K][CoutPad]
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  float* out;
+  int B, Cin, Cout, CoutPad;
+  int Hs, Ws, h0, w0;  // source tensor geometry (replicate-pad fold)
+  int H, W;            // logical input size == conv output size
+  int tilesX, tilesY;
+  int relu;
+};
+
+template <int KS>
+struct ChunkOf {
+  static constexpr int value = (KS == 3) ? 8 : 32;  // input channels staged per LDS round
+};
+
+// KS: 1|3.  TH x TW: spatial tile (KS==1: flat run of TH*TW pixels).  NW waves of 64 lanes,
+// each owning kNT N-tiles of 32 pixels.  POOL: fuse MaxPool2d(2,2).
+template <int KS, int TH, int TW, int NW, bool POOL>
+__global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
+  constexpr int TAPS = KS * KS;
+  constexpr int HALO = KS / 2;
+  constexpr int PW = TW + 2 * HALO;
+  constexpr int PH = TH + 2 * HALO;
+  constexpr int PLANE = PH * PW;
+  constexpr int CK = ChunkOf<KS>::value;
+  constexpr int NTHR = NW * 64;
+  constexpr int NPIX = TH * TW;
+  static_assert(NW * kNT * 32 >= NPIX, "tile does not fit the workgroup's pixel slots");
+  constexpr int IN_ELEMS = CK * PLANE;
+  constexpr int IN_PER_THR = (IN_ELEMS + NTHR - 1) / NTHR;
+  constexpr int W_ROWS = CK * TAPS;
+  constexpr int W_F4 = W_ROWS * kCoutTile / 4;
+  constexpr int W_PER_THR = (W_F4 + NTHR - 1) / NTHR;
+  constexpr int POOL_ELEMS = POOL ? 32 * NPIX : 0;
+  constexpr int LDS_FLOATS = (IN_ELEMS + W_ROWS * kCoutTile) > POOL_ELEMS ? (IN_ELEMS + W_ROWS * kCoutTile) : POOL_ELEMS;
+
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* in_tile = lds;
+  float* w_tile = lds + IN_ELEMS;  // IN_ELEMS is a multiple of 4 for every instantiation
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int j = lane & 31;
+
+  int bid = blockIdx.x;
+  const int tx_i = bid % a.tilesX;
+  bid /= a.tilesX;
+  const int ty_i = bid % a.tilesY;
+  const int b = bid / a.tilesY;
+  const int co0 = blockIdx.y * kCoutTile;
+
+  const int HW = a.H * a.W;
+  int y0, x0, p0;
+  if (KS == 1) {
+    p0 = tx_i * NPIX;  // flat pixel run
+    y0 = x0 = 0;
+  } else {
+    y0 = ty_i * TH;
+    x0 = tx_i * TW;
+    p0 = 0;
+  }
+
+  // ---- per-lane pixel bookkeeping -------------------------------------------------------
+  int bBase[kNT];
+  int opix[kNT];  // output offset within a channel plane, or -1
+  int qidx[kNT];
+#pragma unroll
+  for (int nt = 0; nt < kNT; ++nt) {
+    const int q = (wave * kNT + nt) * 32 + j;
+    const bool vq = q < NPIX;
+    qidx[nt] = vq ? q : -1;
+    if (KS == 1) {
+      bBase[nt] = half * PLANE + (vq ? q : 0);
+      const int p = p0 + q;
+      opix[nt] = (vq && p < HW) ? p : -1;
+    } else {
+      const int ty = vq ? q / TW : 0, tx = vq ? q % TW : 0;
+      bBase[nt] = half * PLANE + ty * PW + tx;
+      const int y = y0 + ty, x = x0 + tx;
+      opix[nt] = (vq && y < a.H && x < a.W) ? y * a.W + x : -1;
+    }
+  }
+  const int aBase = half * kCoutTile + j;
+
+  // ---- staging plan: which global words this thread brings in each round -----------------
+  const size_t src_plane = (size_t)a.Hs * a.Ws;
+  const float* in_b = a.in + (size_t)b * a.Cin * src_plane;
+  int g_off[IN_PER_THR];  // offset inside a source channel plane, -1 = structural zero
+  int g_ci[IN_PER_THR];
+#pragma unroll
+  for (int i = 0; i < IN_PER_THR; ++i) {
+    const int e = tid + i * NTHR;
+    int off = -1, cil = 0;
+    if (e < IN_ELEMS) {
+      cil = e / PLANE;
+      const int r = e % PLANE;
+      if (KS == 1) {
+        const int p = p0 + r;
+        if (p < HW) off = p;  // 1x1 layers never carry the replicate fold
+      } else {
+        const int y = y0 - HALO + r / PW, x = x0 - HALO + r % PW;
+        if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+          int sy = y - a.h0, sx = x - a.w0;
+          sy = sy < 0 ? 0 : (sy > a.Hs - 1 ? a.Hs - 1 : sy);
+          sx = sx < 0 ? 0 : (sx > a.Ws - 1 ? a.Ws - 1 : sx);
+          off = sy * a.Ws + sx;
+        }
+      }
+    }
+    g_off[i] = off;
+    g_ci[i] = cil;
+  }
+
+  f32x16 acc[kMT][kNT];
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  const int pairs_total = (a.Cin + 1) / 2;
+  const int nchunks = (pairs_total * 2 + CK - 1) / CK;
+  const int k_rows_total = pairs_total * 2 * TAPS;
+
+  float r_in[IN_PER_THR];
+  f32x4 r_w[W_PER_THR];
+
+  auto issue_loads = [&](int c) {
+    const int ci0 = c * CK;
+#pragma unroll
+    for (int i = 0; i < IN_PER_THR; ++i) {
+      const int ci = ci0 + g_ci[i];
+      float v = 0.0f;
+      if (g_off[i] >= 0 && ci < a.Cin) v = in_b[(size_t)ci * src_plane + g_off[i]];
+      r_in[i] = v;
+    }
+    const int krow0 = c * W_ROWS;
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i) {
+      const int f = tid + i * NTHR;
+      const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (f < W_F4 && krow0 + r < k_rows_total)
+        v = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + r) * a.CoutPad + co0 + c4 * 4);
+      r_w[i] = v;
+    }
+  };
+  auto commit_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < IN_PER_THR; ++i) {
+      const int e = tid + i * NTHR;
+      if (e < IN_ELEMS) in_tile[e] = r_in[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i) {
+      const int f = tid + i * NTHR;
+      if (f < W_F4) *reinterpret_cast<f32x4*>(w_tile + f * 4) = r_w[i];
+    }
+  };
+
+  issue_loads(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // previous round's LDS reads are done
+    commit_loads();
+    __syncthreads();
+    if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under the MFMAs below
+#pragma unroll
+    for (int kp = 0; kp < CK / 2; ++kp) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int ky = tap / KS, kx = tap % KS;
+        float av[kMT], bv[kNT];
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) av[mt] = w_tile[aBase + (kp * TAPS + tap) * 2 * kCoutTile + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) bv[nt] = in_tile[bBase[nt] + kp * 2 * PLANE + ky * PW + kx];
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < kNT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store -------------------------
+  const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
+  float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt) {
+    if (POOL) __syncthreads();  // LDS free (main loop / previous M-tile's pooled reads done)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int crow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int co = co0 + mt * 32 + crow;
+      const bool cv = co < a.Cout;
+      const float bi = (cv && a.bias) ? a.bias[co] : 0.0f;
+      const float sc = (cv && a.scale) ? a.scale[co] : 1.0f;
+      const float sh = (cv && a.scale) ? a.shift[co] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < kNT; ++nt) {
+        float v = acc[mt][nt][r] + bi;
+        if (a.relu) v = v > 0.0f ? v : 0.0f;
+        if (a.scale) v = fmaf(v, sc, sh);
+        if (POOL) {
+          if (qidx[nt] >= 0) lds[crow * NPIX + qidx[nt]] = v;
+        } else {
+          if (cv && opix[nt] >= 0) out_b[(size_t)co * HW + opix[nt]] = v;
+        }
+      }
+    }
+    if (POOL) {
+      __syncthreads();
+      constexpr int PHo = TH / 2, PWo = TW / 2;
+      for (int idx = tid; idx < 32 * PHo * PWo; idx += NTHR) {
+        const int c = idx / (PHo * PWo);
+        const int rem = idx % (PHo * PWo);
+        const int py = rem / PWo, px = rem % PWo;
+        const int co = co0 + mt * 32 + c;
+        const int yo = y0 / 2 + py, xo = x0 / 2 + px;
+        if (co < a.Cout && yo < Ho && xo < Wo) {
+          const float* s = lds + c * NPIX + (2 * py) * TW + 2 * px;
+          const float m0 = fmaxf(s[0], s[1]);
+          const float m1 = fmaxf(s[TW], s[TW + 1]);
+          out_b[((size_t)co * Ho + yo) * Wo + xo] = fmaxf(m0, m1);
+        }
+      }
+    }
+  }
+}
+
+// OIHW -> native [K][CoutPad], K = (ci>>1)*2*taps + tap*2 + (ci&1); zero padded.
+__global__ void conv_repack_kernel(const float* w, int cin, int cout, int taps, int coutPad, int krows, float* out) {
+  const size_t n = (size_t)krows * coutPad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % coutPad);
+    const int k = (int)(i / coutPad);
+    const int h = k & 1;
+    const int tap = (k >> 1) % taps;
+    const int cp = (k >> 1) / taps;
+    const int ci = 2 * cp + h;
+    float v = 0.0f;
+    if (ci < cin && co < cout) v = w[((size_t)co * cin + ci) * taps + tap];
+    out[i] = v;
+  }
+}
+
+struct TileCfg {
+  int th, tw, nw;
+};
+
+template <int KS, int TH, int TW, int NW, bool POOL>
+void launch(const ConvArgs& a, int B, hipStream_t s) {
+  dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
+  hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, NW, POOL>), grid, dim3(NW * 64), 0, s, a);
+}
+
+// waste = slots launched / pixels useful, for picking a tile shape per layer
+double tile_waste(int H, int W, int th, int tw, int nw) {
+  const double tiles = (double)einx_cdiv(H, th) * einx_cdiv(W, tw);
+  return tiles * nw * kNT * 32 / ((double)H * W);
+}
+
+}  // namespace
+
+EINX_EXPORT size_t einx_conv_weight_elems(int cin, int cout, int ks) {
+  const int taps = ks * ks;
+  const int pairs = (cin + 1) / 2;
+  const int coutPad = einx_cdiv(cout, kCoutTile) * kCoutTile;
+  return (size_t)pairs * 2 * taps * coutPad;
+}
+
+EINX_EXPORT int einx_conv_repack(const float* w_oihw, int cin, int cout, int ks, float* w_native, void* stream) {
+  EINX_CHECK_ARG(w_oihw && w_native, "null pointer");
+  EINX_CHECK_ARG(ks == 1 || ks == 3, "kernel size must be 1 or 3");
+  EINX_CHECK_ARG(cin > 0 && cout > 0, "bad channel count");
+  const int taps = ks * ks;
+  const int coutPad = einx_cdiv(cout, kCoutTile) * kCoutTile;
+  const int krows = ((cin + 1) / 2) * 2 * taps;
+  const size_t n = (size_t)krows * coutPad;
+  const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(conv_repack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cin, cout, taps, coutPad, krows,
+                     w_native);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d,
+                                float* out, void* stream) {
+  EINX_CHECK_ARG(in && out && d && d->w_native, "null pointer");
+  EINX_CHECK_ARG(d->ks == 1 || d->ks == 3, "kernel size must be 1 or 3");
+  EINX_CHECK_ARG(B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && d->cin > 0 && d->cout > 0, "bad shape");
+  EINX_CHECK_ARG((d->scale == nullptr) == (d->shift == nullptr), "scale and shift go together");
+  EINX_CHECK_ARG(!d->pool || (H % 2 == 0 && W % 2 == 0), "pooling needs even H and W");
+  EINX_CHECK_ARG(d->ks == 3 || (Hs == H && Ws == W && h0 == 0 && w0 == 0), "1x1 layers take no padding fold");
+  EINX_CHECK_ARG(d->ks == 3 || !d->pool, "pooled 1x1 not supported");
+  EINX_CHECK_ARG((size_t)H * W < (1u << 30) && (size_t)Hs * Ws < (1u << 30), "image too large");
+  hipStream_t s = (hipStream_t)stream;
+  ConvArgs a;
+  a.in = in;
+  a.w = d->w_native;
+  a.bias = d->bias;
+  a.scale = d->scale;
+  a.shift = d->shift;
+  a.out = out;
+  a.B = B;
+  a.Cin = d->cin;
+  a.Cout = d->cout;
+  a.CoutPad = einx_cdiv(d->cout, kCoutTile) * kCoutTile;
+  a.Hs = Hs;
+  a.Ws = Ws;
+  a.h0 = h0;
+  a.w0 = w0;
+  a.H = H;
+  a.W = W;
+  a.relu = d->relu;
+  if (d->ks == 1) {
+    a.tilesX = einx_cdiv(H * W, 256);
+    a.tilesY = 1;
+    launch<1, 1, 256, 4, false>(a, B, s);
+    EINX_CHECK_LAUNCH();
+    return EINX_OK;
+  }
+  // candidate tile shapes: (8,32)x4 waves, (12,16)x3, (22,8)x3, (11,22)x4; pooled layers need
+  // even tile dims so that every 2x2 window lives inside one tile.
+  static const TileCfg cfgs[4] = {{8, 32, 4}, {12, 16, 3}, {22, 8, 3}, {11, 22, 4}};
+  int best = 0;
+  double bw = 1e30;
+  for (int i = 0; i < 4; ++i) {
+    if (d->pool && ((cfgs[i].th & 1) || (cfgs[i].tw & 1))) continue;
+    const double wst = tile_waste(H, W, cfgs[i].th, cfgs[i].tw, cfgs[i].nw);
+    if (wst < bw - 1e-9) {
+      bw = wst;
+      best = i;
+    }
+  }
+  a.tilesX = einx_cdiv(W, cfgs[best].tw);
+  a.tilesY = einx_cdiv(H, cfgs[best].th);
+  if (d->pool) {
+    switch (best) {
+      case 0: launch<3, 8, 32, 4, true>(a, B, s); break;
+      case 1: launch<3, 12, 16, 3, true>(a, B, s); break;
+      default: launch<3, 22, 8, 3, true>(a, B, s); break;
+    }
+  } else {
+    switch (best) {
+      case 0: launch<3, 8, 32, 4, false>(a, B, s); break;
+      case 1: launch<3, 12, 16, 3, false>(a, B, s); break;
+      case 2: launch<3, 22, 8, 3, false>(a, B, s); break;
+      default: launch<3, 11, 22, 4, false>(a, B, s); break;
+    }
+  }
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}

@@ -1,0 +1,431 @@
+// detect.hip -- keypoint detector post-processing on gfx950: score map, NMS fix-point,
+// top-k quantile threshold (radix select), raster-order compaction.  All integer/compare work:
+// results are bit-exact with oracle/einx_oracle.c (and hence with the reference's golden
+// vectors); no host synchronisation anywhere in the chain.
+//
+// Replaces (reference file:line): core/modules/utils/detector_util.py:18-77 (logits_to_prob,
+// depth_to_space), :138-164 (remove_border_points), :243-337 (fast_nms), :80-135
+// (prob_map_to_points_map: quantile threshold), :451-484 (prob_map_to_positions_with_prob),
+// core/modules/event_extractors/EventExtractors.py:544-550,561-562 (mask dilation + apply),
+// core/modules/utils/util.py:52-66 (unpad_positions), EventExtractors.py:496-515 (filter).
+#include "einx_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K3: one thread per cell (C==65) or per pixel (C==1).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool mask_on(const uint8_t* mask, int b, int H, int W, int h0, int w0, int Hp, int Wp, int y, int x,
+                                        int dilate) {
+  // mask zero-padded to [Hp,Wp]; optional 3x3 dilation evaluated inside the padded map
+  const int r = dilate ? 1 : 0;
+  for (int dy = -r; dy <= r; ++dy)
+    for (int dx = -r; dx <= r; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= Hp || xx < 0 || xx >= Wp) continue;
+      const int sy = yy - h0, sx = xx - w0;
+      if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+      if (mask[((size_t)b * H + sy) * W + sx]) return true;
+    }
+  return false;
+}
+
+__global__ void score65_kernel(const float* logits, int B, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0,
+                               int dilate, int border, float* prob, float* score) {
+  const int cells = hc * wc;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * cells) return;
+  const int b = gid / cells, cell = gid % cells;
+  const int h = cell / wc, w = cell % wc;
+  const float* l = logits + (size_t)b * 65 * cells + cell;
+  float mx = l[0];
+  for (int c = 1; c < 65; ++c) mx = fmaxf(mx, l[(size_t)c * cells]);
+  float s = 0.0f;
+  for (int c = 0; c < 65; ++c) s = s + einx_expf(l[(size_t)c * cells] - mx);
+  const int Hp = hc * 8, Wp = wc * 8;
+  float* pr = prob + (size_t)b * 65 * cells + cell;
+  for (int c = 0; c < 65; ++c) {
+    const float p = einx_expf(l[(size_t)c * cells] - mx) / s;
+    pr[(size_t)c * cells] = p;
+    if (c < 64) {
+      const int y = h * 8 + (c >> 3), x = w * 8 + (c & 7);
+      float v = p;
+      if (mask && !mask_on(mask, b, H, W, h0, w0, Hp, Wp, y, x, dilate)) v = 0.0f;
+      if (border > 0 && (y < border || y >= Hp - border || x < border || x >= Wp - border)) v = 0.0f;
+      score[((size_t)b * Hp + y) * Wp + x] = v;
+    }
+  }
+}
+
+__global__ void score1_kernel(const float* logits, int B, int Hp, int Wp, const uint8_t* mask, int H, int W, int h0, int w0,
+                              int dilate, int border, float* prob, float* score) {
+  const int n = Hp * Wp;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * n) return;
+  const int b = gid / n, p = gid % n;
+  const int y = p / Wp, x = p % Wp;
+  float v = einx_sigmoidf(logits[gid]);
+  if (mask && !mask_on(mask, b, H, W, h0, w0, Hp, Wp, y, x, dilate)) v = 0.0f;
+  if (border > 0 && (y < border || y >= Hp - border || x < border || x >= Wp - border)) v = 0.0f;
+  prob[gid] = v;  // the reference's score aliases probability for cell-1 networks
+  score[gid] = v;
+}
+
+__global__ void border_kernel(float* score, int B, int Hp, int Wp, int border) {
+  const int n = Hp * Wp;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * n) return;
+  const int p = gid % n;
+  const int y = p / Wp, x = p % Wp;
+  if (y < border || y >= Hp - border || x < border || x >= Wp - border) score[gid] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: one suppression pass of fast_nms.  Tile 16x64 with halo 2R; LDS holds values and the
+// is-max bitmap.  A pass for image b runs only while the previous pass changed that image
+// (flags[b][it-1]); it raises flags[b][it] if it zeroes any non-zero pixel.  When a pass changes
+// nothing src == dst, so skipped passes leave both ping-pong buffers holding the fix-point.
+// ------------------------------------------------------------------------------------------
+constexpr int NMS_TH = 16, NMS_TW = 64, NMS_MAXR = 4;
+
+template <int R>
+__global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
+                                                       int32_t* flags, int it, int nIt) {
+  constexpr int VH = NMS_TH + 4 * R, VW = NMS_TW + 4 * R;  // values: tile + halo 2R
+  constexpr int MH = NMS_TH + 2 * R, MW = NMS_TW + 2 * R;  // is-max: tile + halo R
+  __shared__ float vals[VH * VW];
+  __shared__ uint8_t ismax[MH * MW];
+  __shared__ int changed;
+  int bid = blockIdx.x;
+  const int txi = bid % tilesX;
+  bid /= tilesX;
+  const int tyi = bid % tilesY;
+  const int b = bid / tilesY;
+  // passes 0 and 1 always run so that BOTH ping-pong buffers hold image b; from then on a pass
+  // is skipped once the previous one changed nothing (fix-point reached).
+  if (it >= 2 && flags[b * nIt + it - 1] == 0) return;
+  const float* s = src + (size_t)b * Hp * Wp;
+  float* d = dst + (size_t)b * Hp * Wp;
+  const int y0 = tyi * NMS_TH, x0 = txi * NMS_TW;
+  const int tid = threadIdx.x;
+  if (tid == 0) changed = 0;
+  for (int i = tid; i < VH * VW; i += 256) {
+    const int y = y0 - 2 * R + i / VW, x = x0 - 2 * R + i % VW;
+    vals[i] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? s[(size_t)y * Wp + x] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = tid; i < MH * MW; i += 256) {
+    const int my = i / MW, mx = i % MW;  // position in the is-max grid
+    const int vy = my + R, vx = mx + R;  // same pixel in vals
+    const float c = vals[vy * VW + vx];
+    bool ok = c > 0.0f;  // a zero centre never wins: window tap 0 is >= 0
+    // pixels outside the image are not candidates
+    const int y = y0 - R + my, x = x0 - R + mx;
+    ok = ok && y >= 0 && y < Hp && x >= 0 && x < Wp;
+    if (ok) {
+      for (int dy = -R; dy <= R && ok; ++dy)
+        for (int dx = -R; dx <= R; ++dx) {
+          if (dy == 0 && dx == 0) continue;
+          const float v = vals[(vy + dy) * VW + vx + dx];
+          const bool earlier = (dy < 0) || (dy == 0 && dx < 0);
+          if (earlier ? !(v < c) : !(v <= c)) {
+            ok = false;
+            break;
+          }
+        }
+    }
+    ismax[i] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  int my_changed = 0;
+  for (int i = tid; i < NMS_TH * NMS_TW; i += 256) {
+    const int ty = i / NMS_TW, tx = i % NMS_TW;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= Hp || x >= Wp) continue;
+    const float c = vals[(ty + 2 * R) * VW + tx + 2 * R];
+    float o = c;
+    if (c != 0.0f) {
+      bool sup = false;
+      for (int dy = -R; dy <= R && !sup; ++dy)
+        for (int dx = -R; dx <= R; ++dx) {
+          if (dy == 0 && dx == 0) continue;
+          if (ismax[(ty + R + dy) * MW + tx + R + dx]) {
+            sup = true;
+            break;
+          }
+        }
+      if (sup) {
+        o = 0.0f;
+        my_changed = 1;
+      }
+    }
+    d[(size_t)y * Wp + x] = o;
+  }
+  if (my_changed) changed = 1;
+  __syncthreads();
+  if (tid == 0 && changed) atomicOr(&flags[b * nIt + it], 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: per image one 1024-thread workgroup: radix select of the order statistics
+// sorted[lo], sorted[hi] (ascending), thr = min(b - (b-a)*0.5, det_thr), then raster-order
+// stream compaction of (v > thr) with wave ballots.
+// ------------------------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+
+struct SelArgs {
+  const float* map;  // [B,Hp,Wp] NMS output
+  const int32_t* flags;
+  float* nms_out;  // [B,H,W] or null
+  float* positions;
+  int32_t* indices;
+  int32_t* counts;
+  float* thr_out;
+  int32_t* not_converged;
+  int Hp, Wp, H, W, h0, w0;
+  int top_k, lo, hi, cap, ordering_xy, nIt;
+  float det_thr;
+};
+
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* scratch /*>= 17 ints*/) {
+  // exclusive prefix sum of v over the 1024-thread block (16 waves); scratch in LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) scratch[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < SEL_THREADS / 64; ++w) {
+      const int t = scratch[w];
+      scratch[w] = run;
+      run += t;
+    }
+    scratch[16] = run;
+  }
+  __syncthreads();
+  const int res = scratch[wave] + incl - v;
+  *total = scratch[16];
+  __syncthreads();
+  return res;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ int scratch[17];
+  __shared__ unsigned sh_prefix, sh_rank;
+  __shared__ unsigned sh_minkey;
+  const int b = blockIdx.x;
+  const int N = a.Hp * a.Wp;
+  const float* m = a.map + (size_t)b * N;
+  const int tid = threadIdx.x;
+
+  float thr = a.det_thr;
+  if (a.top_k > 0) {
+    float tk = 0.0f;
+    if (a.top_k < N) {
+      // ---- radix select of the key at ascending rank lo (MSB first, 8 bits per pass) -------
+      unsigned prefix = 0, rank = (unsigned)a.lo;
+      unsigned less_total = 0;  // number of keys strictly below the selected prefix so far
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+        __syncthreads();
+        const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < N; i += SEL_THREADS) {
+          const unsigned k = einx_ordered_key(m[i]);
+          if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned run = 0, r = rank;
+          int dsel = 255;
+          for (int dgt = 0; dgt < 256; ++dgt) {
+            const unsigned c = hist[dgt];
+            if (r < run + c) {
+              dsel = dgt;
+              break;
+            }
+            run += c;
+          }
+          sh_prefix = prefix | ((unsigned)dsel << shift);
+          sh_rank = r - run;
+          hist[0] = run;  // keys below the chosen digit in this pass
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        rank = sh_rank;
+        less_total += hist[0];
+        __syncthreads();
+      }
+      const unsigned key_lo = prefix;
+      const float v_lo = einx_ordered_unkey(key_lo);
+      float v_hi = v_lo;
+      if (a.hi != a.lo) {
+        // count of keys <= key_lo decides whether rank hi still sits on the same value
+        for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+        if (tid == 0) sh_minkey = 0xFFFFFFFFu;
+        __syncthreads();
+        unsigned local_eq = 0, local_min = 0xFFFFFFFFu;
+        for (int i = tid; i < N; i += SEL_THREADS) {
+          const unsigned k = einx_ordered_key(m[i]);
+          if (k == key_lo) ++local_eq;
+          if (k > key_lo && k < local_min) local_min = k;
+        }
+        atomicAdd(&hist[0], local_eq);
+        atomicMin(&sh_minkey, local_min);
+        __syncthreads();
+        const unsigned le = less_total + hist[0];
+        if ((unsigned)a.hi >= le) v_hi = einx_ordered_unkey(sh_minkey);
+        __syncthreads();
+      }
+      tk = v_hi - (v_hi - v_lo) * 0.5f;
+    }
+    thr = fminf(tk, a.det_thr);
+  }
+  if (tid == 0) {
+    a.thr_out[b] = thr;
+    a.not_converged[b] = a.nIt > 0 ? a.flags[b * a.nIt + a.nIt - 1] : 0;
+  }
+
+  // ---- thresholded map (cropped) + raster-order compaction ----------------------------------
+  int base = 0;
+  for (int i0 = 0; i0 < N; i0 += SEL_THREADS) {
+    const int i = i0 + tid;
+    float v = 0.0f;
+    bool keep = false;
+    int y = 0, x = 0;
+    if (i < N) {
+      v = m[i];
+      y = i / a.Wp;
+      x = i % a.Wp;
+      const bool above = v > thr;
+      const int uy = y - a.h0, ux = x - a.w0;
+      const bool inside = uy >= 0 && uy < a.H && ux >= 0 && ux < a.W;
+      if (a.nms_out && inside) a.nms_out[((size_t)b * a.H + uy) * a.W + ux] = above ? v : 0.0f;
+      keep = above && v > 0.0f && inside;
+    }
+    int total;
+    const int pos = base + block_excl_scan(keep ? 1 : 0, &total, scratch);
+    if (keep && pos < a.cap) {
+      const float py = ((float)y + 0.5f) - (float)a.h0, px = ((float)x + 0.5f) - (float)a.w0;
+      float* o = a.positions + ((size_t)b * a.cap + pos) * 3;
+      o[0] = a.ordering_xy ? px : py;
+      o[1] = a.ordering_xy ? py : px;
+      o[2] = v;
+      a.indices[(size_t)b * a.cap + pos] = i;
+    }
+    base += total;
+  }
+  if (tid == 0) a.counts[b] = base;
+}
+
+void topk_ranks(int N, int k, int* lo, int* hi) {
+  // fp32 arithmetic of the reference: q = float32(N-k)/float32(N); rank = q*float32(N-1)
+  const float q = (float)(N - k) / (float)N;
+  const float rank = q * (float)(N - 1);
+  *lo = (int)floorf(rank);
+  *hi = (int)ceilf(rank);
+}
+
+}  // namespace
+
+EINX_EXPORT int einx_score_map(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0,
+                               int dilate, int border, float* prob, float* score, void* stream) {
+  EINX_CHECK_ARG(logits && prob && score, "null pointer");
+  EINX_CHECK_ARG(C == 65 || C == 1, "detector head must have 65 or 1 channels");
+  EINX_CHECK_ARG(B > 0 && hc > 0 && wc > 0, "bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 65) {
+    const int n = B * hc * wc;
+    hipLaunchKernelGGL(score65_kernel, dim3(einx_cdiv(n, 128)), dim3(128), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
+                       prob, score);
+  } else {
+    const int n = B * hc * wc;
+    hipLaunchKernelGGL(score1_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
+                       prob, score);
+  }
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_remove_border(float* score, int B, int Hp, int Wp, int border, void* stream) {
+  EINX_CHECK_ARG(score, "null pointer");
+  if (border <= 0) return EINX_OK;
+  const int n = B * Hp * Wp;
+  hipLaunchKernelGGL(border_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, score, B, Hp, Wp, border);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT size_t einx_detect_ws_bytes(const einx_detect_params* p) {
+  if (!p) return 0;
+  const size_t map = (size_t)p->B * p->Hp * p->Wp * sizeof(float);
+  const size_t flags = (size_t)p->B * (p->nms_iters > 0 ? p->nms_iters : 1) * sizeof(int32_t);
+  return 2 * map + ((flags + 255) & ~(size_t)255) + 256;
+}
+
+EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions,
+                            int32_t* indices, int32_t* counts, float* thr, int32_t* not_converged, void* stream) {
+  EINX_CHECK_ARG(score && p && ws && positions && indices && counts && thr && not_converged, "null pointer");
+  EINX_CHECK_ARG(p->B > 0 && p->Hp > 0 && p->Wp > 0 && p->cap > 0, "bad shape");
+  EINX_CHECK_ARG(p->radius >= 0 && p->radius <= NMS_MAXR, "nms radius must be in 0..4");
+  EINX_CHECK_ARG(p->radius == 0 || p->nms_iters >= 1, "nms_iters must be >= 1");
+  EINX_CHECK_ARG((size_t)p->Hp * p->Wp < (1u << 30), "map too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = p->Hp * p->Wp;
+  const size_t map_bytes = (size_t)p->B * N * sizeof(float);
+  float* buf0 = (float*)ws;
+  float* buf1 = (float*)((char*)ws + map_bytes);
+  int32_t* flags = (int32_t*)((char*)ws + 2 * map_bytes);
+  const float* cur = score;
+  const int nIt = p->radius > 0 ? p->nms_iters : 0;
+  if (nIt > 0) {
+    if (hipMemsetAsync(flags, 0, (size_t)p->B * nIt * sizeof(int32_t), s) != hipSuccess) {
+      einx_set_error("einx_detect: memset failed");
+      return EINX_ERR_LAUNCH;
+    }
+    const int tilesX = einx_cdiv(p->Wp, NMS_TW), tilesY = einx_cdiv(p->Hp, NMS_TH);
+    const dim3 grid((unsigned)(tilesX * tilesY * p->B));
+    for (int it = 0; it < nIt; ++it) {
+      float* dst = (it & 1) ? buf1 : buf0;
+      switch (p->radius) {
+        case 1: hipLaunchKernelGGL(nms_pass_kernel<1>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        case 2: hipLaunchKernelGGL(nms_pass_kernel<2>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        case 3: hipLaunchKernelGGL(nms_pass_kernel<3>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        default: hipLaunchKernelGGL(nms_pass_kernel<4>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+      }
+      EINX_CHECK_LAUNCH();
+      cur = dst;
+    }
+  }
+  SelArgs a;
+  a.map = cur;
+  a.flags = flags;
+  a.nms_out = nms_out;
+  a.positions = positions;
+  a.indices = indices;
+  a.counts = counts;
+  a.thr_out = thr;
+  a.not_converged = not_converged;
+  a.Hp = p->Hp;
+  a.Wp = p->Wp;
+  a.H = p->H;
+  a.W = p->W;
+  a.h0 = p->h0;
+  a.w0 = p->w0;
+  a.top_k = p->top_k;
+  a.cap = p->cap;
+  a.ordering_xy = p->ordering_xy;
+  a.nIt = nIt;
+  a.det_thr = p->det_thr;
+  a.lo = a.hi = 0;
+  if (p->top_k > 0 && p->top_k < N) topk_ranks(N, p->top_k, &a.lo, &a.hi);
+  hipLaunchKernelGGL(select_compact_kernel, dim3(p->B), dim3(SEL_THREADS), 0, s, a);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}

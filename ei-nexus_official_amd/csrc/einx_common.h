@@ -1,0 +1,33 @@
+// Shared helpers for the gfx950 kernels of libeinx_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/einx.h"
+#include "../../include/einx_math.h"
+
+#define EINX_EXPORT extern "C" __attribute__((visibility("default")))
+
+void einx_set_error(const char* fmt, ...);
+
+#define EINX_CHECK_ARG(cond, msg)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      einx_set_error("%s: %s", __func__, msg);    \
+      return EINX_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define EINX_CHECK_LAUNCH()                                                   \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) {                                                   \
+      einx_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+      return EINX_ERR_LAUNCH;                                                 \
+    }                                                                         \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int einx_cdiv(int a, int b) { return (a + b - 1) / b; }

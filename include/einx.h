@@ -1,0 +1,187 @@
+/* einx.h -- C ABI of libeinx_hip.so: the MI355X (gfx950) native implementation of the
+ * EI-Nexus event<->image feature extraction + matching hot path.
+ *
+ * The reference (ZhonghuaYi/EI-Nexus_official) is pure Python/PyTorch and owns no native
+ * layer, so the "FFI" a maintainer would bind is the set of torch op groups its nn.Modules
+ * dispatch.  Each entry point below names the reference code it replaces (file:line relative
+ * to the reference root).  Conventions:
+ *   - plain pointers + sizes; every pointer is DEVICE memory unless it says "host";
+ *   - tensors are dense, fp32, NCHW / row-major, exactly the reference's logical layouts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
+ *   - return 0 on success, negative on error (einx_last_error() gives the text);
+ *   - no allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.
+ * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
+ */
+#ifndef EINX_H
+#define EINX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EINX_OK 0
+#define EINX_ERR_ARG (-1)
+#define EINX_ERR_LAUNCH (-2)
+#define EINX_ERR_NO_DEVICE (-3)
+
+const char* einx_version(void);
+const char* einx_last_error(void);
+/* number of visible HIP devices (0 without a GPU); never initialises a context beyond that */
+int einx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution blocks  (K1/K2 of SURVEY.md 2.3)
+ * replaces: nn.Conv2d(3x3,pad 1 | 1x1) + ReLU + BatchNorm2d(eval) + MaxPool2d(2,2)
+ *   core/modules/net/vgg.py:34-38, core/modules/net/backbone.py:105-128,
+ *   core/modules/net/detector_head.py:42-48, core/modules/net/descriptor_head.py:40-43,
+ *   core/modules/image_extractors/superpoint_extractor.py:388-406,
+ *   core/modules/image_extractors/silk/backbones/superpoint/vgg.py:284-290
+ * and Padder.pad (replicate) folded into the first layer's addressing
+ *   core/modules/utils/util.py:17-32.
+ * ---------------------------------------------------------------------------------------- */
+
+/* floats needed for the kernel-native weight image of one conv (k-major, cout padded to 64) */
+size_t einx_conv_weight_elems(int cin, int cout, int ks);
+/* OIHW fp32 -> kernel-native [K][CoutPad], K ordered (ci>>1, tap, ci&1); runs on `stream` */
+int einx_conv_repack(const float* w_oihw, int cin, int cout, int ks, float* w_native, void* stream);
+
+typedef struct einx_conv_desc {
+  const float* w_native; /* from einx_conv_repack */
+  const float* bias;     /* [cout] or NULL */
+  const float* scale;    /* [cout] BN(eval) gamma/sqrt(var+eps), or NULL (no BN) */
+  const float* shift;    /* [cout] beta - mean*scale, or NULL */
+  int32_t cin, cout, ks; /* ks in {1,3}; padding ks/2, stride 1 */
+  int32_t relu;          /* apply ReLU after bias (before BN, as the reference orders it) */
+  int32_t pool;          /* fuse MaxPool2d(2,2) after BN (H, W must be even) */
+} einx_conv_desc;
+
+/* in:  [B,cin,Hs,Ws] source tensor.  The layer sees a logical [B,cin,H,W] input where
+ *      logical (y,x) = source (clamp(y-h0,0,Hs-1), clamp(x-w0,0,Ws-1))  (replicate padding);
+ *      pass Hs=H, Ws=W, h0=w0=0 for an ordinary layer.
+ * out: [B,cout,H,W] or [B,cout,H/2,W/2] when pool. */
+int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d, float* out,
+                    void* stream);
+
+/* x /= divisor in place (SuperPointv1.forward `image /= 255.0`, superpoint_extractor.py:372) */
+int einx_div_inplace(float* x, size_t n, float divisor, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Detector head post-processing  (K3, K4, K5)
+ * ---------------------------------------------------------------------------------------- */
+
+/* logits_to_prob + depth_to_space + score[~dilate3x3(mask)] = 0 + remove_border_points
+ *   core/modules/utils/detector_util.py:18-77,138-164,
+ *   core/modules/event_extractors/EventExtractors.py:544-550,561-562
+ * logits [B,C,hc,wc], C in {65,1}.  prob [B,C,hc,wc] (C==1: written with the mask/border zeros,
+ * because the reference's score aliases probability there).  score [B,Hp,Wp], Hp=hc*cell.
+ * mask: uint8 [B,H,W] (bool) or NULL; (h0,w0) = top/left padding of the padded map; dilate:
+ * apply the 3x3 dilation (event extractors) or use the mask as is (image extractors). */
+int einx_score_map(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0,
+                   int dilate, int border, float* prob, float* score, void* stream);
+
+/* remove_border_points alone, in place on [B,Hp,Wp] (detector_util.py:138-164) */
+int einx_remove_border(float* score, int B, int Hp, int Wp, int border, void* stream);
+
+typedef struct einx_detect_params {
+  int32_t B, Hp, Wp;     /* padded map */
+  int32_t H, W, h0, w0;  /* unpadded size and top/left padding (Padder) */
+  int32_t radius;        /* nms_radius (0 = no NMS) */
+  int32_t top_k;         /* detection_top_k (0 = none) */
+  float det_thr;         /* detection_threshold */
+  int32_t ordering_xy;   /* 0: (y,x,p)  1: (x,y,p) */
+  int32_t cap;           /* rows available per image in positions/indices */
+  int32_t nms_iters;     /* suppression passes enqueued (>= 1); see not_converged */
+} einx_detect_params;
+
+size_t einx_detect_ws_bytes(const einx_detect_params* p);
+
+/* prob_map_to_points_map (fast_nms fix-point + top-k quantile threshold) +
+ * prob_map_to_positions_with_prob + Padder.unpad_positions + filter_sparse_feats
+ *   core/modules/utils/detector_util.py:80-135,243-337,451-484, core/modules/utils/util.py:52-66,
+ *   core/modules/event_extractors/EventExtractors.py:496-515
+ * score     [B,Hp,Wp]  input (already masked / border-zeroed), not modified
+ * nms_out   [B,H,W]    thresholded NMS map cropped to the unpadded window, or NULL
+ * positions [B,cap,3]  (y+.5-h0, x+.5-w0, p) in raster order
+ * indices   [B,cap]    int32 flat index y*Wp+x in the padded map
+ * counts    [B]        int32 number of keypoints (may exceed cap: only cap rows are written)
+ * thr       [B]        threshold used
+ * not_converged [B]    int32, nonzero if the fix-point needed more than nms_iters passes
+ *                      (caller re-runs with more passes; never observed above 4 at 264x352) */
+int einx_detect(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
+                int32_t* counts, float* thr, int32_t* not_converged, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Descriptor heads post-processing  (K6, K10)
+ * ---------------------------------------------------------------------------------------- */
+
+/* sparsify_low_resolution_descriptors (bilinear=1; descriptor_util.py:74-128) or
+ * sparsify_full_resolution_descriptors (bilinear=0; descriptor_util.py:50-71), then
+ * F.normalize * scale.  raw [B,D,hc,wc]; indices/counts from einx_detect; out [B,cap,D]. */
+int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, const int32_t* indices,
+                     const int32_t* counts, int cap, float scale, float* out, void* stream);
+
+/* normalize_descriptors over channels of a dense map (descriptor_util.py:21-28). [B,D,P] */
+int einx_normalize_map(const float* raw, int B, int D, int P, float scale, float* out, void* stream);
+
+/* upsample_descriptors: bilinear resize to (Hp,Wp) + normalize, written cropped to the
+ * unpadded window [B,D,H,W] (descriptor_util.py:131-138 + Padder.unpad util.py:34-50) */
+int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int h0, int w0, int H, int W,
+                            float scale, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Mutual-nearest-neighbour matcher  (K7)   core/modules/matchers/MNN.py:43-140
+ * desc0 [B,cap0,D], desc1 [B,cap1,D]; n[b], m[b] device int32 counts (<= cap).
+ * matches0 [B,cap0] int64 (-1 = none), matches1 [B,cap1]; scores fp32 0/1.
+ * la: optional [B,cap0+1,cap1+1] log_assignment written at [b, :n+1, :m+1] with row pitch
+ * (cap1+1), or NULL.  ws: einx_mnn_ws_bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t einx_mnn_ws_bytes(int B, int cap0, int cap1);
+int einx_mnn(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
+             void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, void* stream);
+
+/* matched keypoint gather in ascending keypoint-0 order (MNN.py:119-129, lightglue.py:690-698)
+ * kpts0 [B,cap0,3], kpts1 [B,cap1,3]; cols = 3 (MNN) or 2 (LightGlue);
+ * out0/out1 [B,cap0,cols]; nmatch [B] int32. */
+int einx_gather_matches(const float* kpts0, const float* kpts1, const int64_t* matches0, const int32_t* n, int cap0, int cap1,
+                        int B, int cols, float* out0, float* out1, int32_t* nmatch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LightGlue  (K8, K9)   core/modules/matchers/lightglue.py:522-716
+ * ---------------------------------------------------------------------------------------- */
+typedef struct einx_lg_layer {
+  /* SelfBlock (:240-272) */
+  const float *Wqkv, *bqkv, *Wo, *bo, *sf0_w, *sf0_b, *sln_g, *sln_b, *sf3_w, *sf3_b;
+  /* CrossBlock (:275-330) */
+  const float *Wqk, *bqk, *Wv, *bv, *Wco, *bco, *cf0_w, *cf0_b, *cln_g, *cln_b, *cf3_w, *cf3_b;
+} einx_lg_layer;
+
+typedef struct einx_lg_weights {
+  const float* in_w; /* input_proj [d,input_dim] or NULL (Identity) */
+  const float* in_b;
+  const float* Wr;   /* posenc.Wr [32,2] */
+  const float* proj_w; /* log_assignment[last].final_proj [d,d] */
+  const float* proj_b;
+  const float* match_w; /* log_assignment[last].matchability [1,d] */
+  const float* match_b;
+  int32_t n_layers, heads, d, input_dim;
+  float filter_threshold;
+  const einx_lg_layer* layers; /* host array of n_layers */
+} einx_lg_weights;
+
+size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);
+/* kpts [B,cap,3] (first two columns used), desc [B,cap,input_dim], counts device int32.
+ * size0/size1: image sizes (H,W) used by normalize_keypoints (:137-148).
+ * outputs as einx_mnn; scores are exp(max log-assignment) for mutual matches (:402-418);
+ * ref0/ref1: optional [B,cap,d] last-layer descriptors (ref_descriptors), or NULL. */
+int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0, const float* kpts1,
+                   const float* desc1, const int32_t* m, int cap1, int B, float h0, float w0, float h1, float w1, void* ws,
+                   int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, float* ref0, float* ref1,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EINX_H */

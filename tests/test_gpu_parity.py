@@ -1,0 +1,360 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the package and
+hence through the C ABI of libeinx_hip.so; the checker is the CPU oracle (pinned to the reference
+by test_oracle_golden.py) plus the golden vectors themselves.
+
+Bar: bit-exact for keypoint sets / indices / match assignments and -- because the kernels follow
+the oracle's arithmetic order exactly -- also for every fp32 tensor of the extractors; fp32 within
+1e-4 against the reference's golden vectors (BASELINE.json north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, load_pkg, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth
+
+pytestmark = pytest.mark.gpu
+pkg = load_pkg()
+FTOL = 1e-4
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    assert pkg.native.lib().einx_device_count() >= 1
+    yield
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ conv blocks vs oracle (bit exact)
+CONV_SHAPES = [
+    # cin, cout, H, W, ks, relu, bn, pool, fold(h0,w0,Hs,Ws) or None
+    (1, 64, 40, 48, 3, True, False, False, (1, 2, 37, 45)),
+    (5, 64, 40, 48, 3, True, True, False, (1, 2, 37, 45)),
+    (16, 64, 24, 64, 3, True, True, False, None),
+    (64, 64, 40, 64, 3, True, True, True, None),       # tile (8,32) pooled
+    (64, 64, 24, 32, 3, True, False, True, None),      # tile (12,16) pooled
+    (64, 128, 22, 24, 3, True, True, False, None),
+    (128, 128, 44, 16, 3, True, True, True, None),     # tile (22,8) pooled
+    (128, 128, 33, 44, 3, True, True, False, None),    # tile (11,22)
+    (128, 256, 33, 44, 3, True, False, False, None),
+    (256, 65, 33, 44, 1, False, False, False, None),
+    (256, 256, 5, 6, 1, False, True, False, None),
+    (128, 1, 37, 45, 1, False, True, False, None),
+    (6, 7, 9, 10, 3, False, True, False, None),        # ragged everything
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "x".join(str(v) for v in s[:8]))
+def test_conv_block_bit_exact(oracle, shape):
+    cin, cout, H, W, ks, relu, bn, pool, fold = shape
+    seed = 1000 + cin * 7 + cout
+    B = 2
+    Hs, Ws = (fold[2], fold[3]) if fold else (H, W)
+    x = synth.normalish(seed, (B, cin, Hs, Ws))
+    w = synth.synth_param("c.weight", (cout, cin, ks, ks), seed)
+    b = synth.uniform(seed + 1, (cout,), -0.5, 0.5)
+    bnp = None
+    scale = shift = None
+    if bn:
+        g, be = synth.uniform(seed + 2, (cout,), 0.5, 1.5), synth.uniform(seed + 3, (cout,), -0.3, 0.3)
+        mu, var = synth.uniform(seed + 4, (cout,), -0.3, 0.3), synth.uniform(seed + 5, (cout,), 0.5, 1.5)
+        g[0] = -g[0]  # negative gain: BN must stay after ReLU and before the pool
+        scale, shift = oracle.bn_fold(g, be, mu, var)
+        bnp = (_t(g), _t(be), _t(mu), _t(var), 1e-5)
+    xin = x
+    if fold:
+        h0, w0 = fold[0], fold[1]
+        xin = oracle.pad_replicate(x, (w0, W - Ws - w0, h0, H - Hs - h0))
+    exp = oracle.conv_block(xin, w, b, scale, shift, relu=relu, pool=pool)
+    layer = pkg.native.ConvLayer(_t(w), _t(b), bnp, relu=relu, pool=pool)
+    got = layer(_t(x), fold=(fold[0], fold[1], H, W) if fold else None)
+    assert np.array_equal(_np(got), exp)
+
+
+# ------------------------------------------------------------------ detector post-processing
+POST = Golden("post")
+
+
+@pytest.mark.parametrize("name", list(POST.cases))
+def test_post_golden_bit_exact(name):
+    """reference-named helper API -> HIP kernels -> must equal the reference's own outputs."""
+    from importlib import import_module
+    du = import_module(pkg.__name__ + ".core.modules.utils.detector_util")
+    c = POST.cases[name]
+    score = _t(score_map(c))
+    nms = du.prob_map_to_points_map(score, prob_thresh=c["thr"], nms_dist=c["radius"], border_dist=c["border"], use_fast_nms=True,
+                                    top_k=(c["k"] or None))
+    pos = du.prob_map_to_positions_with_prob(nms, threshold=0.0, ordering=c.get("ordering", "yx"))
+    counts = POST[f"{name}.counts"]
+    assert [int(p.shape[0]) for p in pos] == counts.tolist()
+    got = np.concatenate([_np(p) for p in pos], 0)
+    assert np.array_equal(got, POST[f"{name}.positions"])
+    flat = _np(nms).reshape(-1)
+    nz = np.nonzero(flat)[0]
+    assert np.array_equal(nz, POST[f"{name}.nms_idx"])
+    assert np.array_equal(flat[nz], POST[f"{name}.nms_val"])
+    # border removal happened in place on the caller's tensor (reference side effect)
+    assert abs(float(_np(score).astype(np.float64).sum()) - float(POST[f"{name}.score_sum"][0])) < 1e-6 * score.numel()
+
+
+def test_detect_fused_matches_oracle(oracle):
+    """fused einx_detect (NMS + threshold + compaction + unpad/filter) vs the oracle, with padding."""
+    s = synth.uniform01(77, (3, 1, 72, 96)) ** 4
+    pads = (3, 3, 2, 2)
+    sc = s.copy()
+    oracle.mask_border(sc, None, pads, False, 4)
+    exp_nms, exp_pos, exp_idx, exp_thr, iters = oracle.detect_post(sc.copy(), 60, 4, 4, 1.0, pads, "yx")
+    d = pkg.native.detect(_t(sc), top_k=60, radius=4, det_thr=1.0, pads=pads)
+    cnt = _np(d.counts)
+    assert cnt.tolist() == [len(p) for p in exp_pos]
+    assert not _np(d.not_converged).any()
+    for b in range(3):
+        assert np.array_equal(_np(d.positions[b, :cnt[b]]), exp_pos[b])
+        assert np.array_equal(_np(d.indices[b, :cnt[b]]), exp_idx[b])
+    assert np.array_equal(_np(d.thr), exp_thr)
+    assert np.array_equal(_np(d.nms), exp_nms[:, 2:-2, 3:-3])
+
+
+def test_nms_needs_more_passes_is_reported(oracle):
+    """a monotone ramp forces a long suppression chain: few passes must raise the flag, and the
+    helper API must still converge to the oracle's fix-point by re-running with more passes."""
+    from importlib import import_module
+    du = import_module(pkg.__name__ + ".core.modules.utils.detector_util")
+    H, W = 16, 200
+    m = np.zeros((1, H, W), np.float32)
+    m[0, 8, 4:196] = np.linspace(0.1, 0.9, 192, dtype=np.float32)  # strictly increasing along the row
+    exp = m.copy()
+    it = oracle.fast_nms(exp, 4)
+    assert it > 8
+    d = pkg.native.detect(_t(m), top_k=0, radius=4, det_thr=float("-inf"), cap=1, nms_iters=2)
+    assert int(_np(d.not_converged)[0]) != 0
+    got = du.fast_nms(_t(m)[:, None], 4)
+    assert np.array_equal(_np(got)[:, 0], exp)
+
+
+# ------------------------------------------------------------------ descriptors
+DESC = Golden("desc")
+
+
+def test_desc_helpers_vs_golden_and_oracle(oracle):
+    from importlib import import_module
+    from test_oracle_golden import _desc_positions
+    dd = import_module(pkg.__name__ + ".core.modules.utils.descriptor_util")
+    for name in ("low_d32", "low_d256"):
+        c = DESC.cases[name]
+        raw = synth.normalish(c["seed"], (2, c["D"], c["hc"], c["wc"]))
+        Hp, Wp = c["hc"] * 8, c["wc"] * 8
+        idx = _desc_positions(c, 0)
+        pos0 = np.stack([idx // Wp + 0.5, idx % Wp + 0.5, np.zeros(len(idx))], 1).astype(np.float32)
+        out = dd.sparsify_low_resolution_descriptors(_t(raw), [_t(pos0), _t(pos0[:0])], (Hp, Wp), scale_factor=1.0)
+        np.testing.assert_allclose(_np(out[0]), DESC[f"{name}.desc0"], atol=2e-6, rtol=0)
+        assert tuple(out[1].shape) == tuple(DESC[f"{name}.desc1_shape"])
+        exp = oracle.desc_sample_bilinear(raw, [idx, idx[:0]], (Hp, Wp), 1.0)
+        assert np.array_equal(_np(out[0]), exp[0])
+        co = dd.normalize_descriptors(_t(raw), 1.0)
+        assert np.array_equal(_np(co), oracle.normalize_map(raw, 1.0))
+        np.testing.assert_allclose(_np(co), DESC[f"{name}.coarse"], atol=2e-6, rtol=0)
+    c = DESC.cases["full_d128"]
+    raw = synth.normalish(c["seed"], (1, c["D"], c["H"], c["W"]))
+    idx = _desc_positions(c, 0)
+    pos0 = np.stack([idx // c["W"] + 0.5, idx % c["W"] + 0.5, np.zeros(len(idx))], 1).astype(np.float32)
+    out = dd.sparsify_full_resolution_descriptors(_t(raw), (_t(pos0),), scale_factor=torch.tensor(1.41))
+    np.testing.assert_allclose(_np(out[0]), DESC["full_d128.desc0"], atol=2e-6, rtol=0)
+    assert np.array_equal(_np(out[0]), oracle.desc_gather(raw, [idx], 1.41)[0])
+    c = DESC.cases["dense_d16"]
+    raw = synth.normalish(c["seed"], (1, c["D"], c["hc"], c["wc"]))
+    up = dd.upsample_descriptors(_t(raw), (c["hc"] * 8, c["wc"] * 8), 1.0)
+    np.testing.assert_allclose(_np(up), DESC["dense_d16.up"], atol=2e-6, rtol=0)
+    assert np.array_equal(_np(up), oracle.upsample_normalize(raw, (c["hc"] * 8, c["wc"] * 8), 1.0))
+
+
+# ------------------------------------------------------------------ MNN
+MNN = Golden("mnn")
+
+
+@pytest.mark.parametrize("name", list(MNN.cases))
+def test_mnn_vs_golden_and_oracle(oracle, name):
+    c = MNN.cases[name]
+    d0, d1, k0, k1 = mnn_inputs(c)
+    mm = pkg.NearestNeighborMatcher(ratio_thresh=False, distance_thresh=False, mutual_check=True)
+    size = torch.tensor([260, 346])
+    f0 = {"sparse_descriptors": _t(d0)[None], "sparse_positions": _t(k0)[None], "image_size": [size]}
+    f1 = {"sparse_descriptors": _t(d1)[None], "sparse_positions": _t(k1)[None], "image_size": [size]}
+    r = mm(f0, f1)
+    exp = oracle.mnn(d0, d1)
+    assert r["matches0"].dtype == torch.int64 and tuple(r["matches0"].shape) == (1, c["n"])
+    for key, gk in (("matches0", "matches0"), ("matches1", "matches1"), ("matching_scores0", "mscores0"), ("matching_scores1", "mscores1")):
+        assert np.array_equal(_np(r[key])[0], exp[key]), key
+        assert np.array_equal(_np(r[key]), MNN[f"{name}.{gk}"]), key
+    assert np.array_equal(_np(r["matched_kpts0"]), MNN[f"{name}.matched_kpts0"])
+    assert np.array_equal(_np(r["matched_kpts1"]), MNN[f"{name}.matched_kpts1"])
+    la = _np(r["log_assignment"])
+    assert la.shape == (1, c["n"] + 1, c["m"] + 1)
+    np.testing.assert_allclose(la[0], exp["log_assignment"], atol=1e-5, rtol=0)
+    if f"{name}.la" in MNN:
+        np.testing.assert_allclose(la, MNN[f"{name}.la"], atol=2e-5, rtol=0)
+
+
+def test_mnn_empty_and_zero_match_quirks():
+    mm = pkg.NearestNeighborMatcher(False, False, True)
+    size = torch.tensor([260, 346])
+    d = _t(synth.synth_unit_descriptors(3, 4, 256))
+    k = _t(synth.uniform(4, (4, 3), 0, 100))
+    empty = {"sparse_descriptors": d[:0][None], "sparse_positions": k[:0][None], "image_size": [size]}
+    full = {"sparse_descriptors": d[None], "sparse_positions": k[None], "image_size": [size]}
+    r = mm(empty, full)
+    assert tuple(r["matches0"].shape) == (1, 0) and tuple(r["matches1"].shape) == (1, 4)
+    assert tuple(r["matched_kpts0"].shape) == (0, 3) and tuple(r["log_assignment"].shape) == (1, 1, 5)
+
+
+# ------------------------------------------------------------------ whole extractors / EIM
+CONV = Golden("conv")
+E2E = Golden("e2e")
+
+
+def _build(c, G):
+    cfg = pkg.configs.to_attr(c["cfg"])
+    model = pkg.EIM(cfg, device=DEV)
+    sd = state_dict_for(c, G)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("descriptor_scale_factor") for k in missing), (missing, unexpected)
+    return model.eval(), sd
+
+
+def _inputs(c):
+    H, W = c.get("H", 260), c.get("W", 346)
+    ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"], H, W)
+    img = synth.synth_image(c["iseed"], c["B"], H, W)
+    return ev, mask, img
+
+
+def _oracle_feats(oracle, c, sd, ev, mask, img, dense=False):
+    cfg = c["cfg"]
+    et, it = cfg["event_extractor"]["type"], cfg["image_extractor"]["type"]
+    ecfg, icfg = cfg["event_extractor"][et], cfg["image_extractor"][it]
+    ef = oracle.extractor_forward(et, sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=ecfg["detection_top_k"],
+                                  radius=ecfg["nms_radius"], border=ecfg["remove_borders"], det_thr=ecfg["detection_threshold"],
+                                  scale=ecfg["descriptor_scale_factor"], dense=dense)
+    imf = oracle.extractor_forward(it, sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=icfg["detection_top_k"],
+                                   radius=icfg["nms_radius"], border=icfg["remove_borders"], det_thr=icfg["detection_threshold"],
+                                   scale=icfg["descriptor_scale_factor"], dense=dense)
+    return ef, imf
+
+
+def _assert_feats_equal_oracle(got, exp, dense=False):
+    keys = ["backbone_feats", "logits", "raw_descriptors", "probability", "score", "nms"]
+    if "coarse_descriptors" in exp:
+        keys.append("coarse_descriptors")
+    if dense:
+        keys.append("normalized_descriptors")
+    for k in keys:
+        assert np.array_equal(_np(got[k]), exp[k]), f"{k} differs from the oracle"
+    assert [int(p.shape[0]) for p in got["sparse_positions"]] == [len(p) for p in exp["sparse_positions"]]
+    for b in range(len(exp["sparse_positions"])):
+        assert np.array_equal(_np(got["sparse_positions"][b]), exp["sparse_positions"][b])
+        assert np.array_equal(_np(got["sparse_descriptors"][b]), exp["sparse_descriptors"][b])
+    assert [tuple(_np(s)) for s in got["image_size"]] == [tuple(s) for s in exp["image_size"]]
+
+
+@pytest.mark.parametrize("name", list(CONV.cases))
+def test_extractors_small_vs_oracle_and_golden(oracle, name):
+    from test_oracle_golden import _check_feats
+    c = CONV.cases[name]
+    model, sd = _build(c, CONV)
+    ev, mask, img = _inputs(c)
+    img_t = _t(img)
+    ef, imf, m = model(_t(ev), img_t, _t(mask))
+    oef, oimf = _oracle_feats(oracle, c, sd, ev, mask, img, dense=True)
+    _assert_feats_equal_oracle(ef, oef, dense=True)
+    _assert_feats_equal_oracle(imf, oimf, dense=True)
+    if c["cfg"]["image_extractor"]["type"] == "superpointv1":
+        assert np.array_equal(_np(img_t), img / np.float32(255.0))  # in-place `image /= 255` quirk
+    else:
+        assert np.array_equal(_np(img_t), img)
+    # and against the reference's own outputs
+    as_np = lambda f: {k: (_np(v) if torch.is_tensor(v) else [_np(t) for t in v]) for k, v in f.items()}  # noqa: E731
+    _check_feats(f"{name}.ev", as_np(ef), CONV)
+    _check_feats(f"{name}.im", as_np(imf), CONV)
+    # key set of the output dict (reference: 13 keys for cell-8 nets, 12 for cell-1 nets)
+    import json
+    assert sorted(ef.keys()) == json.loads(bytes(CONV[f"{name}.ev.keys"]).decode())
+    assert sorted(imf.keys()) == json.loads(bytes(CONV[f"{name}.im.keys"]).decode())
+
+
+@pytest.mark.parametrize("name", ["sp_mnn", "sp_mnn16", "silk_mnn"])
+def test_e2e_full_size(oracle, name):
+    from test_oracle_golden import _check_feats
+    c = E2E.cases[name]
+    model, sd = _build(c, E2E)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    ev, mask, img = _inputs(c)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oef, oimf = _oracle_feats(oracle, c, sd, ev, mask, img)
+    _assert_feats_equal_oracle(ef, oef)
+    _assert_feats_equal_oracle(imf, oimf)
+    as_np = lambda f: {k: (_np(v) if torch.is_tensor(v) else [_np(t) for t in v]) for k, v in f.items()}  # noqa: E731
+    _check_feats(f"{name}.ev", as_np(ef), E2E)
+    _check_feats(f"{name}.im", as_np(imf), E2E)
+    # matcher: bit-exact against the oracle on the same descriptors; against the reference up to
+    # arg-max near-ties (checked with margins in test_oracle_golden.py::test_e2e_full_size)
+    for b in range(c["B"]):
+        exp = oracle.mnn(oef["sparse_descriptors"][b], oimf["sparse_descriptors"][b])
+        assert np.array_equal(_np(m["matches0"][b])[0], exp["matches0"])
+        assert np.array_equal(_np(m["matches1"][b])[0], exp["matches1"])
+        assert np.array_equal(_np(m["matching_scores0"][b])[0], exp["matching_scores0"])
+        mk0, mk1 = oracle.matched_kpts(oef["sparse_positions"][b], oimf["sparse_positions"][b], exp["matches0"], 3)
+        assert np.array_equal(_np(m["matched_kpts0"][b]), mk0)
+        assert np.array_equal(_np(m["matched_kpts1"][b]), mk1)
+        np.testing.assert_allclose(_np(m["log_assignment"][b])[0], exp["log_assignment"], atol=1e-5, rtol=0)
+    ref0 = split(E2E[f"{name}.m.matches0"], E2E[f"{name}.m.matches0.lens"])
+    ndiff = sum(int((_np(m["matches0"][b])[0] != ref0[b]).sum()) for b in range(c["B"]))
+    assert ndiff <= 2, f"{ndiff} match indices differ from the reference"
+
+
+# ------------------------------------------------------------------ size-independent properties at bench size
+def test_properties_at_bench_batch():
+    c = dict(E2E.cases["sp_mnn"])
+    model, _ = _build(c, E2E)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    B = 32
+    ev, mask = synth.synth_events(500, B, 5)
+    img = synth.synth_image(500, B)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    from importlib import import_module
+    du = import_module(pkg.__name__ + ".core.modules.utils.detector_util")
+    for feats in (ef, imf):
+        nms = feats["nms"]
+        again = du.fast_nms(nms[:, None].contiguous(), 4)
+        assert torch.equal(again[:, 0], nms)  # NMS is idempotent on its own output
+        for b in range(B):
+            p = _np(feats["sparse_positions"][b])
+            assert 0 < p.shape[0] <= 1024
+            flat = (p[:, 0] - 0.5) * 346 + (p[:, 1] - 0.5)
+            assert np.all(np.diff(flat) > 0)  # raster order
+            assert p[:, 0].min() >= 2 and p[:, 0].max() <= 258 and p[:, 1].min() >= 1 and p[:, 1].max() <= 345  # border 4 - pad
+            yy, xx = p[:, 0], p[:, 1]
+            dy = np.abs(yy[:, None] - yy[None]); dx = np.abs(xx[:, None] - xx[None])
+            close = (np.maximum(dy, dx) <= 4) & ~np.eye(len(p), dtype=bool)
+            assert not close.any()  # no two survivors within the NMS window
+            d = _np(feats["sparse_descriptors"][b])
+            np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
+    for b in range(B):
+        m0, m1 = _np(m["matches0"][b])[0], _np(m["matches1"][b])[0]
+        sel = np.nonzero(m0 > -1)[0]
+        assert np.array_equal(m1[m0[sel]], sel)  # mutual consistency
+        assert (m0 > -1).sum() == (m1 > -1).sum() == m["matched_kpts0"][b].shape[0]
+    # batch invariance: pair 7 alone gives the same bits as pair 7 inside the batch
+    ef1, imf1, m1_ = model(_t(ev[7:8]), _t(img[7:8]), _t(mask[7:8]))
+    assert torch.equal(ef1["sparse_positions"][0], ef["sparse_positions"][7])
+    assert torch.equal(imf1["sparse_descriptors"][0], imf["sparse_descriptors"][7])
+    assert torch.equal(m1_["matches0"][0], m["matches0"][7])

@@ -1,0 +1,94 @@
+"""CPU-only checks of the host side: the C ABI is complete, the module tree reproduces the
+reference's state_dict names/shapes, and the product refuses to run without a GPU (no fallback)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, ROOT, load_pkg
+
+pkg = load_pkg()
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "einx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(einx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = pkg.native.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libeinx_hip.so does not export {name}"
+    # and the Python binding knows each of them
+    from importlib import import_module
+    sig = import_module(pkg.__name__ + "._lib").SIGNATURES
+    assert declared == set(sig), declared ^ set(sig)
+    assert lib.einx_version().startswith(b"einx-hip")
+
+
+def test_no_gpu_means_no_silent_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = pkg.EIM(pkg.default_config("SP_MNN"), device="cpu").eval()
+    ev = torch.zeros(1, 5, 64, 64)
+    img = torch.zeros(1, 1, 64, 64)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        model(ev, img, torch.zeros(1, 1, 64, 64, dtype=torch.bool))
+
+
+E2E = Golden("e2e")
+LG = Golden("lg")
+
+
+@pytest.mark.parametrize("name", list(E2E.cases))
+def test_state_dict_names_match_reference(name):
+    c = E2E.cases[name]
+    cfg = pkg.configs.to_attr(c["cfg"])
+    model = pkg.EIM(cfg, device="cpu")
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    ref = dict(c["state_keys"])
+    # the generator skipped descriptor_scale_factor entries when synthesising weights
+    mine_cmp = {k: v for k, v in mine.items() if not k.endswith("descriptor_scale_factor")}
+    assert mine_cmp == ref
+    assert any(k.endswith("descriptor_scale_factor") for k in mine)
+
+
+@pytest.mark.parametrize("name", ["d256", "d128"])
+def test_lightglue_state_dict(name):
+    c = LG.cases[name]
+    keys = json.loads(bytes(LG[f"{name}.state_keys"]).decode())
+    lg = pkg.LightGlue({"input_dim": c["input_dim"]})
+    mine = {k: list(v.shape) for k, v in lg.state_dict().items()}
+    assert mine == keys
+
+
+def test_unknown_types_raise_like_reference():
+    cfg = pkg.default_config("SP_MNN")
+    cfg.event_extractor.type = "nope"
+    with pytest.raises(ValueError):
+        pkg.EIM(cfg, device="cpu")
+    cfg = pkg.default_config("SP_MNN")
+    cfg.matcher.type = "nope"
+    with pytest.raises(NotImplementedError):
+        pkg.EIM(cfg, device="cpu")
+    cfg = pkg.default_config("SP_MNN")
+    cfg.name = "other"
+    with pytest.raises(NotImplementedError):
+        pkg.build_model(cfg, "cpu", None)
+
+
+def test_padder_and_ranks():
+    from importlib import import_module
+    nat = pkg.native
+    assert nat.padder_pads(260, 346, 8) == (3, 3, 2, 2)
+    assert nat.padder_pads(260, 346, 1) == (0, 0, 0, 0)
+    assert nat.topk_ranks(264 * 352, 1024) == (91903, 91904)
+    assert nat.topk_capacity(264 * 352, 1024, 1.0) == 1024
+    util = import_module(pkg.__name__ + ".core.modules.utils.util")
+    p = util.Padder((1, 1, 260, 346), 8)
+    x = torch.arange(260 * 346, dtype=torch.float32).reshape(1, 1, 260, 346)
+    xp = p.pad(x)[0]
+    assert xp.shape[-2:] == (264, 352)
+    assert torch.equal(p.unpad(xp)[0], x)
