@@ -45,6 +45,7 @@ SIGNATURES = {
     "einx_device_count": (c_int, []),
     "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "einx_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "einx_conv_block": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
     "einx_div_inplace": (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
     "einx_score_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

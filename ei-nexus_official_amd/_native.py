@@ -62,7 +62,7 @@ def topk_capacity(N, top_k, det_thr):
 # ------------------------------------------------------------------------------ conv
 class ConvLayer:
     """Kernel-native image of one conv block: weights repacked on device, BN(eval) folded into a
-    per-channel (scale, shift) on the host with the same fp32 ops the oracle uses."""
+    per-channel (scale, shift) by einx_bn_fold (IEEE fp32, same op order as the oracle)."""
 
     def __init__(self, weight, bias, bn=None, relu=True, pool=False):
         _dev_check(weight)
@@ -75,11 +75,12 @@ class ConvLayer:
         self.bias = None if bias is None else bias.detach().to(F32).contiguous()
         self.scale = self.shift = None
         if bn is not None:
-            g, b, mean, var, eps = [t.detach().to("cpu", F32) if torch.is_tensor(t) else t for t in bn]
-            scale = g / torch.sqrt(var + eps)
-            shift = b - mean * scale
-            self.scale = scale.to(w.device).contiguous()
-            self.shift = shift.to(w.device).contiguous()
+            g, b, mean, var = [t.detach().to(w.device, F32).contiguous() for t in bn[:4]]
+            self.scale = torch.empty(cout, dtype=F32, device=w.device)
+            self.shift = torch.empty(cout, dtype=F32, device=w.device)
+            check(L.einx_bn_fold(_ptr(g), _ptr(b), _ptr(mean), _ptr(var), float(bn[4]), cout, _ptr(self.scale), _ptr(self.shift),
+                                 _stream(w)), "einx_bn_fold")
+            self._keep_bn = (g, b, mean, var)
         self.desc = ConvDesc(self.w_native.data_ptr(), 0 if self.bias is None else self.bias.data_ptr(),
                              0 if self.scale is None else self.scale.data_ptr(), 0 if self.shift is None else self.shift.data_ptr(),
                              cin, cout, ks, int(relu), int(pool))

@@ -278,6 +278,17 @@ __global__ void conv_repack_kernel(const float* w, int cin, int cout, int taps, 
   }
 }
 
+// BatchNorm2d(eval) -> per-channel affine.  IEEE sqrt/div (hipcc's default correctly rounded
+// forms), same op order as oracle.bn_fold: scale = g / sqrt(var + eps); shift = b - mean * scale.
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var, float eps, int n, float* scale,
+                               float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = g[i] / sqrtf(var[i] + eps);
+  scale[i] = s;
+  shift[i] = b[i] - mean[i] * s;
+}
+
 struct TileCfg {
   int th, tw, nw;
 };
@@ -314,6 +325,16 @@ EINX_EXPORT int einx_conv_repack(const float* w_oihw, int cin, int cout, int ks,
   const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
   hipLaunchKernelGGL(conv_repack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cin, cout, taps, coutPad, krows,
                      w_native);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int n, float* scale,
+                             float* shift, void* stream) {
+  EINX_CHECK_ARG(gamma && beta && mean && var && scale && shift, "null pointer");
+  EINX_CHECK_ARG(n > 0, "bad channel count");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, n, scale,
+                     shift);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

@@ -48,6 +48,11 @@ size_t einx_conv_weight_elems(int cin, int cout, int ks);
 /* OIHW fp32 -> kernel-native [K][CoutPad], K ordered (ci>>1, tap, ci&1); runs on `stream` */
 int einx_conv_repack(const float* w_oihw, int cin, int cout, int ks, float* w_native, void* stream);
 
+/* BatchNorm2d(eval) running statistics -> (scale, shift): scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale (torch.nn.BatchNorm2d in eval mode; core/modules/net/vgg.py:37) */
+int einx_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int n, float* scale,
+                 float* shift, void* stream);
+
 typedef struct einx_conv_desc {
   const float* w_native; /* from einx_conv_repack */
   const float* bias;     /* [cout] or NULL */
