@@ -238,3 +238,27 @@ def gather_matches(r, kpts0, kpts1, n, cols):
     check(lib().einx_gather_matches(_ptr(kpts0), _ptr(kpts1), _ptr(r.matches0), _ptr(n), cap0, cap1, B, cols, _ptr(r.mk0), _ptr(r.mk1),
                                     _ptr(r.nmatch), _stream(kpts0)), "einx_gather_matches")
     return r
+
+
+def lightglue(weights, pb0, pb1, want_la=True, want_ref=False):
+    """weights: _lib.LgWeights; pb0/pb1: PairBatch (kpts [B,cap,3], desc [B,cap,Din], counts)."""
+    _dev_check(pb0.kpts, pb0.desc, pb0.counts, pb1.kpts, pb1.desc, pb1.counts)
+    B, cap0, cap1 = pb0.B, pb0.cap, pb1.cap
+    L = lib()
+    dev = pb0.desc.device
+    d = int(weights.d)
+    ws = torch.empty(L.einx_lg_ws_bytes(B, cap0, cap1, d, int(weights.input_dim)), dtype=torch.uint8, device=dev)
+    r = MatchResult()
+    r.matches0 = torch.empty((B, cap0), dtype=torch.int64, device=dev)
+    r.matches1 = torch.empty((B, cap1), dtype=torch.int64, device=dev)
+    r.scores0 = torch.empty((B, cap0), dtype=F32, device=dev)
+    r.scores1 = torch.empty((B, cap1), dtype=F32, device=dev)
+    r.la = torch.empty((B, cap0 + 1, cap1 + 1), dtype=F32, device=dev) if want_la else None
+    r.ref0 = torch.empty((B, cap0, d), dtype=F32, device=dev) if want_ref else None
+    r.ref1 = torch.empty((B, cap1, d), dtype=F32, device=dev) if want_ref else None
+    (h0, w0), (h1, w1) = pb0.image_size, pb1.image_size
+    check(L.einx_lightglue(ctypes.byref(weights), _ptr(pb0.kpts), _ptr(pb0.desc), _ptr(pb0.counts), cap0, _ptr(pb1.kpts), _ptr(pb1.desc),
+                           _ptr(pb1.counts), cap1, B, float(h0), float(w0), float(h1), float(w1), _ptr(ws), _ptr(r.matches0),
+                           _ptr(r.matches1), _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _ptr(r.ref0), _ptr(r.ref1), _stream(pb0.desc)),
+          "einx_lightglue")
+    return r

@@ -22,8 +22,11 @@ struct Frag {
 // A rows [i0, i0+128) valid while < Mvalid; B rows [j0, j0+128) valid while < Nvalid.
 // K must be a multiple of 4 (rows are 16-byte aligned); K tail beyond a multiple of 32 is
 // zero-filled.  lds: LDS_FLOATS floats.
+// Optional second A source: columns k >= Ksplit come from A2[i][k - Ksplit] (Ksplit % 32 == 0),
+// which evaluates cat([A, A2], -1) @ B^T without materialising the concatenation.
 __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, int i0, int Mvalid, const float* __restrict__ B, int ldb,
-                                        int j0, int Nvalid, int K, float* lds, Frag& f) {
+                                        int j0, int Nvalid, int K, float* lds, Frag& f, const float* __restrict__ A2 = nullptr,
+                                        int lda2 = 0, int Ksplit = 0x7fffffff) {
   float* As = lds;
   float* Bs = lds + BM * PITCH;
   const int tid = threadIdx.x;
@@ -46,7 +49,9 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
       const int r = fidx >> 3, c4 = fidx & 7;
       const int k = k0 + c4 * 4;
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-      if (i0 + r < Mvalid && k < K) va = *reinterpret_cast<const f32x4*>(A + (size_t)(i0 + r) * lda + k);
+      if (i0 + r < Mvalid && k < K)
+        va = (k < Ksplit) ? *reinterpret_cast<const f32x4*>(A + (size_t)(i0 + r) * lda + k)
+                          : *reinterpret_cast<const f32x4*>(A2 + (size_t)(i0 + r) * lda2 + (k - Ksplit));
       if (j0 + r < Nvalid && k < K) vb = *reinterpret_cast<const f32x4*>(B + (size_t)(j0 + r) * ldb + k);
       ra[i] = va;
       rb[i] = vb;

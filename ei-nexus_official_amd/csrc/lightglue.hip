@@ -1,10 +1,562 @@
-// lightglue.hip -- placeholder translation unit; kernels are added below in this round.
-#include "einx_common.h"
-EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) { return 0; }
+// lightglue.hip -- LightGlue inference on gfx950 (fp32 end to end, fp32 matrix cores).
+//
+// Per layer: SelfBlock (Wqkv GEMM -> rotary -> fused softmax(QK^T/8)V -> out_proj GEMM ->
+// concat-free FFN GEMM -> LayerNorm+GELU -> FFN GEMM + residual) on both sides, then CrossBlock
+// (to_qk / to_v GEMMs, two fused attentions sharing the 1/8 scale, to_out, same FFN).  After the
+// last layer MatchAssignment: final_proj/d^(1/4), similarity tiles with double log-softmax +
+// matchability (match_tiles.h), mutual filter.  Everything for a batch of pairs is enqueued on one
+// stream with device-side keypoint counts; no host synchronisation.
+//
+// Attention is flash-style per (pair, head, 128 queries): S^T = K Q^T on the matrix cores with the
+// query on the MFMA column so that (a) the online-softmax state (running max / sum) is per lane
+// and (b) the probability registers are directly the B operand of the PV product O^T = V^T P^T --
+// no LDS round trip for P.  K/V blocks of 64 keys are staged through LDS (K with an odd pitch).
+//
+// Replaces (reference file:line): core/modules/matchers/lightglue.py:137-148 (normalize_keypoints),
+// :161-174 (posenc), :151-158 (rotary), :240-272 (SelfBlock), :275-330 (CrossBlock), :365-418
+// (assignment + filter_matches), :522-716 (forward).
+#include "match_tiles.h"
+
+using namespace einx_gemm;
+using namespace einx_match;
+
+namespace {
+
+constexpr int D = 256;   // descriptor_dim
+constexpr int DH = 64;   // head dim
+constexpr int HEADS = 4;
+
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ------------------------------------------------------------------------------------------
+// positional encoding: enc[b][i][0..63] = cos, [64..127] = sin of Wr . normalised keypoint,
+// each frequency repeated twice (repeat_interleave(2)).
+// ------------------------------------------------------------------------------------------
+__global__ void lg_posenc_kernel(const float* kpts, const int32_t* cnt, int cap, float s0, float s1, const float* Wr, float* enc) {
+  const int b = blockIdx.y;
+  const int n = min(cnt[b], cap);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 5, f = t & 31;
+  if (i >= n) return;
+  const float sh0 = s0 / 2.0f, sh1 = s1 / 2.0f;
+  const float sc = fmaxf(s0, s1) / 2.0f;
+  const float* kp = kpts + ((size_t)b * cap + i) * 3;
+  const float k0 = (kp[0] - sh0) / sc, k1 = (kp[1] - sh1) / sc;
+  float p = fmaf(k0, Wr[f * 2 + 0], 0.0f);
+  p = fmaf(k1, Wr[f * 2 + 1], p);
+  float sn, cs;
+  einx_sincosf(p, &sn, &cs);
+  float* e = enc + ((size_t)b * cap + i) * 128;
+  e[2 * f] = cs;
+  e[2 * f + 1] = cs;
+  e[64 + 2 * f] = sn;
+  e[64 + 2 * f + 1] = sn;
+}
+
+// ------------------------------------------------------------------------------------------
+// batched Linear: Y[b,i,:] = cat(X[b,i,:], X2[b,i,:]) @ W^T + bias  (+ epilogue)
+// ------------------------------------------------------------------------------------------
+enum { EPI_BIAS = 0, EPI_DIV = 1, EPI_RESID = 2 };
+
+struct GemmArgs {
+  const float* X;
+  const float* X2;
+  const float* W;
+  const float* bias;
+  float* Y;
+  const int32_t* cnt;
+  int cap, ldx, ldx2, Ksplit, K, N, ldy;
+  float div;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(THREADS) void lg_gemm_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int b = blockIdx.z;
+  const int n = min(g.cnt[b], g.cap);
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  if (i0 >= n) return;
+  Frag f;
+  const float* X = g.X + (size_t)b * g.cap * g.ldx;
+  const float* X2 = g.X2 ? g.X2 + (size_t)b * g.cap * g.ldx2 : nullptr;
+  tile_nt(X, g.ldx, i0, n, g.W, g.K, j0, g.N, g.K, lds, f, X2, g.ldx2, g.Ksplit);
+  float* Y = g.Y + (size_t)b * g.cap * g.ldy;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + row_of(mt, r);
+      if (i >= n) continue;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int j = j0 + col_of(nt);
+        if (j >= g.N) continue;
+        float v = f.acc[mt][nt][r] + g.bias[j];
+        if (EPI == EPI_DIV) v = v / g.div;
+        if (EPI == EPI_RESID) v = Y[(size_t)i * g.ldy + j] + v;
+        Y[(size_t)i * g.ldy + j] = v;
+      }
+    }
+}
+
+// qkv [B,cap,768] with feature (h*64+c)*3+t  ->  q,k (rotary applied), v as [B,cap,256]
+__global__ void lg_rope_split_kernel(const float* qkv, const float* enc, const int32_t* cnt, int cap, float* q, float* k, float* v) {
+  const int b = blockIdx.y;
+  const int n = min(cnt[b], cap);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // token * 128 + pair index
+  const int i = t >> 7, pidx = t & 127;
+  if (i >= n) return;
+  const int hc = pidx * 2;  // even channel in 0..255 (h*64 + c)
+  const int c = hc & 63;
+  const float* src = qkv + ((size_t)b * cap + i) * 768 + (size_t)hc * 3;
+  const float* e = enc + ((size_t)b * cap + i) * 128;
+  const float c0 = e[c], c1 = e[c + 1], s0 = e[64 + c], s1 = e[64 + c + 1];
+  const size_t o = ((size_t)b * cap + i) * D + hc;
+  const float q0 = src[0], q1 = src[3], k0 = src[1], k1 = src[4];
+  q[o] = (q0 * c0) + ((-q1) * s0);
+  q[o + 1] = (q1 * c1) + (q0 * s1);
+  k[o] = (k0 * c0) + ((-k1) * s0);
+  k[o + 1] = (k1 * c1) + (k0 * s1);
+  v[o] = src[2];
+  v[o + 1] = src[5];
+}
+
+// ------------------------------------------------------------------------------------------
+// fused attention: out[b,q,h*64:(h+1)*64] = softmax_j(scale * Q_h[q] . K_h[j]) V_h[j]
+// ------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* Q;
+  const float* K;
+  const float* V;
+  float* O;
+  const int32_t* nq;
+  const int32_t* nk;
+  int capq, capk;
+  float scale;
+};
+
+constexpr int AKB = 64;  // keys staged per round
+constexpr int KPITCH = DH + 1;
+
+__global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[AKB * KPITCH];
+  __shared__ __attribute__((aligned(16))) float Vs[AKB * DH];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int nq = min(a.nq[b], a.capq), nk = min(a.nk[b], a.capk);
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= nq || nk <= 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int q = q0 + wave * 32 + l31;
+  const bool qv = q < nq;
+  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * D + h * DH;
+  float qreg[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) qreg[t] = Qrow[2 * t + half];
+  const float* Kb = a.K + (size_t)b * a.capk * D + h * DH;
+  const float* Vb = a.V + (size_t)b * a.capk * D + h * DH;
+  f32x16 o[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[mt][r] = 0.0f;
+  const float NEG = -einx_u2f(0x7f800000u);
+  float m_run = NEG, l_run = 0.0f;
+
+  for (int kb0 = 0; kb0 < nk; kb0 += AKB) {
+    __syncthreads();
+    // stage 64 keys x 64 dims of K and V: 1024 float4 each, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int fidx = tid + i * 256;
+      const int row = fidx >> 4, c4 = fidx & 15;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (kb0 + row < nk) {
+        kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)(kb0 + row) * D + c4 * 4);
+        vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)(kb0 + row) * D + c4 * 4);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Ks[row * KPITCH + c4 * 4 + t] = kv[t];
+      *reinterpret_cast<f32x4*>(Vs + row * DH + c4 * 4) = vv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < AKB / 32; ++sub) {
+      const int kbase = kb0 + sub * 32;
+      if (kbase >= nk) break;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const float av = Ks[(sub * 32 + l31) * KPITCH + 2 * t + half];
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qreg[t], s, 0, 0, 0);
+      }
+      float mx = NEG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + crow(r, half);
+        s[r] = key < nk ? s[r] * a.scale : NEG;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = einx_expf(m_run - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = einx_expf(s[r] - m_new);
+        psum += s[r];
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int krow = sub * 32 + crow(r, half);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const float av = Vs[krow * DH + mt * 32 + l31];
+          o[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[r], o[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float l = l_run + __shfl_xor(l_run, 32, 64);
+  if (qv) {
+    float* orow = a.O + ((size_t)b * a.capq + q) * D + h * DH;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) orow[mt * 32 + crow(r, half)] = o[mt][r] / l;
+  }
+}
+
+// LayerNorm(512, eps 1e-5, biased variance) + exact GELU, in place; one wave per token
+__global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* hbuf, const int32_t* cnt, int cap, const float* g, const float* be) {
+  const int b = blockIdx.y;
+  const int n = min(cnt[b], cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  float* row = hbuf + ((size_t)b * cap + i) * 512;
+  float v[8];
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    v[t] = row[lane + 64 * t];
+    s += v[t];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / 512.0f;
+  float q = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) q = fmaf(v[t] - mean, v[t] - mean, q);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int c = lane + 64 * t;
+    row[c] = einx_geluf(fmaf((v[t] - mean) * rstd, g[c], be[c]));
+  }
+}
+
+// matchability logit z = x . w + b per token, plus logsigmoid(z) and logsigmoid(-z)
+__global__ __launch_bounds__(256) void lg_matchability_kernel(const float* x, const int32_t* cnt, int cap, const float* w, const float* bm,
+                                                              float* cert, float* dust) {
+  const int b = blockIdx.y;
+  const int n = min(cnt[b], cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* row = x + ((size_t)b * cap + i) * D;
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) s = fmaf(row[lane + 64 * t], w[lane + 64 * t], s);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) {
+    const float z = s + bm[0];
+    cert[(size_t)b * cap + i] = einx_logsigmoidf(z);
+    dust[(size_t)b * cap + i] = einx_logsigmoidf(-z);
+  }
+}
+
+// filter_matches (lightglue.py:402-418) from the packed arg-max keys of the assignment scores
+__global__ void lg_finalize_kernel(const unsigned long long* rowkey, const unsigned long long* colkey, const int32_t* nn, const int32_t* mm,
+                                   int cap0, int cap1, float th, int64_t* m0, int64_t* m1, float* s0, float* s1) {
+  const int b = blockIdx.y;
+  const int n = min(nn[b], cap0), m = min(mm[b], cap1);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long* rk = rowkey + (size_t)b * cap0;
+  const unsigned long long* ck = colkey + (size_t)b * cap1;
+  auto idx_of = [](unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); };
+  auto val_of = [](unsigned long long k) { return einx_ordered_unkey((unsigned)(k >> 32)); };
+  if (t < cap0) {
+    int64_t r = -1;
+    float sc = 0.0f;
+    if (t < n && m > 0) {
+      const int j = idx_of(rk[t]);
+      const bool mutual = idx_of(ck[j]) == t;
+      sc = mutual ? einx_expf(val_of(rk[t])) : 0.0f;
+      if (mutual && sc > th) r = j;
+    }
+    m0[(size_t)b * cap0 + t] = r;
+    s0[(size_t)b * cap0 + t] = sc;
+  }
+  if (t < cap1) {
+    int64_t r = -1;
+    float sc = 0.0f;
+    if (t < m && n > 0) {
+      const int i = idx_of(ck[t]);
+      const int back = idx_of(rk[i]);
+      const bool mutual1 = back == t;
+      // mscores1 = mscores0[m1] where mutual1; mscores0[i] is non-zero only if i is mutual too,
+      // which is the same condition (back == t  <=>  i's best is t and t's best is i)
+      const float ms0 = mutual1 ? einx_expf(val_of(rk[i])) : 0.0f;
+      sc = ms0;
+      if (mutual1 && ms0 > th) r = i;
+    }
+    m1[(size_t)b * cap1 + t] = r;
+    s1[(size_t)b * cap1 + t] = sc;
+  }
+}
+
+__global__ void lg_copy_rows_kernel(const float* src, float* dst, const int32_t* cnt, int cap, int width) {
+  const int b = blockIdx.y;
+  const int n = min(cnt[b], cap);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * width) return;
+  dst[(size_t)b * cap * width + t] = src[(size_t)b * cap * width + t];
+}
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Side {
+  const float* kpts;
+  const float* desc;
+  const int32_t* cnt;
+  int cap;
+  float *x, *enc, *qkv, *q, *k, *v, *ctx, *msg, *h, *cert, *dust;
+};
+
+size_t side_bytes(int B, int cap) {
+  const size_t tok = (size_t)B * cap;
+  return al(tok * D * 4) + al(tok * 128 * 4) + al(tok * 768 * 4) + 3 * al(tok * D * 4) + 2 * al(tok * D * 4) + al(tok * 512 * 4) + 2 * al(tok * 4);
+}
+
+char* carve_side(Side& s, char* p, int B, int cap) {
+  const size_t tok = (size_t)B * cap;
+  auto take = [&](size_t bytes) { float* r = (float*)p; p += al(bytes); return r; };
+  s.x = take(tok * D * 4);
+  s.enc = take(tok * 128 * 4);
+  s.qkv = take(tok * 768 * 4);
+  s.q = take(tok * D * 4);
+  s.k = take(tok * D * 4);
+  s.v = take(tok * D * 4);
+  s.ctx = take(tok * D * 4);
+  s.msg = take(tok * D * 4);
+  s.h = take(tok * 512 * 4);
+  s.cert = take(tok * 4);
+  s.dust = take(tok * 4);
+  return p;
+}
+
+int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx, const float* X2, int ldx2, int Ksplit, int K, const float* W,
+         const float* bias, int N, float* Y, int ldy, float div = 1.0f) {
+  GemmArgs g;
+  g.X = X;
+  g.X2 = X2;
+  g.W = W;
+  g.bias = bias;
+  g.Y = Y;
+  g.cnt = s.cnt;
+  g.cap = s.cap;
+  g.ldx = ldx;
+  g.ldx2 = ldx2;
+  g.Ksplit = Ksplit;
+  g.K = K;
+  g.N = N;
+  g.ldy = ldy;
+  g.div = div;
+  const dim3 grid((unsigned)einx_cdiv(N, BN), (unsigned)einx_cdiv(s.cap, BM), (unsigned)B);
+  if (epi == EPI_BIAS) hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, st, g);
+  else if (epi == EPI_DIV) hipLaunchKernelGGL(lg_gemm_kernel<EPI_DIV>, grid, dim3(THREADS), 0, st, g);
+  else hipLaunchKernelGGL(lg_gemm_kernel<EPI_RESID>, grid, dim3(THREADS), 0, st, g);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, const float* K, const float* V, const int32_t* nk, int capk,
+         float* O) {
+  AttnArgs a;
+  a.Q = Q;
+  a.K = K;
+  a.V = V;
+  a.O = O;
+  a.nq = nq;
+  a.nk = nk;
+  a.capq = capq;
+  a.capk = capk;
+  a.scale = 0.125f;  // 1/sqrt(64): SDPA scale (self) = (64^-1/4)^2 (cross, lightglue.py:316)
+  hipLaunchKernelGGL(lg_attn_kernel, dim3((unsigned)einx_cdiv(capq, 128), HEADS, (unsigned)B), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ffn(cat[x,msg]) + residual, in place on s.x
+int ffn(hipStream_t st, const Side& s, int B, const float* w0, const float* b0, const float* g, const float* be, const float* w3,
+        const float* b3) {
+  if (gemm(st, EPI_BIAS, s, B, s.x, D, s.msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
+  hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+  if (hipGetLastError() != hipSuccess) return -1;
+  return gemm(st, EPI_RESID, s, B, s.h, 2 * D, nullptr, 0, 0x7fffffff, 2 * D, w3, b3, D, s.x, D);
+}
+
+}  // namespace
+
+EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) {
+  if (B <= 0 || cap0 <= 0 || cap1 <= 0 || d != D) return 0;
+  (void)input_dim;
+  return side_bytes(B, cap0) + side_bytes(B, cap1) + einx_mnn_ws_bytes(B, cap0, cap1) + 1024;
+}
+
 EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0,
                                const float* kpts1, const float* desc1, const int32_t* m, int cap1, int B, float h0, float w0, float h1,
                                float w1, void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la,
                                float* ref0, float* ref1, void* stream) {
-  einx_set_error("einx_lightglue: not built yet");
-  return EINX_ERR_ARG;
+  EINX_CHECK_ARG(w && kpts0 && desc0 && n && kpts1 && desc1 && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
+  EINX_CHECK_ARG(w->d == D && w->heads == HEADS, "kernels are built for d=256, 4 heads of 64");
+  EINX_CHECK_ARG(w->n_layers >= 1 && w->layers, "no layers");
+  EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0, "bad shape");
+  EINX_CHECK_ARG(w->input_dim % 4 == 0 && w->input_dim > 0, "input_dim must be a multiple of 4");
+  EINX_CHECK_ARG((w->input_dim == D) == (w->in_w == nullptr), "input_proj must be given exactly when input_dim != d");
+  hipStream_t st = (hipStream_t)stream;
+  Side s0{}, s1{};
+  s0.kpts = kpts0;
+  s0.desc = desc0;
+  s0.cnt = n;
+  s0.cap = cap0;
+  s1.kpts = kpts1;
+  s1.desc = desc1;
+  s1.cnt = m;
+  s1.cap = cap1;
+  char* p = (char*)ws;
+  p = carve_side(s0, p, B, cap0);
+  p = carve_side(s1, p, B, cap1);
+  void* mnn_ws = p;
+  Side* sides[2] = {&s0, &s1};
+  const float sz[2][2] = {{h0, w0}, {h1, w1}};
+#define LG_CHECK(expr)                                                    \
+  do {                                                                    \
+    if ((expr) != 0 || hipGetLastError() != hipSuccess) {                 \
+      einx_set_error("einx_lightglue: kernel launch failed at %s", #expr); \
+      return EINX_ERR_LAUNCH;                                             \
+    }                                                                     \
+  } while (0)
+  // ---- input projection (or copy) + positional encodings -----------------------------------
+  for (int sd = 0; sd < 2; ++sd) {
+    Side& s = *sides[sd];
+    if (w->in_w) {
+      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.desc, w->input_dim, nullptr, 0, 0x7fffffff, w->input_dim, w->in_w, w->in_b, D, s.x, D));
+    } else {
+      const size_t per = (size_t)s.cap * D;
+      hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.desc, s.x, s.cnt, s.cap, D);
+      LG_CHECK(0);
+    }
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3((unsigned)einx_cdiv(s.cap * 32, 256), (unsigned)B), dim3(256), 0, st, s.kpts, s.cnt, s.cap,
+                       sz[sd][0], sz[sd][1], w->Wr, s.enc);
+    LG_CHECK(0);
+  }
+  // ---- transformer layers --------------------------------------------------------------------
+  for (int li = 0; li < w->n_layers; ++li) {
+    const einx_lg_layer& L = w->layers[li];
+    for (int sd = 0; sd < 2; ++sd) {
+      Side& s = *sides[sd];
+      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqkv, L.bqkv, 3 * D, s.qkv, 3 * D));
+      hipLaunchKernelGGL(lg_rope_split_kernel, dim3((unsigned)einx_cdiv(s.cap * 128, 256), (unsigned)B), dim3(256), 0, st, s.qkv, s.enc, s.cnt,
+                         s.cap, s.q, s.k, s.v);
+      LG_CHECK(0);
+      LG_CHECK(attn(st, B, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
+      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
+      LG_CHECK(ffn(st, s, B, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+    }
+    for (int sd = 0; sd < 2; ++sd) {
+      Side& s = *sides[sd];
+      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqk, L.bqk, D, s.q, D));
+      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wv, L.bv, D, s.v, D));
+    }
+    LG_CHECK(attn(st, B, s0.q, s0.cnt, s0.cap, s1.q, s1.v, s1.cnt, s1.cap, s0.ctx));
+    LG_CHECK(attn(st, B, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));
+    for (int sd = 0; sd < 2; ++sd) {
+      Side& s = *sides[sd];
+      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wco, L.bco, D, s.msg, D));
+      LG_CHECK(ffn(st, s, B, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+    }
+  }
+  // ---- assignment ------------------------------------------------------------------------------
+  for (int sd = 0; sd < 2; ++sd) {
+    Side& s = *sides[sd];
+    LG_CHECK(gemm(st, EPI_DIV, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, w->proj_w, w->proj_b, D, s.q, D, sqrtf(sqrtf((float)D))));
+    hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.x, s.cnt, s.cap, w->match_w,
+                       w->match_b, s.cert, s.dust);
+    LG_CHECK(0);
+    float* ref = sd == 0 ? ref0 : ref1;
+    if (ref) {
+      const size_t per = (size_t)s.cap * D;
+      hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.x, ref, s.cnt, s.cap, D);
+      LG_CHECK(0);
+    }
+  }
+  MnnArgs a;
+  a.d0 = s0.q;
+  a.d1 = s1.q;
+  a.n = n;
+  a.m = m;
+  a.cap0 = cap0;
+  a.cap1 = cap1;
+  a.D = D;
+  a.nc64 = einx_cdiv(cap1, 64);
+  a.nr64 = einx_cdiv(cap0, 64);
+  char* q = (char*)mnn_ws;
+  a.rowkey = (unsigned long long*)q;
+  q += al((size_t)B * cap0 * 8);
+  a.colkey = (unsigned long long*)q;
+  q += al((size_t)B * cap1 * 8);
+  a.rowstat = (float*)q;
+  q += al((size_t)B * cap0 * a.nc64 * 8);
+  a.colstat = (float*)q;
+  q += al((size_t)B * cap1 * a.nr64 * 8);
+  a.rowlse = (float*)q;
+  q += al((size_t)B * cap0 * 8);
+  a.collse = (float*)q;
+  a.la = la;
+  a.cert0 = s0.cert;
+  a.cert1 = s1.cert;
+  a.dust0 = s0.dust;
+  a.dust1 = s1.dust;
+  const size_t keybytes = al((size_t)B * cap0 * 8) + al((size_t)B * cap1 * 8);
+  if (hipMemsetAsync(mnn_ws, 0, keybytes, st) != hipSuccess) {
+    einx_set_error("einx_lightglue: memset failed");
+    return EINX_ERR_LAUNCH;
+  }
+  const dim3 grid((unsigned)einx_cdiv(cap1, BN), (unsigned)einx_cdiv(cap0, BM), (unsigned)B);
+  const int mx = cap0 > cap1 ? cap0 : cap1;
+  hipLaunchKernelGGL((mnn_tile_kernel<1, false>), grid, dim3(THREADS), 0, st, a);
+  LG_CHECK(0);
+  hipLaunchKernelGGL(mnn_lse_kernel, dim3((unsigned)einx_cdiv(mx + 1, 256), (unsigned)B), dim3(256), 0, st, a);
+  LG_CHECK(0);
+  hipLaunchKernelGGL((mnn_tile_kernel<0, true>), grid, dim3(THREADS), 0, st, a);
+  LG_CHECK(0);
+  if (la) {
+    hipLaunchKernelGGL((mnn_tile_kernel<2, true>), grid, dim3(THREADS), 0, st, a);
+    LG_CHECK(0);
+  }
+  hipLaunchKernelGGL(lg_finalize_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, st, a.rowkey, a.colkey, n, m, cap0, cap1,
+                     w->filter_threshold, matches0, matches1, scores0, scores1);
+  LG_CHECK(0);
+#undef LG_CHECK
+  return EINX_OK;
 }

@@ -8,282 +8,11 @@
 //
 // Replaces (reference file:line): core/modules/matchers/MNN.py:12-32 (find_nn, mutual_check),
 // :88-129 (similarity, log_assignment, matched keypoint gather); lightglue.py:690-698 (gather).
-#include "gemm_tile.h"
+#include "match_tiles.h"
 
-namespace {
-
+using namespace einx_match;
 using namespace einx_gemm;
 
-__device__ __forceinline__ unsigned long long pack_key(float v, int idx) {
-  return ((unsigned long long)einx_ordered_key(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
-}
-
-struct MnnArgs {
-  const float* d0;
-  const float* d1;
-  const int32_t* n;
-  const int32_t* m;
-  int cap0, cap1, D;
-  unsigned long long* rowkey;  // [B,cap0]
-  unsigned long long* colkey;  // [B,cap1]
-  float* rowstat;              // [B,cap0,nc64,2]  (max, sumexp) per 64-column chunk
-  float* colstat;              // [B,cap1,nr64,2]
-  float* rowlse;               // [B,cap0,2] (max, log-sum-exp)
-  float* collse;               // [B,cap1,2]
-  float* la;                   // [B,cap0+1,cap1+1]
-  int nc64, nr64;
-};
-
-// MODE 0: arg-max keys.  MODE 1: per-chunk softmax statistics.  MODE 2: write log_assignment.
-template <int MODE>
-__global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  const int b = blockIdx.z;
-  const int n = min(a.n[b], a.cap0), m = min(a.m[b], a.cap1);
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-  if (i0 >= n || j0 >= m) return;
-  Frag f;
-  tile_nt(a.d0 + (size_t)b * a.cap0 * a.D, a.D, i0, n, a.d1 + (size_t)b * a.cap1 * a.D, a.D, j0, m, a.D, lds, f);
-  const int lane = threadIdx.x & 63;
-  const int half = lane >> 5;
-  const float NEG = -einx_u2f(0x7f800000u);
-
-  if (MODE == 0) {
-    // ---- column arg-max over this wave's 64 rows (ascending i, strict > keeps the first) ----
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int j = j0 + col_of(nt);
-      float bv = NEG;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = i0 + row_of(mt, r);
-          const float v = f.acc[mt][nt][r];
-          if (i < n && (v > bv || bi == 0x7fffffff)) {
-            bv = v;
-            bi = i;
-          }
-        }
-      // the other lane-half holds the interleaved rows of the same column
-      const float ov = __shfl_xor(bv, 32, 64);
-      const int oi = __shfl_xor(bi, 32, 64);
-      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
-        bv = ov;
-        bi = oi;
-      }
-      if (half == 0 && j < m && bi != 0x7fffffff) atomicMax(&a.colkey[(size_t)b * a.cap1 + j], pack_key(bv, bi));
-    }
-    // ---- row arg-max over this wave's 64 columns ---------------------------------------------
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + row_of(mt, r);
-        float bv = NEG;
-        int bj = 0x7fffffff;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int j = j0 + col_of(nt);
-          const float v = f.acc[mt][nt][r];
-          if (j < m && (bj == 0x7fffffff || v > bv)) {
-            bv = v;
-            bj = j;
-          }
-        }
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-          const float ov = __shfl_xor(bv, off, 64);
-          const int oj = __shfl_xor(bj, off, 64);
-          if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) {
-            bv = ov;
-            bj = oj;
-          }
-        }
-        if ((lane & 31) == 0 && i < n && bj != 0x7fffffff) atomicMax(&a.rowkey[(size_t)b * a.cap0 + i], pack_key(bv, bj));
-      }
-  } else if (MODE == 1) {
-    const int wave = threadIdx.x >> 6;
-    const int cchunk = (j0 >> 6) + (wave & 1), rchunk = (i0 >> 6) + (wave >> 1);
-    // rows: (max, sum exp(v-max)) over this wave's 64 columns
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + row_of(mt, r);
-        float v0 = (j0 + col_of(0) < m) ? f.acc[mt][0][r] : NEG;
-        float v1 = (j0 + col_of(1) < m) ? f.acc[mt][1][r] : NEG;
-        float mx = fmaxf(v0, v1);
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        float s = 0.0f;
-        if (v0 != NEG) s += einx_expf(v0 - mx);
-        if (v1 != NEG) s += einx_expf(v1 - mx);
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        if ((lane & 31) == 0 && i < n && cchunk * 64 < m) {
-          float* o = a.rowstat + (((size_t)b * a.cap0 + i) * a.nc64 + cchunk) * 2;
-          o[0] = mx;
-          o[1] = s;
-        }
-      }
-    // columns: over this wave's 64 rows
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int j = j0 + col_of(nt);
-      float mx = NEG;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (i0 + row_of(mt, r) < n) mx = fmaxf(mx, f.acc[mt][nt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float s = 0.0f;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (i0 + row_of(mt, r) < n) s += einx_expf(f.acc[mt][nt][r] - mx);
-      s += __shfl_xor(s, 32, 64);
-      if (half == 0 && j < m && rchunk * 64 < n) {
-        float* o = a.colstat + (((size_t)b * a.cap1 + j) * a.nr64 + rchunk) * 2;
-        o[0] = mx;
-        o[1] = s;
-      }
-    }
-  } else {
-    const size_t pitch = (size_t)a.cap1 + 1;
-    float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + row_of(mt, r);
-        if (i >= n) continue;
-        const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int j = j0 + col_of(nt);
-          if (j >= m) continue;
-          const float cm = a.collse[((size_t)b * a.cap1 + j) * 2], cl = a.collse[((size_t)b * a.cap1 + j) * 2 + 1];
-          const float sv = f.acc[mt][nt][r];
-          la[(size_t)i * pitch + j] = ((sv - rm) - rl) + ((sv - cm) - cl);
-        }
-      }
-  }
-}
-
-// merge per-chunk (max, sumexp) -> (max, log-sum-exp); also zero the dustbin row/column of la
-__global__ void mnn_lse_kernel(const MnnArgs a) {
-  const int b = blockIdx.y;
-  const int n = min(a.n[b], a.cap0), m = min(a.m[b], a.cap1);
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const float NEG = -einx_u2f(0x7f800000u);
-  if (t < n) {
-    const int chunks = (m + 63) / 64;
-    const float* st = a.rowstat + ((size_t)b * a.cap0 + t) * a.nc64 * 2;
-    float mx = NEG;
-    for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, st[2 * c]);
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s = fmaf(st[2 * c + 1], einx_expf(st[2 * c] - mx), s);
-    a.rowlse[((size_t)b * a.cap0 + t) * 2] = mx;
-    a.rowlse[((size_t)b * a.cap0 + t) * 2 + 1] = einx_logf(s);
-  }
-  if (t < m) {
-    const int chunks = (n + 63) / 64;
-    const float* st = a.colstat + ((size_t)b * a.cap1 + t) * a.nr64 * 2;
-    float mx = NEG;
-    for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, st[2 * c]);
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s = fmaf(st[2 * c + 1], einx_expf(st[2 * c] - mx), s);
-    a.collse[((size_t)b * a.cap1 + t) * 2] = mx;
-    a.collse[((size_t)b * a.cap1 + t) * 2 + 1] = einx_logf(s);
-  }
-  const size_t pitch = (size_t)a.cap1 + 1;
-  float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;
-  if (t <= m) la[(size_t)n * pitch + t] = 0.0f;
-  if (t <= n) la[(size_t)t * pitch + m] = 0.0f;
-}
-
-// keys -> matches, mutual check, scores (MNN.py:25-32, :100-101)
-__global__ void mnn_finalize_kernel(const unsigned long long* rowkey, const unsigned long long* colkey, const int32_t* nn,
-                                    const int32_t* mm, int cap0, int cap1, int64_t* m0, int64_t* m1, float* s0, float* s1) {
-  const int b = blockIdx.y;
-  const int n = min(nn[b], cap0), m = min(mm[b], cap1);
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long* rk = rowkey + (size_t)b * cap0;
-  const unsigned long long* ck = colkey + (size_t)b * cap1;
-  if (t < cap0) {
-    int64_t r = -1;
-    if (t < n && m > 0) {
-      const int j = (int)(0xFFFFFFFFu - (unsigned)(rk[t] & 0xFFFFFFFFull));
-      const int back = (int)(0xFFFFFFFFu - (unsigned)(ck[j] & 0xFFFFFFFFull));
-      if (back == t) r = j;
-    }
-    m0[(size_t)b * cap0 + t] = r;
-    s0[(size_t)b * cap0 + t] = r > -1 ? 1.0f : 0.0f;
-  }
-  if (t < cap1) {
-    int64_t r = -1;
-    if (t < m && n > 0) {
-      const int i = (int)(0xFFFFFFFFu - (unsigned)(ck[t] & 0xFFFFFFFFull));
-      const int back = (int)(0xFFFFFFFFu - (unsigned)(rk[i] & 0xFFFFFFFFull));
-      if (back == t) r = i;
-    }
-    m1[(size_t)b * cap1 + t] = r;
-    s1[(size_t)b * cap1 + t] = r > -1 ? 1.0f : 0.0f;
-  }
-}
-
-// ascending-i compaction of matched keypoints; one 1024-thread workgroup per pair
-__global__ __launch_bounds__(1024) void gather_matches_kernel(const float* k0, const float* k1, const int64_t* m0, const int32_t* nn,
-                                                              int cap0, int cap1, int cols, float* o0, float* o1, int32_t* nmatch) {
-  __shared__ int scratch[17];
-  const int b = blockIdx.x;
-  const int n = min(nn[b], cap0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int base = 0;
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    const int i = i0 + tid;
-    int64_t j = -1;
-    if (i < n) j = m0[(size_t)b * cap0 + i];
-    const int v = j > -1 ? 1 : 0;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) scratch[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-      int run = 0;
-      for (int w = 0; w < 16; ++w) {
-        const int t = scratch[w];
-        scratch[w] = run;
-        run += t;
-      }
-      scratch[16] = run;
-    }
-    __syncthreads();
-    const int pos = base + scratch[wave] + incl - v;
-    const int total = scratch[16];
-    __syncthreads();
-    if (v) {
-      for (int c = 0; c < cols; ++c) {
-        o0[((size_t)b * cap0 + pos) * cols + c] = k0[((size_t)b * cap0 + i) * 3 + c];
-        o1[((size_t)b * cap0 + pos) * cols + c] = k1[((size_t)b * cap1 + (int)j) * 3 + c];
-      }
-    }
-    base += total;
-  }
-  if (tid == 0) nmatch[b] = base;
-}
-
-size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-}  // namespace
 
 EINX_EXPORT size_t einx_mnn_ws_bytes(int B, int cap0, int cap1) {
   if (B <= 0 || cap0 <= 0 || cap1 <= 0) return 0;
@@ -323,6 +52,7 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
   p += align256((size_t)B * cap0 * 8);
   a.collse = (float*)p;
   a.la = la;
+  a.cert0 = a.cert1 = a.dust0 = a.dust1 = nullptr;
   const size_t keybytes = align256((size_t)B * cap0 * 8) + align256((size_t)B * cap1 * 8);
   if (hipMemsetAsync(ws, 0, keybytes, s) != hipSuccess) {
     einx_set_error("einx_mnn: memset failed");

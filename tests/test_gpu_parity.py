@@ -358,3 +358,79 @@ def test_properties_at_bench_batch():
     assert torch.equal(ef1["sparse_positions"][0], ef["sparse_positions"][7])
     assert torch.equal(imf1["sparse_descriptors"][0], imf["sparse_descriptors"][7])
     assert torch.equal(m1_["matches0"][0], m["matches0"][7])
+
+
+# ------------------------------------------------------------------ LightGlue
+LG = Golden("lg")
+
+
+def _lg_model(c):
+    import json
+    cc = dict(c)
+    cc["state_keys"] = json.loads(bytes(LG[f"{c['name']}.state_keys"]).decode())
+    sd = state_dict_for(cc)
+    lg = pkg.LightGlue({"input_dim": c["input_dim"]}).to(DEV)
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return lg.eval(), sd
+
+
+@pytest.mark.parametrize("name", ["d256", "d128", "full"])
+def test_lightglue_vs_golden(oracle, name):
+    from helpers import lg_inputs
+    c = LG.cases[name]
+    lg, sd = _lg_model(c)
+    d0, d1, k0, k1 = lg_inputs(c)
+    size = torch.tensor([260, 346])
+    f0 = {"sparse_descriptors": _t(d0)[None], "sparse_positions": _t(k0)[None], "image_size": [size]}
+    f1 = {"sparse_descriptors": _t(d1)[None], "sparse_positions": _t(k1)[None], "image_size": [size]}
+    r = lg(f0, f1)
+    # bit-exact match assignments against the reference
+    assert np.array_equal(_np(r["matches0"]), LG[f"{name}.matches0"])
+    assert np.array_equal(_np(r["matches1"]), LG[f"{name}.matches1"])
+    np.testing.assert_allclose(_np(r["matching_scores0"]), LG[f"{name}.mscores0"], atol=FTOL)
+    np.testing.assert_allclose(_np(r["matching_scores1"]), LG[f"{name}.mscores1"], atol=FTOL)
+    assert np.array_equal(_np(r["matched_kpts0"]), LG[f"{name}.matched_kpts0"])
+    assert np.array_equal(_np(r["matched_kpts1"]), LG[f"{name}.matched_kpts1"])
+    la = _np(r["log_assignment"])
+    assert la.shape == (1, c["n"] + 1, c["m"] + 1)
+    if f"{name}.la" in LG:
+        np.testing.assert_allclose(la, LG[f"{name}.la"], atol=2e-4, rtol=1e-4)
+    else:
+        np.testing.assert_allclose(la[0, ::37, ::41], LG[f"{name}.la_probe"], atol=2e-4, rtol=1e-4)
+    sn = max(1, c["n"] // 16)
+    ref = _np(r["ref_descriptors0"])
+    assert ref.shape == (1, 1, c["n"], 256)
+    np.testing.assert_allclose(ref[0, 0, ::sn, ::16], LG[f"{name}.ref_desc0_probe"], atol=FTOL, rtol=FTOL)
+    assert tuple(r["prune0"].shape) == (1, c["n"]) and float(r["prune0"][0, 0]) == 9.0
+    if name != "full":
+        exp = oracle.lightglue(sd, k0, d0, k1, d1)
+        assert np.array_equal(_np(r["matches0"])[0], exp["matches0"])
+        np.testing.assert_allclose(la[0], exp["log_assignment"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(ref[0, 0], exp["ref_descriptors0"], atol=FTOL, rtol=FTOL)
+
+
+def test_e2e_sp_lightglue(oracle):
+    from test_oracle_golden import _check_feats
+    name = "sp_lg"
+    c = E2E.cases[name]
+    model, sd = _build(c, E2E)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    ev, mask, img = _inputs(c)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oef, oimf = _oracle_feats(oracle, c, sd, ev, mask, img)
+    _assert_feats_equal_oracle(ef, oef)
+    _assert_feats_equal_oracle(imf, oimf)
+    for key in ("matches0", "matches1"):
+        exp = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
+        for b in range(c["B"]):
+            assert np.array_equal(_np(m[key][b])[0], exp[b]), key
+    for key in ("matched_kpts0", "matched_kpts1"):
+        exp = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
+        for b in range(c["B"]):
+            assert tuple(m[key][b].shape) == exp[b].shape  # [M,2] for LightGlue
+            np.testing.assert_allclose(_np(m[key][b]), exp[b], atol=FTOL)
+    for b in range(c["B"]):
+        la = _np(m["log_assignment"][b])
+        assert list(la.shape) == E2E[f"{name}.m.la_shapes"][b].tolist()
+        np.testing.assert_allclose(la[0, ::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b], atol=5e-4, rtol=1e-4)
