@@ -66,9 +66,7 @@ def sp_pair_flops(ce):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="env://")
     if world != args.gpus and rank == 0:
@@ -99,16 +97,13 @@ def main():
     img_src = torch.from_numpy(img_np).to(dev)
     img = torch.empty_like(img_src)
 
-    acc = torch.zeros(4, dtype=torch.float64, device=dev)  # pairs, keypoints(ev), keypoints(im), matches
+    acc = pkg.shard.MetricAccumulator(dev)  # pairs, keypoints(ev), keypoints(im), matches, ...
 
     def step(accumulate=False):
         img.copy_(img_src)  # SuperPoint scales its input in place (reference quirk), so refresh it
         ef, imf, m = model(ev, img, mask)
         if accumulate:
-            acc[0] += B
-            acc[1] += sum(int(p.shape[0]) for p in ef["sparse_positions"])
-            acc[2] += sum(int(p.shape[0]) for p in imf["sparse_positions"])
-            acc[3] += sum(int(t.shape[0]) for t in m["matched_kpts0"])
+            acc.add_batch(ef, imf, m)
         return ef, imf, m
 
     for _ in range(args.warmup):
@@ -129,9 +124,10 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)  # the one collective of the job: metric accumulators over RCCL
+    acc.all_reduce()  # the one collective of the job: metric accumulators (RCCL over xGMI when world > 1)
     elapsed = float(t.item())
-    pairs_total = float(acc[0].item())
+    stats = acc.as_dict()
+    pairs_total = stats["pairs"]
     value = pairs_total / elapsed
 
     # ---- roofline of the dominant kernel: conv_block_kernel<3,8,32,4,pool> = conv1b 64->64 @264x352 ------
@@ -195,8 +191,8 @@ def main():
             "config": {"workload": wl_desc, "pairs_per_gpu_per_step": B, "global_batch": B * world, "event_bins": ce,
                        "parallelism": f"dp{world} (pairs sharded, metric all-reduce only)", "log_assignment": bool(args.log_assignment),
                        "dense_outputs": bool(args.dense),
-                       "mean_keypoints": [round(float(acc[1].item()) / pairs_total, 1), round(float(acc[2].item()) / pairs_total, 1)],
-                       "mean_matches": round(float(acc[3].item()) / pairs_total, 1)},
+                       "mean_keypoints": [round(stats["keypoints0"] / pairs_total, 1), round(stats["keypoints1"] / pairs_total, 1)],
+                       "mean_matches": round(stats["matches"] / pairs_total, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -15,7 +15,7 @@ from . import _lib
 _lib.load()  # no fallback: raise now if the HIP extension is not built
 
 from . import _native as native  # noqa: E402
-from . import configs, synth  # noqa: E402
+from . import configs, shard, synth  # noqa: E402
 from .configs import AttrDict, default_config  # noqa: E402
 from .core.modules import EIM, ImageImageMatcher, build_model  # noqa: E402
 from .core.modules.Extractors import EventKeypointsExtractor, ImageKeypointsExtractor  # noqa: E402
