@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="also materialise the dense descriptor maps (reference-complete dict)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--kernel-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
 
@@ -106,6 +107,8 @@ def main():
             acc.add_batch(ef, imf, m)
         return ef, imf, m
 
+    if args.kernel_only:
+        args.steps, args.warmup, args.no_cpu_baseline = 0, 0, True
     for _ in range(args.warmup):
         step()
 
@@ -127,8 +130,8 @@ def main():
     acc.all_reduce()  # the one collective of the job: metric accumulators (RCCL over xGMI when world > 1)
     elapsed = float(t.item())
     stats = acc.as_dict()
-    pairs_total = stats["pairs"]
-    value = pairs_total / elapsed
+    pairs_total = max(stats["pairs"], 1.0)
+    value = stats["pairs"] / elapsed
 
     # ---- roofline of the dominant kernel: conv_block_kernel<3,8,32,4,pool> = conv1b 64->64 @264x352 ------
     roofline = None
@@ -186,7 +189,7 @@ def main():
         out = {
             "metric": "event-image pairs/s (extract+match, 346x260, 1024 kpts)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc, "pairs_per_gpu_per_step": B, "global_batch": B * world, "event_bins": ce,
                        "parallelism": f"dp{world} (pairs sharded, metric all-reduce only)", "log_assignment": bool(args.log_assignment),

@@ -31,10 +31,35 @@ class EIM(nn.Module):
             if logger is not None:
                 logger.log_info(f"Loaded pretrain_stage2 model from {config.pretrain_stage2.model_path}")
 
+    overlap_extractors = True  # run the two (independent) extractors on two HIP streams
+
+    def _side_stream(self, device):
+        st = getattr(self, "_einx_side_stream", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._einx_side_stream = st
+        return st
+
     def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False):
-        """Enqueue the whole pipeline; returns device-side results without synchronising."""
-        ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
-        im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
+        """Enqueue the whole pipeline; returns device-side results without synchronising.
+        The event and image extractors share nothing, so the event side is enqueued on a second HIP
+        stream: its small late layers and its latency-bound NMS/selection kernels overlap the other
+        side's convolutions instead of leaving most of the 256 CUs idle."""
+        if self.overlap_extractors and events.device.type == "cuda":
+            cur = torch.cuda.current_stream(events.device)
+            side = self._side_stream(events.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
+            im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
+            cur.wait_stream(side)
+            for t in (ev.feats, ev.logits, ev.raw, ev.prob, ev.score, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
+                      ev.det.indices, ev.det.counts, ev.det.thr, ev.det.not_converged, ev.det.nms):
+                if t is not None:
+                    t.record_stream(cur)  # allocated on the side stream, consumed on the caller's stream
+        else:
+            ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
+            im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
         mr = None
         if self.matcher.matcher is not None:
             if not self.matcher.freeze:
