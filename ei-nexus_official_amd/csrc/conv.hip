@@ -21,8 +21,6 @@
 namespace {
 
 constexpr int kCoutTile = 64;  // output channels per workgroup (2 MFMA M-tiles)
-constexpr int kMT = 2;
-constexpr int kNT = 2;
 
 struct ConvArgs {
   const float* in;
@@ -38,24 +36,24 @@ struct ConvArgs {
   int relu;
 };
 
-template <int KS>
-struct ChunkOf {
-  static constexpr int value = (KS == 3) ? 8 : 32;  // input channels staged per LDS round
-};
-
-// KS: 1|3.  TH x TW: spatial tile (KS==1: flat run of TH*TW pixels).  NW waves of 64 lanes,
-// each owning kNT N-tiles of 32 pixels.  POOL: fuse MaxPool2d(2,2).
-template <int KS, int TH, int TW, int NW, bool POOL>
-__global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
+// KS: 1|3.  TH x TW: spatial tile (KS==1: flat run of TH*TW pixels).  Waves are arranged
+// WM (output-channel groups) x WN (pixel groups); each wave owns MT x NT MFMA tiles of 32x32, with
+// WM*MT == 2 (64 output channels per workgroup).  CK: input channels staged per LDS round.
+// POOL: fuse MaxPool2d(2,2).
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
+__global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs a) {
+  constexpr int kMT = MT, kNT = NT;
+  constexpr int NW = WM * WN;
   constexpr int TAPS = KS * KS;
   constexpr int HALO = KS / 2;
   constexpr int PW = TW + 2 * HALO;
   constexpr int PH = TH + 2 * HALO;
   constexpr int PLANE = PH * PW;
-  constexpr int CK = ChunkOf<KS>::value;
   constexpr int NTHR = NW * 64;
   constexpr int NPIX = TH * TW;
-  static_assert(NW * kNT * 32 >= NPIX, "tile does not fit the workgroup's pixel slots");
+  static_assert(WM * MT * 32 == kCoutTile, "a workgroup covers 64 output channels");
+  static_assert(WN * NT * 32 >= NPIX, "tile does not fit the workgroup's pixel slots");
+  static_assert(CK % 2 == 0, "channels are consumed in pairs");
   constexpr int IN_ELEMS = CK * PLANE;
   constexpr int IN_PER_THR = (IN_ELEMS + NTHR - 1) / NTHR;
   constexpr int W_ROWS = CK * TAPS;
@@ -70,6 +68,7 @@ __global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
   const int lane = tid & 63;
   const int half = lane >> 5;
   const int j = lane & 31;
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
   int qidx[kNT];
 #pragma unroll
   for (int nt = 0; nt < kNT; ++nt) {
-    const int q = (wave * kNT + nt) * 32 + j;
+    const int q = (wn * kNT + nt) * 32 + j;
     const bool vq = q < NPIX;
     qidx[nt] = vq ? q : -1;
     if (KS == 1) {
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
       opix[nt] = (vq && y < a.H && x < a.W) ? y * a.W + x : -1;
     }
   }
-  const int aBase = half * kCoutTile + j;
+  const int aBase = half * kCoutTile + wm * MT * 32 + j;
 
   // ---- staging plan: which global words this thread brings in each round -----------------
   const size_t src_plane = (size_t)a.Hs * a.Ws;
@@ -219,13 +218,17 @@ __global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
   // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store -------------------------
   const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
   float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
+  // pooled layers go through LDS in rounds of 32 output channels (slab = which half of the 64)
 #pragma unroll
-  for (int mt = 0; mt < kMT; ++mt) {
-    if (POOL) __syncthreads();  // LDS free (main loop / previous M-tile's pooled reads done)
+  for (int slab = 0; slab < (POOL ? 2 : 1); ++slab) {
+    if (POOL) __syncthreads();  // LDS free (main loop / previous slab's pooled reads done)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int mt = 0; mt < kMT; ++mt) {
+      if (POOL && (wm * MT + mt) != slab) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
       const int crow = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int co = co0 + mt * 32 + crow;
+      const int co = co0 + (wm * MT + mt) * 32 + crow;
       const bool cv = co < a.Cout;
       const float bi = (cv && a.bias) ? a.bias[co] : 0.0f;
       const float sc = (cv && a.scale) ? a.scale[co] : 1.0f;
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
           if (cv && opix[nt] >= 0) out_b[(size_t)co * HW + opix[nt]] = v;
         }
       }
+      }
     }
     if (POOL) {
       __syncthreads();
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void conv_block_kernel(const ConvArgs a) {
         const int c = idx / (PHo * PWo);
         const int rem = idx % (PHo * PWo);
         const int py = rem / PWo, px = rem % PWo;
-        const int co = co0 + mt * 32 + c;
+        const int co = co0 + slab * 32 + c;
         const int yo = y0 / 2 + py, xo = x0 / 2 + px;
         if (co < a.Cout && yo < Ho && xo < Wo) {
           const float* s = lds + c * NPIX + (2 * py) * TW + 2 * px;
@@ -290,19 +294,19 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean
 }
 
 struct TileCfg {
-  int th, tw, nw;
+  int th, tw, slots;  // slots = pixel slots a workgroup launches for this tile
 };
 
-template <int KS, int TH, int TW, int NW, bool POOL>
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
 void launch(const ConvArgs& a, int B, hipStream_t s) {
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
-  hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, NW, POOL>), grid, dim3(NW * 64), 0, s, a);
+  hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
 // waste = slots launched / pixels useful, for picking a tile shape per layer
-double tile_waste(int H, int W, int th, int tw, int nw) {
-  const double tiles = (double)einx_cdiv(H, th) * einx_cdiv(W, tw);
-  return tiles * nw * kNT * 32 / ((double)H * W);
+double tile_waste(int H, int W, const TileCfg& c) {
+  const double tiles = (double)einx_cdiv(H, c.th) * einx_cdiv(W, c.tw);
+  return tiles * c.slots / ((double)H * W);
 }
 
 }  // namespace
@@ -371,18 +375,19 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   if (d->ks == 1) {
     a.tilesX = einx_cdiv(H * W, 256);
     a.tilesY = 1;
-    launch<1, 1, 256, 4, false>(a, B, s);
+    launch<1, 1, 256, 1, 4, 2, 2, 32, false>(a, B, s);
     EINX_CHECK_LAUNCH();
     return EINX_OK;
   }
-  // candidate tile shapes: (8,32)x4 waves, (12,16)x3, (22,8)x3, (11,22)x4; pooled layers need
-  // even tile dims so that every 2x2 window lives inside one tile.
-  static const TileCfg cfgs[4] = {{8, 32, 4}, {12, 16, 3}, {22, 8, 3}, {11, 22, 4}};
+  // candidate tile shapes (all 4 waves): A (8,32) 1x4 waves of 2x2 tiles; B (12,16) and C (22,8)
+  // 2x2 waves of 1x3 tiles (192 pixel slots); D (11,22) like A.  Pooled layers need even tile dims
+  // so that every 2x2 window lives inside one tile.
+  static const TileCfg cfgs[4] = {{8, 32, 256}, {12, 16, 192}, {22, 8, 192}, {11, 22, 256}};
   int best = 0;
   double bw = 1e30;
   for (int i = 0; i < 4; ++i) {
     if (d->pool && ((cfgs[i].th & 1) || (cfgs[i].tw & 1))) continue;
-    const double wst = tile_waste(H, W, cfgs[i].th, cfgs[i].tw, cfgs[i].nw);
+    const double wst = tile_waste(H, W, cfgs[i]);
     if (wst < bw - 1e-9) {
       bw = wst;
       best = i;
@@ -392,16 +397,21 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   a.tilesY = einx_cdiv(H, cfgs[best].th);
   if (d->pool) {
     switch (best) {
-      case 0: launch<3, 8, 32, 4, true>(a, B, s); break;
-      case 1: launch<3, 12, 16, 3, true>(a, B, s); break;
-      default: launch<3, 22, 8, 3, true>(a, B, s); break;
+      case 0: launch<3, 8, 32, 1, 4, 2, 2, 8, true>(a, B, s); break;
+      case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
+      default: launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s); break;
     }
   } else {
     switch (best) {
-      case 0: launch<3, 8, 32, 4, false>(a, B, s); break;
-      case 1: launch<3, 12, 16, 3, false>(a, B, s); break;
-      case 2: launch<3, 22, 8, 3, false>(a, B, s); break;
-      default: launch<3, 11, 22, 4, false>(a, B, s); break;
+      case 0:
+        // thin first layers (1 / 5 input channels): stage only the channel pairs that exist
+        if (d->cin <= 2) launch<3, 8, 32, 1, 4, 2, 2, 2, false>(a, B, s);
+        else if (d->cin <= 6) launch<3, 8, 32, 1, 4, 2, 2, 6, false>(a, B, s);
+        else launch<3, 8, 32, 1, 4, 2, 2, 8, false>(a, B, s);
+        break;
+      case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
+      case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;
+      default: launch<3, 11, 22, 1, 4, 2, 2, 8, false>(a, B, s); break;
     }
   }
   EINX_CHECK_LAUNCH();

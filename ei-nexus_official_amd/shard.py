@@ -28,7 +28,9 @@ class MetricAccumulator:
     """fp64 sums of per-pair statistics; `all_reduce()` is the job's one collective."""
 
     def __init__(self, device="cpu"):
-        self.v = torch.zeros(len(FIELDS), dtype=torch.float64, device=device)
+        self.device = device
+        self.host = [0.0] * len(FIELDS)  # accumulated on the host; one device tensor at reduce time
+        self.v = None
 
     def add_batch(self, events_feats, image_feats, matches):
         n0 = sum(int(p.shape[0]) for p in events_feats["sparse_positions"])
@@ -37,12 +39,15 @@ class MetricAccumulator:
         self.add(len(events_feats["sparse_positions"]), n0, n1, nm, 0.0)
 
     def add(self, pairs, k0, k1, matches, score_sum):
-        self.v += torch.tensor([pairs, k0, k1, matches, score_sum], dtype=torch.float64, device=self.v.device)
+        for i, x in enumerate((pairs, k0, k1, matches, score_sum)):
+            self.host[i] += float(x)
 
     def all_reduce(self):
+        self.v = torch.tensor(self.host, dtype=torch.float64, device=self.device)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.v, op=dist.ReduceOp.SUM)
         return self
 
     def as_dict(self):
-        return {k: float(x) for k, x in zip(FIELDS, self.v.tolist())}
+        vals = self.v.tolist() if self.v is not None else self.host
+        return {k: float(x) for k, x in zip(FIELDS, vals)}
