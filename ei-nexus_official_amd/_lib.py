@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeinx_hip.so")
+LIB_PATH = os.environ.get("EINX_LIB") or os.path.join(_HERE, "libeinx_hip.so")  # EINX_LIB: A/B builds when tuning
 
 c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
 

@@ -4,6 +4,8 @@ Same constructor, checkpoint-prefix loading and `forward` contract.  The differe
 schedule: both extractors and the matcher are enqueued for the whole batch on the current HIP
 stream, and the host synchronises exactly once (to read the keypoint / match counts that shape
 the returned Python lists)."""
+import os
+
 import torch
 from torch import nn
 
@@ -31,7 +33,7 @@ class EIM(nn.Module):
             if logger is not None:
                 logger.log_info(f"Loaded pretrain_stage2 model from {config.pretrain_stage2.model_path}")
 
-    overlap_extractors = True  # run the two (independent) extractors on two HIP streams
+    overlap_extractors = os.environ.get("EINX_OVERLAP", "1") != "0"  # two (independent) extractors on two HIP streams
 
     def _side_stream(self, device):
         st = getattr(self, "_einx_side_stream", None)

@@ -16,6 +16,8 @@
 // net/detector_head.py:42-48, net/descriptor_head.py:40-43,
 // image_extractors/superpoint_extractor.py:388-406, silk/backbones/superpoint/vgg.py:284-290,
 // utils/util.py:17-32 (replicate pad folded into the first layer's addressing).
+#include <stdlib.h>
+
 #include "einx_common.h"
 
 namespace {
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
   constexpr int W_ROWS = CK * TAPS;
   constexpr int W_F4 = W_ROWS * kCoutTile / 4;
   constexpr int W_PER_THR = (W_F4 + NTHR - 1) / NTHR;
-  constexpr int POOL_ELEMS = POOL ? 32 * NPIX : 0;
+  constexpr int POOL_ELEMS = 0;  // pooling is done in registers
   constexpr int LDS_FLOATS = (IN_ELEMS + W_ROWS * kCoutTile) > POOL_ELEMS ? (IN_ELEMS + W_ROWS * kCoutTile) : POOL_ELEMS;
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -152,7 +154,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
 
   const int pairs_total = (a.Cin + 1) / 2;
   const int nchunks = (pairs_total * 2 + CK - 1) / CK;
-  const int k_rows_total = pairs_total * 2 * TAPS;
 
   float r_in[IN_PER_THR];
   f32x4 r_w[W_PER_THR];
@@ -161,20 +162,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
     const int ci0 = c * CK;
 #pragma unroll
     for (int i = 0; i < IN_PER_THR; ++i) {
+      // unconditional load from a clamped (always valid) address, then select: no branches
       const int ci = ci0 + g_ci[i];
-      float v = 0.0f;
-      if (g_off[i] >= 0 && ci < a.Cin) v = in_b[(size_t)ci * src_plane + g_off[i]];
-      r_in[i] = v;
+      const bool ok = g_off[i] >= 0 && ci < a.Cin;
+      const float v = in_b[(size_t)(ci < a.Cin ? ci : a.Cin - 1) * src_plane + (g_off[i] >= 0 ? g_off[i] : 0)];
+      r_in[i] = ok ? v : 0.0f;
     }
     const int krow0 = c * W_ROWS;
 #pragma unroll
     for (int i = 0; i < W_PER_THR; ++i) {
       const int f = tid + i * NTHR;
       const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (f < W_F4 && krow0 + r < k_rows_total)
-        v = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + r) * a.CoutPad + co0 + c4 * 4);
-      r_w[i] = v;
+      // the native weight image is zero-padded to whole 16-channel row groups (einx_conv_repack),
+      // so every row a chunk can name exists; only the thread-count tail is clamped
+      const int rr = (f < W_F4) ? r : 0;
+      r_w[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + rr) * a.CoutPad + co0 + c4 * 4);
     }
   };
   auto commit_loads = [&]() {
@@ -196,35 +198,56 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
     commit_loads();
     __syncthreads();
     if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under the MFMAs below
+    // 36 K-steps (CK/2 channel pairs x taps), software pipelined: the LDS fragments of step t+1
+    // are requested before the MFMAs of step t so that no MFMA group waits on a fresh ds_read.
+    constexpr int STEPS = (CK / 2) * TAPS;
+    float av[2][kMT], bv[2][kNT];
+    auto load_frag = [&](int st, int buf) {
+      const int kp = st / TAPS, tap = st % TAPS;
+      const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
-    for (int kp = 0; kp < CK / 2; ++kp) {
+      for (int mt = 0; mt < kMT; ++mt) av[buf][mt] = w_tile[aBase + (kp * TAPS + tap) * 2 * kCoutTile + mt * 32];
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int ky = tap / KS, kx = tap % KS;
-        float av[kMT], bv[kNT];
+      for (int nt = 0; nt < kNT; ++nt) bv[buf][nt] = in_tile[bBase[nt] + kp * 2 * PLANE + ky * PW + kx];
+    };
+    load_frag(0, 0);
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt) av[mt] = w_tile[aBase + (kp * TAPS + tap) * 2 * kCoutTile + mt * 32];
+    for (int st = 0; st < STEPS; ++st) {
+      if (st + 1 < STEPS) load_frag(st + 1, (st + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) bv[nt] = in_tile[bBase[nt] + kp * 2 * PLANE + ky * PW + kx];
+      for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < kNT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-      }
+        for (int nt = 0; nt < kNT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][mt], bv[st & 1][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store -------------------------
   const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
   float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
-  // pooled layers go through LDS in rounds of 32 output channels (slab = which half of the 64)
+  // Pooling happens in registers: a 2x2 window is {lane j, lane j^1} horizontally and, vertically,
+  // either the wave's neighbouring N-tile (TW == 32: tiles nt, nt+1 are rows 2k, 2k+1) or lane
+  // j^TW inside one N-tile (TW in {8,16}: an N-tile holds 32/TW whole rows).
+  static_assert(!POOL || TW == 32 || TW == 16 || TW == 8, "in-register pooling needs TW in {8,16,32}");
+  static_assert(!POOL || TW != 32 || (NT % 2 == 0), "TW == 32 pools across N-tile pairs");
+  int ppix[kNT];  // pooled output offset inside a channel plane (valid on the window's top-left lane)
+  if (POOL) {
 #pragma unroll
-  for (int slab = 0; slab < (POOL ? 2 : 1); ++slab) {
-    if (POOL) __syncthreads();  // LDS free (main loop / previous slab's pooled reads done)
+    for (int nt = 0; nt < kNT; ++nt) {
+      ppix[nt] = -1;
+      const int q = qidx[nt];
+      if (q >= 0) {
+        const int ty = q / TW, tx = q % TW;
+        const int yo = (y0 + ty) >> 1, xo = (x0 + tx) >> 1;
+        if (!(ty & 1) && !(tx & 1) && yo < Ho && xo < Wo) ppix[nt] = yo * Wo + xo;
+      }
+    }
+  }
+  {
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) {
-      if (POOL && (wm * MT + mt) != slab) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
       const int crow = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -233,34 +256,35 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
       const float bi = (cv && a.bias) ? a.bias[co] : 0.0f;
       const float sc = (cv && a.scale) ? a.scale[co] : 1.0f;
       const float sh = (cv && a.scale) ? a.shift[co] : 0.0f;
+      float pv[kNT];
 #pragma unroll
       for (int nt = 0; nt < kNT; ++nt) {
         float v = acc[mt][nt][r] + bi;
         if (a.relu) v = v > 0.0f ? v : 0.0f;
         if (a.scale) v = fmaf(v, sc, sh);
         if (POOL) {
-          if (qidx[nt] >= 0) lds[crow * NPIX + qidx[nt]] = v;
+          pv[nt] = v;
         } else {
           if (cv && opix[nt] >= 0) out_b[(size_t)co * HW + opix[nt]] = v;
         }
       }
-      }
-    }
-    if (POOL) {
-      __syncthreads();
-      constexpr int PHo = TH / 2, PWo = TW / 2;
-      for (int idx = tid; idx < 32 * PHo * PWo; idx += NTHR) {
-        const int c = idx / (PHo * PWo);
-        const int rem = idx % (PHo * PWo);
-        const int py = rem / PWo, px = rem % PWo;
-        const int co = co0 + slab * 32 + c;
-        const int yo = y0 / 2 + py, xo = x0 / 2 + px;
-        if (co < a.Cout && yo < Ho && xo < Wo) {
-          const float* s = lds + c * NPIX + (2 * py) * TW + 2 * px;
-          const float m0 = fmaxf(s[0], s[1]);
-          const float m1 = fmaxf(s[TW], s[TW + 1]);
-          out_b[((size_t)co * Ho + yo) * Wo + xo] = fmaxf(m0, m1);
+      if (POOL) {
+        if (TW == 32) {
+#pragma unroll
+          for (int nt = 0; nt < kNT; nt += 2) {
+            float m = fmaxf(pv[nt], pv[nt + 1]);        // rows 2k, 2k+1
+            m = fmaxf(m, __shfl_xor(m, 1, 64));          // columns 2c, 2c+1
+            if (cv && ppix[nt] >= 0) out_b[(size_t)co * Ho * Wo + ppix[nt]] = m;
+          }
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < kNT; ++nt) {
+            float m = fmaxf(pv[nt], __shfl_xor(pv[nt], TW, 64));
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            if (cv && ppix[nt] >= 0) out_b[(size_t)co * Ho * Wo + ppix[nt]] = m;
+          }
         }
+      }
       }
     }
   }
@@ -293,6 +317,10 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean
   shift[i] = b[i] - mean[i] * s;
 }
 
+// rows of the native weight image: K = (ci>>1, tap, ci&1), zero-padded to whole groups of 32 input
+// channels (the largest chunk any kernel variant stages) so that chunk loads never need bounds
+int native_krows(int cin, int taps) { return einx_cdiv(cin, 32) * 32 * taps; }
+
 struct TileCfg {
   int th, tw, slots;  // slots = pixel slots a workgroup launches for this tile
 };
@@ -313,9 +341,8 @@ double tile_waste(int H, int W, const TileCfg& c) {
 
 EINX_EXPORT size_t einx_conv_weight_elems(int cin, int cout, int ks) {
   const int taps = ks * ks;
-  const int pairs = (cin + 1) / 2;
   const int coutPad = einx_cdiv(cout, kCoutTile) * kCoutTile;
-  return (size_t)pairs * 2 * taps * coutPad;
+  return (size_t)native_krows(cin, taps) * coutPad;
 }
 
 EINX_EXPORT int einx_conv_repack(const float* w_oihw, int cin, int cout, int ks, float* w_native, void* stream) {
@@ -324,7 +351,7 @@ EINX_EXPORT int einx_conv_repack(const float* w_oihw, int cin, int cout, int ks,
   EINX_CHECK_ARG(cin > 0 && cout > 0, "bad channel count");
   const int taps = ks * ks;
   const int coutPad = einx_cdiv(cout, kCoutTile) * kCoutTile;
-  const int krows = ((cin + 1) / 2) * 2 * taps;
+  const int krows = native_krows(cin, taps);
   const size_t n = (size_t)krows * coutPad;
   const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
   hipLaunchKernelGGL(conv_repack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cin, cout, taps, coutPad, krows,
@@ -395,9 +422,14 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   }
   a.tilesX = einx_cdiv(W, cfgs[best].tw);
   a.tilesY = einx_cdiv(H, cfgs[best].th);
+  static const int variant = getenv("EINX_CONV_VARIANT") ? atoi(getenv("EINX_CONV_VARIANT")) : 0;
   if (d->pool) {
     switch (best) {
-      case 0: launch<3, 8, 32, 1, 4, 2, 2, 8, true>(a, B, s); break;
+      case 0:
+        if (variant == 1) launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s);
+        else if (variant == 2) launch<3, 8, 32, 1, 4, 2, 2, 16, true>(a, B, s);
+        else launch<3, 8, 32, 1, 4, 2, 2, 8, true>(a, B, s);
+        break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
       default: launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s); break;
     }
