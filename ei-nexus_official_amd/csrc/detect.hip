@@ -81,12 +81,19 @@ __global__ void border_kernel(float* score, int B, int Hp, int Wp, int border) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: one suppression pass of fast_nms.  Tile 16x64 with halo 2R; LDS holds values and the
-// is-max bitmap.  A pass for image b runs only while the previous pass changed that image
-// (flags[b][it-1]); it raises flags[b][it] if it zeroes any non-zero pixel.  When a pass changes
-// nothing src == dst, so skipped passes leave both ping-pong buffers holding the fix-point.
+// K4: one suppression pass of fast_nms on a 32x64 tile (halo 2R), written as separable window
+// scans so that every lane does the same fixed amount of LDS work (the naive 81-tap test makes a
+// whole wave wait for its one surviving maximum on every pass):
+//   A  R9[y][x]   = max(v[y][x-R..x+R])                                   (row scan)
+//   B  ismax[y][x]= v>0 && max(v[y][x-R..x-1]) <  v && max(v[y][x+1..x+R]) <= v
+//                        && max(R9[y-R..y-1][x]) <  v && max(R9[y+1..y+R][x]) <= v
+//      (first maximum wins: earlier raster taps must be strictly smaller, later ones <=)
+//   C  rowor[y][x]= OR(ismax[y][x-R..x+R]);   D  suppressed = OR(rowor[y-R..y+R][x]) && !ismax
+// A pass for image b runs only while the previous pass changed that image (flags[b][it-1]); it
+// raises flags[b][it] if it zeroes any non-zero pixel.  When a pass changes nothing src == dst, so
+// skipped passes leave both ping-pong buffers holding the fix-point.
 // ------------------------------------------------------------------------------------------
-constexpr int NMS_TH = 16, NMS_TW = 64, NMS_MAXR = 4;
+constexpr int NMS_TH = 32, NMS_TW = 64, NMS_MAXR = 4;
 
 template <int R>
 __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
@@ -94,7 +101,9 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* 
   constexpr int VH = NMS_TH + 4 * R, VW = NMS_TW + 4 * R;  // values: tile + halo 2R
   constexpr int MH = NMS_TH + 2 * R, MW = NMS_TW + 2 * R;  // is-max: tile + halo R
   __shared__ float vals[VH * VW];
+  __shared__ float r9[VH * MW];
   __shared__ uint8_t ismax[MH * MW];
+  __shared__ uint8_t rowor[MH * NMS_TW];
   __shared__ int changed;
   int bid = blockIdx.x;
   const int txi = bid % tilesX;
@@ -114,52 +123,67 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* 
     vals[i] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? s[(size_t)y * Wp + x] : 0.0f;
   }
   __syncthreads();
+  // A: row-wise window maximum for every staged row, columns of the is-max grid
+  for (int i = tid; i < VH * MW; i += 256) {
+    const int vy = i / MW, mx = i % MW;
+    const float* row = vals + vy * VW + mx;  // window = row[0 .. 2R], centre row[R]
+    float m = row[0];
+#pragma unroll
+    for (int dx = 1; dx <= 2 * R; ++dx) m = fmaxf(m, row[dx]);
+    r9[i] = m;
+  }
+  __syncthreads();
+  // B: is-max on tile + halo R
   for (int i = tid; i < MH * MW; i += 256) {
-    const int my = i / MW, mx = i % MW;  // position in the is-max grid
-    const int vy = my + R, vx = mx + R;  // same pixel in vals
-    const float c = vals[vy * VW + vx];
-    bool ok = c > 0.0f;  // a zero centre never wins: window tap 0 is >= 0
-    // pixels outside the image are not candidates
+    const int my = i / MW, mx = i % MW;
+    const int vy = my + R;
+    const float* row = vals + vy * VW + mx;
+    const float c = row[R];
     const int y = y0 - R + my, x = x0 - R + mx;
-    ok = ok && y >= 0 && y < Hp && x >= 0 && x < Wp;
-    if (ok) {
-      for (int dy = -R; dy <= R && ok; ++dy)
-        for (int dx = -R; dx <= R; ++dx) {
-          if (dy == 0 && dx == 0) continue;
-          const float v = vals[(vy + dy) * VW + vx + dx];
-          const bool earlier = (dy < 0) || (dy == 0 && dx < 0);
-          if (earlier ? !(v < c) : !(v <= c)) {
-            ok = false;
-            break;
-          }
-        }
+    float left = row[0], right = row[R + 1];
+#pragma unroll
+    for (int dx = 1; dx < R; ++dx) {
+      left = fmaxf(left, row[dx]);
+      right = fmaxf(right, row[R + 1 + dx]);
     }
+    float above = r9[(vy - R) * MW + mx], below = r9[(vy + 1) * MW + mx];
+#pragma unroll
+    for (int dy = 1; dy < R; ++dy) {
+      above = fmaxf(above, r9[(vy - R + dy) * MW + mx]);
+      below = fmaxf(below, r9[(vy + 1 + dy) * MW + mx]);
+    }
+    const bool ok = c > 0.0f && y >= 0 && y < Hp && x >= 0 && x < Wp && left < c && above < c && right <= c && below <= c;
     ismax[i] = ok ? 1 : 0;
   }
   __syncthreads();
+  // C: row-wise OR of is-max for the tile's columns
+  for (int i = tid; i < MH * NMS_TW; i += 256) {
+    const int my = i / NMS_TW, tx = i % NMS_TW;
+    const uint8_t* row = ismax + my * MW + tx;  // window row[0 .. 2R]
+    unsigned o = 0;
+#pragma unroll
+    for (int dx = 0; dx <= 2 * R; ++dx) o |= row[dx];
+    rowor[i] = (uint8_t)o;
+  }
+  __syncthreads();
+  // D: suppress
   int my_changed = 0;
   for (int i = tid; i < NMS_TH * NMS_TW; i += 256) {
     const int ty = i / NMS_TW, tx = i % NMS_TW;
     const int y = y0 + ty, x = x0 + tx;
     if (y >= Hp || x >= Wp) continue;
     const float c = vals[(ty + 2 * R) * VW + tx + 2 * R];
-    float o = c;
-    if (c != 0.0f) {
-      bool sup = false;
-      for (int dy = -R; dy <= R && !sup; ++dy)
-        for (int dx = -R; dx <= R; ++dx) {
-          if (dy == 0 && dx == 0) continue;
-          if (ismax[(ty + R + dy) * MW + tx + R + dx]) {
-            sup = true;
-            break;
-          }
-        }
-      if (sup) {
-        o = 0.0f;
-        my_changed = 1;
-      }
+    unsigned o = 0;
+#pragma unroll
+    for (int dy = 0; dy <= 2 * R; ++dy) o |= rowor[(ty + dy) * NMS_TW + tx];
+    // a maximum has no other maximum in its window, so "some maximum nearby and not one myself"
+    const bool sup = o != 0 && !ismax[(ty + R) * MW + tx + R];
+    float out = c;
+    if (c != 0.0f && sup) {
+      out = 0.0f;
+      my_changed = 1;
     }
-    d[(size_t)y * Wp + x] = o;
+    d[(size_t)y * Wp + x] = out;
   }
   if (my_changed) changed = 1;
   __syncthreads();
