@@ -238,9 +238,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* scratch /
   return res;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelArgs a) {
-  __shared__ unsigned hist[256];
-  __shared__ int scratch[17];
+// generic path: works for any input (negative values, dense maps); 6 passes over the map
+__device__ void select_compact_generic(const SelArgs& a, unsigned* hist, int* scratch) {
   __shared__ unsigned sh_prefix, sh_rank;
   __shared__ unsigned sh_minkey;
   const int b = blockIdx.x;
@@ -346,6 +345,159 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
     base += total;
   }
   if (tid == 0) a.counts[b] = base;
+}
+
+
+// Fast path (the one the extractors hit): after NMS almost every pixel is zero, so one float4
+// sweep compacts the non-zero candidates (value + flat index, raster order preserved) into LDS;
+// the radix select and the final compaction then run on <= SEL_LCAP candidates instead of on the
+// whole map.  Falls back to the generic path when the map is dense or holds negative values.
+constexpr int SEL_LCAP = 6144;
+
+__global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ int scratch[17];
+  __shared__ float cval[SEL_LCAP];
+  __shared__ int cidx[SEL_LCAP];
+  __shared__ int sh_bad;
+  __shared__ unsigned sh_pre, sh_rk, sh_mink;
+  const int b = blockIdx.x;
+  const int N = a.Hp * a.Wp;
+  const float* m = a.map + (size_t)b * N;
+  const int tid = threadIdx.x;
+  if (tid == 0) sh_bad = 0;
+  __syncthreads();
+  // ---- sweep 1: ordered compaction of non-zeros into LDS ---------------------------------------
+  int nz = 0;
+  const bool vec = (N % 4 == 0) && ((reinterpret_cast<size_t>(m) & 15) == 0);
+  for (int i0 = 0; i0 < N; i0 += SEL_THREADS * 4) {
+    const int i = i0 + tid * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec && i + 3 < N) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(m + i);
+      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) if (i + t < N) v[t] = m[i + t];
+    }
+    int c = 0;
+    bool neg = false;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      c += (v[t] != 0.0f) ? 1 : 0;
+      neg = neg || (v[t] < 0.0f) || (v[t] != v[t]);
+    }
+    if (neg) sh_bad = 1;
+    int total;
+    int pos = nz + block_excl_scan(c, &total, scratch);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (v[t] != 0.0f) {
+        if (pos < SEL_LCAP) {
+          cval[pos] = v[t];
+          cidx[pos] = i + t;
+        }
+        ++pos;
+      }
+    nz += total;
+  }
+  __syncthreads();
+  if (sh_bad || nz > SEL_LCAP) {  // uniform across the block
+    select_compact_generic(a, hist, scratch);
+    return;
+  }
+  // ---- threshold from the order statistics ------------------------------------------------------
+  float thr = a.det_thr;
+  if (a.top_k > 0) {
+    float tk = 0.0f;
+    if (a.top_k < N) {
+      const int zeros = N - nz;  // all candidates are > 0, so zeros occupy ranks [0, zeros)
+      float vq[2] = {0.0f, 0.0f};
+      for (int w = 0; w < 2; ++w) {
+        const int rank_all = w == 0 ? a.lo : a.hi;
+        if (w == 1 && a.hi == a.lo) {
+          vq[1] = vq[0];
+          break;
+        }
+        if (rank_all < zeros) continue;  // value 0
+        unsigned prefix = 0, rank = (unsigned)(rank_all - zeros);
+        for (int pass = 0; pass < 4; ++pass) {
+          const int shift = 24 - 8 * pass;
+          for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+          __syncthreads();
+          const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+          for (int i = tid; i < nz; i += SEL_THREADS) {
+            const unsigned k = einx_ordered_key(cval[i]);
+            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+          }
+          __syncthreads();
+          if (tid == 0) {
+            unsigned run = 0;
+            int dsel = 255;
+            for (int dgt = 0; dgt < 256; ++dgt) {
+              const unsigned c = hist[dgt];
+              if (rank < run + c) {
+                dsel = dgt;
+                break;
+              }
+              run += c;
+            }
+            sh_pre = prefix | ((unsigned)dsel << shift);
+            sh_rk = rank - run;
+          }
+          __syncthreads();
+          prefix = sh_pre;
+          rank = sh_rk;
+          __syncthreads();
+        }
+        vq[w] = einx_ordered_unkey(prefix);
+      }
+      tk = vq[1] - (vq[1] - vq[0]) * 0.5f;
+    }
+    thr = fminf(tk, a.det_thr);
+  }
+  if (tid == 0) {
+    a.thr_out[b] = thr;
+    a.not_converged[b] = a.nIt > 0 ? a.flags[b * a.nIt + a.nIt - 1] : 0;
+  }
+  // ---- final raster-order compaction from the candidate list ----------------------------------------
+  int base = 0;
+  for (int i0 = 0; i0 < nz; i0 += SEL_THREADS) {
+    const int i = i0 + tid;
+    bool keep = false;
+    float v = 0.0f;
+    int fi = 0, y = 0, x = 0;
+    if (i < nz) {
+      v = cval[i];
+      fi = cidx[i];
+      y = fi / a.Wp;
+      x = fi % a.Wp;
+      const int uy = y - a.h0, ux = x - a.w0;
+      keep = v > thr && uy >= 0 && uy < a.H && ux >= 0 && ux < a.W;
+    }
+    int total;
+    const int pos = base + block_excl_scan(keep ? 1 : 0, &total, scratch);
+    if (keep && pos < a.cap) {
+      const float py = ((float)y + 0.5f) - (float)a.h0, px = ((float)x + 0.5f) - (float)a.w0;
+      float* o = a.positions + ((size_t)b * a.cap + pos) * 3;
+      o[0] = a.ordering_xy ? px : py;
+      o[1] = a.ordering_xy ? py : px;
+      o[2] = v;
+      a.indices[(size_t)b * a.cap + pos] = fi;
+    }
+    base += total;
+  }
+  if (tid == 0) a.counts[b] = base;
+  // ---- thresholded map, cropped to the unpadded window ------------------------------------------------
+  if (a.nms_out) {
+    const int HW = a.H * a.W;
+    float* o = a.nms_out + (size_t)b * HW;
+    for (int i = tid; i < HW; i += SEL_THREADS) {
+      const int uy = i / a.W, ux = i % a.W;
+      const float v = m[(size_t)(uy + a.h0) * a.Wp + ux + a.w0];
+      o[i] = v > thr ? v : 0.0f;
+    }
+  }
 }
 
 void topk_ranks(int N, int k, int* lo, int* hi) {

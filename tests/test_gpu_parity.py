@@ -434,3 +434,18 @@ def test_e2e_sp_lightglue(oracle):
         la = _np(m["log_assignment"][b])
         assert list(la.shape) == E2E[f"{name}.m.la_shapes"][b].tolist()
         np.testing.assert_allclose(la[0, ::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b], atol=5e-4, rtol=1e-4)
+
+
+def test_detect_generic_path_dense_and_negative(oracle):
+    """dense maps (more non-zeros than the LDS candidate list holds) and negative values take the
+    generic radix-select path of einx_detect; compare with the oracle bit for bit."""
+    for seed, lo_val, radius, k in ((91, 0.0, 0, 700), (92, -0.5, 0, 300), (93, -0.2, 2, 50)):
+        s = synth.uniform(seed, (2, 1, 120, 136), lo_val, 1.0)
+        exp_nms, exp_pos, exp_idx, exp_thr, _ = oracle.detect_post(s.copy(), k, radius, 0, 1.0)
+        d = pkg.native.detect(_t(s), top_k=k, radius=radius, det_thr=1.0)
+        cnt = _np(d.counts)
+        assert cnt.tolist() == [len(p) for p in exp_pos]
+        assert np.array_equal(_np(d.thr), exp_thr)
+        for b in range(2):
+            assert np.array_equal(_np(d.positions[b, :cnt[b]]), exp_pos[b])
+        assert np.array_equal(_np(d.nms), exp_nms)
