@@ -133,29 +133,38 @@ def main():
     pairs_total = max(stats["pairs"], 1.0)
     value = stats["pairs"] / elapsed
 
-    # ---- roofline of the dominant kernel: conv_block_kernel<3,8,32,4,pool> = conv1b 64->64 @264x352 ------
+    # ---- roofline of the dominant kernel: the second backbone conv (64->64 at full resolution) ----------
+    # SP-shaped nets: conv_block_kernel<3,8,32,1,4,2,2,8,true> (conv1b, fused pool); SiLK: same tile, no pool.
     roofline = None
-    if rank == 0 and args.config != "silk_mnn":
-        eng = model.image_extractor.extractor.engine()
+    if rank == 0:
+        ext = model.image_extractor.extractor
+        eng = ext.engine()
         l0, l1 = eng.backbone[0], eng.backbone[1]
-        x1 = l0(img_src, fold=(2, 3, 264, 352))
+        pads = pkg.native.padder_pads(260, 346, ext.cell_size)
+        Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
+        x1 = l0(img_src, fold=(pads[2], pads[0], Hp, Wp))
         reps = 10
         for _ in range(2):
             l1(x1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        e0.record()
+        e0.record()  # HIP events on the stream the kernel is launched on (torch's current stream)
         for _ in range(reps):
             l1(x1)
         e1.record()
         torch.cuda.synchronize()
         dur = e0.elapsed_time(e1) * 1e-3 / reps
-        flops = conv_layer_flops(64, 64, 3, 264, 352) * B
+        flops = conv_layer_flops(l1.cin, l1.cout, l1.ks, Hp, Wp) * B
         ach = flops / dur / 1e12
-        roofline = {"kernel": "conv_block_kernel<3,8,32,4,pool> (conv1b 64->64 @264x352)", "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launch_ms": round(dur * 1e3, 4), "flop_per_launch": flops,
-                    "pipeline_conv_tflops": round(sp_pair_flops(ce) * value / max(world, 1) / 1e12, 2)}
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv1b.json")
+        if args.config == "sp_mnn" and B == 32 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]  # FETCH_SIZE+WRITE_SIZE, separate --pmc passes
+        kname = f"conv_block_kernel<3,8,32,1,4,2,2,8,{'true' if l1.pool else 'false'}> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "launch_ms": round(dur * 1e3, 4),
+                    "flop_per_launch": flops,
+                    "hbm_frac_at_measured_rate": round(188.8e6 * value / max(world, 1) / 8e12, 4) if args.config == "sp_mnn" else None}
 
     # ---- CPU baseline: the oracle (a port, not the reference files) on the host cores, bounded sample ----
     cpu_baseline = None
