@@ -92,6 +92,29 @@ class ExtractorEngine:
         self.desc_head = []
         self.nms_iters = 8
 
+    def redetect(self, bf, nms_iters=None):
+        """NMS fix-point + top-k + compaction + sparse descriptor sampling on bf.score (also the
+        retry path when the fix-point needed more passes than were enqueued: only this tail of the
+        pipeline is redone, never the convolutions)."""
+        det = N.detect(bf.score, top_k=self.top_k, radius=self.radius, det_thr=self.det_thr, pads=bf.pads, ordering=self.ordering,
+                       nms_iters=nms_iters or self.nms_iters)
+        if det.cap > 8192:
+            # unbounded-capacity configuration (no top-k or detection_threshold < 1): size the
+            # descriptor buffer from the real counts (one extra sync, never on the default path)
+            cmax = max(int(det.counts.max().item()), 1)
+            det.positions = det.positions[:, :cmax].contiguous()
+            det.indices = det.indices[:, :cmax].contiguous()
+            det.cap = cmax
+        bf.det = det
+        bf.sparse_desc = N.desc_sample(bf.raw, det.indices, det.counts, bf.padded, bilinear=(self.cell == 8), scale=bf.scale)
+        return bf
+
+    def grow_nms_iters(self):
+        """The fix-point needed more passes than enqueued: quadruple the budget and keep it
+        (skipped passes cost ~4 us each, a redo costs a host round trip)."""
+        self.nms_iters = min(self.nms_iters * 4, 4096)
+        return self.nms_iters
+
     def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None):
         if x.dim() != 4:
             raise ValueError(f"Expected 4D tensor, got {x.dim()}D tensor instead.")
@@ -119,21 +142,12 @@ class ExtractorEngine:
             d = layer(d)
         raw = d
         prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
-        det = N.detect(score, top_k=self.top_k, radius=self.radius, det_thr=self.det_thr, pads=pads, ordering=self.ordering,
-                       nms_iters=nms_iters or self.nms_iters)
         bf = BatchedFeats()
         bf.kind, bf.cell, bf.B = self.kind, self.cell, B
         bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
-        bf.feats, bf.logits, bf.raw, bf.prob, bf.score, bf.det = feats, logits, raw, prob, score, det
+        bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
         bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
-        if det.cap > 8192:
-            # unbounded-capacity configuration (no top-k or detection_threshold < 1): size the
-            # descriptor buffer from the real counts (one extra sync, never on the default path)
-            cmax = max(int(det.counts.max().item()), 1)
-            det.positions = det.positions[:, :cmax].contiguous()
-            det.indices = det.indices[:, :cmax].contiguous()
-            det.cap = cmax
-        bf.sparse_desc = N.desc_sample(raw, det.indices, det.counts, (Hp, Wp), bilinear=(self.cell == 8), scale=scale)
+        self.redetect(bf, nms_iters)
         if self.cell == 8:
             bf.coarse = N.normalize_map(raw, scale)
         if dense:

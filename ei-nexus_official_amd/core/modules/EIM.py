@@ -70,17 +70,23 @@ class EIM(nn.Module):
         return ev, im, mr
 
     def forward(self, events, image, events_mask=None, image_mask=None):
-        iters, prepared = None, False
+        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask)
         while True:
-            ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, nms_iters=iters, prepared=prepared)
             rows = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
             if mr is not None:
                 rows.append(mr.nmatch)
             host = torch.stack(rows).cpu()  # the one host synchronisation of the forward pass
-            if not bool(host[2].any() or host[3].any()):
+            redo = [bool(host[2].any()), bool(host[3].any())]
+            if not any(redo):
                 break
-            iters = 4 * (iters or 8)  # NMS fix-point needed more passes than enqueued: redo
-            prepared = True  # inputs were already scaled in place (SuperPoint's image /= 255)
+            # the NMS fix-point of some image needed more passes than were enqueued: redo only the
+            # detection tail (and the matcher) with a larger, remembered, pass budget
+            for flag, bf, wrapper in ((redo[0], ev, self.event_extractor), (redo[1], im, self.image_extractor)):
+                if flag:
+                    eng = wrapper.extractor.engine()
+                    eng.redetect(bf, eng.grow_nms_iters())
+            if mr is not None:
+                mr = self.matcher.match_batched(ev, im)
         n, m = host[0].tolist(), host[1].tolist()
         events_feats = ev.materialize(n)
         image_feats = im.materialize(m)

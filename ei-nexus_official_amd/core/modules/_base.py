@@ -77,11 +77,9 @@ class NativeExtractor(nn.Module):
                                  dense=self.dense_outputs if dense is None else dense, nms_iters=nms_iters)
 
     def forward(self, x, score_mask=None, **kwargs):
-        iters = None
-        x = self._prepare_input(x)
+        bf = self.extract_batched(x, score_mask)
         while True:
-            bf = self.extract_batched(x, score_mask, nms_iters=iters, prepared=True)
             host = torch.stack([bf.det.counts, bf.det.not_converged]).cpu()
             if not bool(host[1].any()):
                 return bf.materialize(host[0].tolist())
-            iters = 4 * (iters or self.engine().nms_iters)  # NMS fix-point needs more passes: redo
+            self.engine().redetect(bf, self.engine().grow_nms_iters())  # NMS fix-point needs more passes
