@@ -134,7 +134,7 @@ def main():
     value = stats["pairs"] / elapsed
 
     # ---- roofline of the dominant kernel: the second backbone conv (64->64 at full resolution) ----------
-    # SP-shaped nets: conv_block_kernel<3,8,32,1,4,2,2,8,true> (conv1b, fused pool); SiLK: same tile, no pool.
+    # SP-shaped nets: conv_block_kernel<3,8,32,2,4,1,2,8,true> (conv1b, fused pool); SiLK: same tile, no pool.
     roofline = None
     if rank == 0:
         ext = model.image_extractor.extractor
@@ -160,7 +160,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv1b.json")
         if args.config == "sp_mnn" and B == 32 and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]  # FETCH_SIZE+WRITE_SIZE, separate --pmc passes
-        kname = f"conv_block_kernel<3,8,32,1,4,2,2,8,{'true' if l1.pool else 'false'}> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
+        kname = f"conv_block_kernel<3,8,32,2,4,1,2,8,{'true' if l1.pool else 'false'}> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
         roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "launch_ms": round(dur * 1e3, 4),
                     "flop_per_launch": flops,

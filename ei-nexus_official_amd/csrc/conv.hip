@@ -65,6 +65,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
   constexpr int LDS_FLOATS = (IN_ELEMS + W_ROWS * kCoutTile) > POOL_ELEMS ? (IN_ELEMS + W_ROWS * kCoutTile) : POOL_ELEMS;
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  __shared__ float s_bias[kCoutTile], s_scale[kCoutTile], s_shift[kCoutTile];  // epilogue constants
   float* in_tile = lds;
   float* w_tile = lds + IN_ELEMS;  // IN_ELEMS is a multiple of 4 for every instantiation
 
@@ -82,6 +83,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
   const int b = bid / a.tilesY;
   const int co0 = blockIdx.y * kCoutTile;
 
+  if (threadIdx.x < kCoutTile) {  // visible to everyone after the main loop's first barrier
+    const int co = co0 + threadIdx.x;
+    const bool cv = co < a.Cout;
+    s_bias[threadIdx.x] = (cv && a.bias) ? a.bias[co] : 0.0f;
+    s_scale[threadIdx.x] = (cv && a.scale) ? a.scale[co] : 1.0f;
+    s_shift[threadIdx.x] = (cv && a.scale) ? a.shift[co] : 0.0f;
+  }
   const int HW = a.H * a.W;
   int y0, x0, p0;
   if (KS == 1) {
@@ -253,9 +261,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
       const int crow = (r & 3) + 8 * (r >> 2) + 4 * half;
       const int co = co0 + (wm * MT + mt) * 32 + crow;
       const bool cv = co < a.Cout;
-      const float bi = (cv && a.bias) ? a.bias[co] : 0.0f;
-      const float sc = (cv && a.scale) ? a.scale[co] : 1.0f;
-      const float sh = (cv && a.scale) ? a.shift[co] : 0.0f;
+      const int cl = (wm * MT + mt) * 32 + crow;
+      const float bi = s_bias[cl], sc = s_scale[cl], sh = s_shift[cl];
       float pv[kNT];
 #pragma unroll
       for (int nt = 0; nt < kNT; ++nt) {
@@ -422,14 +429,12 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   }
   a.tilesX = einx_cdiv(W, cfgs[best].tw);
   a.tilesY = einx_cdiv(H, cfgs[best].th);
-  static const int variant = getenv("EINX_CONV_VARIANT") ? atoi(getenv("EINX_CONV_VARIANT")) : 0;
+  // Wave layouts: 8 waves (2 channel groups x 4 pixel groups, one 32x64 accumulator block each)
+  // for the 256-slot tiles, 6 waves (2 x 3) for the 192-slot tiles: two waves per SIMD from one
+  // workgroup hide each other's LDS/epilogue latency at half the accumulator registers per wave.
   if (d->pool) {
     switch (best) {
-      case 0:
-        if (variant == 1) launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s);
-        else if (variant == 2) launch<3, 8, 32, 1, 4, 2, 2, 16, true>(a, B, s);
-        else launch<3, 8, 32, 1, 4, 2, 2, 8, true>(a, B, s);
-        break;
+      case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s); break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
       default: launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s); break;
     }
@@ -439,11 +444,11 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         // thin first layers (1 / 5 input channels): stage only the channel pairs that exist
         if (d->cin <= 2) launch<3, 8, 32, 1, 4, 2, 2, 2, false>(a, B, s);
         else if (d->cin <= 6) launch<3, 8, 32, 1, 4, 2, 2, 6, false>(a, B, s);
-        else launch<3, 8, 32, 1, 4, 2, 2, 8, false>(a, B, s);
+        else launch<3, 8, 32, 2, 4, 1, 2, 8, false>(a, B, s);
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
       case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;
-      default: launch<3, 11, 22, 1, 4, 2, 2, 8, false>(a, B, s); break;
+      default: launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s); break;
     }
   }
   EINX_CHECK_LAUNCH();
