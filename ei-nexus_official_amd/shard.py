@@ -44,7 +44,7 @@ class MetricAccumulator:
 
     def all_reduce(self):
         self.v = torch.tensor(self.host, dtype=torch.float64, device=self.device)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.v, op=dist.ReduceOp.SUM)
         return self
 
