@@ -64,6 +64,10 @@ SIGNATURES = {
                          c_void_p, c_void_p, c_void_p]),
     "einx_gather_matches": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    "einx_events_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "einx_voxel_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p]),
+    "einx_events_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "einx_lg_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "einx_lightglue": (c_int, [ctypes.POINTER(LgWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -186,6 +186,21 @@ int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* de
                    int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, float* ref0, float* ref1,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Event representation (the step before the path)
+ * events of B samples are concatenated; offsets_host[B+1] (HOST array) delimits the samples.
+ * x, y, p: float32 [N]; t: float64 [N] raw timestamps (normalised inside exactly like
+ * datasets/representations.py:8-21).  ws: einx_events_ws_bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t einx_events_ws_bytes(int B, int H, int W);
+/* events_to_voxel_grid (datasets/representations.py:67-124): grid [B,bins,H,W] */
+int einx_voxel_grid(const float* x, const float* y, const double* t, const float* p, const int64_t* offsets_host, int B, int bins, int H,
+                    int W, int normalize, float* grid, void* ws, void* stream);
+/* draw_events_accumulation_image(...) > 0 (datasets/visualize.py:23-50,
+ * test_events-image_same-time.py:137): mask uint8 [B,H,W] */
+int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host, int B, int H, int W, void* ws, uint8_t* mask,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -804,3 +804,72 @@ EXPORT void orc_lg_assign(const float* x0, int n, const float* x1, int m, int d,
   free(z0);
   free(md0);
 }
+
+/* =======================================================================================
+ * Event representation (the step before the path).
+ * ===================================================================================== */
+
+/* events_to_voxel_grid (datasets/representations.py:67-124) incl. time_normalization (:8-21):
+ * float64 time normalisation, fp32 trilinear weights, sequential accumulation in the reference's
+ * loop order (corner loops outermost, events in order), then (v-mean)/std(unbiased) on non-zeros. */
+EXPORT void orc_voxel_grid(const float* x, const float* y, const double* t, const float* p, long long n, int bins, int H, int W,
+                           int normalize, float* grid) {
+  const size_t per = (size_t)bins * H * W;
+  memset(grid, 0, per * sizeof(float));
+  if (n <= 0) return;
+  const double t0d = t[0], den = (t[n - 1] - t[0]) + 1e-8;
+  const float tf0 = (float)(0.0 / den), tfl = (float)((t[n - 1] - t0d) / den);
+  for (int dx = 0; dx < 2; ++dx)
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dt = 0; dt < 2; ++dt)
+        for (long long i = 0; i < n; ++i) {
+          const float tf = (float)((t[i] - t0d) / den);
+          const float tn = ((float)(bins - 1) * (tf - tf0)) / (tfl - tf0);
+          float value = p[i];
+          if (value < 1.0f) value = -1.0f;
+          const int xl = (int)x[i] + dx, yl = (int)y[i] + dy, tl = (int)tn + dt;
+          if (xl < W && xl >= 0 && yl < H && yl >= 0 && tl >= 0 && tl < bins) {
+            const float w = value * (1.0f - fabsf((float)xl - x[i])) * (1.0f - fabsf((float)yl - y[i])) * (1.0f - fabsf((float)tl - tn));
+            grid[((size_t)tl * H + yl) * W + xl] += w;
+          }
+        }
+  if (normalize) {
+    double c = 0, s = 0, q = 0;
+    for (size_t i = 0; i < per; ++i)
+      if (grid[i] != 0.0f) {
+        c += 1;
+        s += grid[i];
+        q += (double)grid[i] * grid[i];
+      }
+    if (c > 0) {
+      const double mean = s / c;
+      double var = c > 1 ? (q - c * mean * mean) / (c - 1) : 0.0;
+      if (var < 0) var = 0;
+      const float meanf = (float)mean, stdf = (float)sqrt(var);
+      for (size_t i = 0; i < per; ++i)
+        if (grid[i] != 0.0f) grid[i] = stdf > 0.0f ? (grid[i] - meanf) / stdf : (grid[i] - meanf);
+    }
+  }
+}
+
+/* draw_events_accumulation_image (datasets/visualize.py:23-50) followed by `> 0`
+ * (test_events-image_same-time.py:137): count image, min-max scaled to 0..255 in float64,
+ * truncated to uint8. */
+EXPORT void orc_events_mask(const float* x, const float* y, long long n, int H, int W, uint8_t* mask) {
+  double* img = (double*)calloc((size_t)H * W, sizeof(double));
+  for (long long i = 0; i < n; ++i) {
+    const int yi = (int)y[i], xi = (int)x[i];
+    if (yi >= 0 && yi < H && xi >= 0 && xi < W) img[(size_t)yi * W + xi] += 1.0;
+  }
+  double lo = img[0], hi = img[0];
+  for (size_t i = 0; i < (size_t)H * W; ++i) {
+    if (img[i] < lo) lo = img[i];
+    if (img[i] > hi) hi = img[i];
+  }
+  for (size_t i = 0; i < (size_t)H * W; ++i) {
+    double v = (img[i] - lo) / (hi - lo) * 255.0;
+    if (v > 255.0) v = 255.0;
+    mask[i] = (v == v && (int)v > 0) ? 1 : 0;
+  }
+  free(img);
+}

@@ -387,3 +387,23 @@ def matched_kpts(kpts0, kpts1, matches0, cols):
     """ascending-i gather of matched keypoints (MNN.py:119-129 -> 3 columns; lightglue.py:690-698 -> 2)."""
     sel = np.nonzero(matches0 > -1)[0]
     return kpts0[sel][:, :cols], kpts1[matches0[sel]][:, :cols]
+
+
+# ------------------------------------------------------------------------------ event representation
+def voxel_grid(events, input_size, normalize=True):
+    """events_to_voxel_grid (datasets/representations.py:67-124); events: dict of numpy arrays."""
+    bins, H, W = (int(v) for v in input_size)
+    x, y = _c(events["x"]), _c(events["y"])
+    t, p = _c(events["t"], np.float64), _c(events["p"])
+    grid = np.empty((bins, H, W), np.float32)
+    lib().orc_voxel_grid(_f(x), _f(y), t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _f(p), ctypes.c_longlong(len(x)), bins, H, W,
+                         int(normalize), _f(grid))
+    return grid
+
+
+def events_mask(events, resolution):
+    W, H = (int(v) for v in resolution)
+    x, y = _c(events["x"]), _c(events["y"])
+    mask = np.empty((H, W), np.uint8)
+    lib().orc_events_mask(_f(x), _f(y), ctypes.c_longlong(len(x)), H, W, mask.ctypes.data_as(c_u8))
+    return mask.astype(bool)

@@ -470,7 +470,65 @@ def gen_lg():
     save("lg.npz", **out)
 
 
-GROUPS = {"post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
+# =========================================================================================
+# events: raw events -> voxel grid and events mask (datasets/representations.py, visualize.py)
+# =========================================================================================
+EVENT_CASES = [
+    dict(name="int_p01", seed=71, n=3000, H=40, W=48, bins=5, frac=False, pneg=False),
+    dict(name="frac_pm1", seed=72, n=2500, H=37, W=45, bins=16, frac=True, pneg=True),
+    dict(name="full", seed=73, n=60000, H=260, W=346, bins=5, frac=False, pneg=False),
+]
+
+
+def synth_raw_events(c):
+    n, H, W = c["n"], c["H"], c["W"]
+    u = synth.uniform01(c["seed"], (n,)).astype(np.float64)
+    t = 1.5e9 + np.cumsum(u * 1e-4 + 1e-6)  # increasing float64 timestamps
+    x = synth.uniform01(c["seed"] + 1, (n,)) * np.float32(W - 1)
+    y = synth.uniform01(c["seed"] + 2, (n,)) * np.float32(H - 1)
+    if not c["frac"]:
+        x, y = np.floor(x), np.floor(y)
+    # cluster a share of the events so that the accumulation image has a wide count range
+    hot = synth.uniform01(c["seed"] + 4, (n,)) < np.float32(0.3)
+    x = np.where(hot, np.float32(W // 2) + np.floor(x / 8), x).astype(np.float32)
+    y = np.where(hot, np.float32(H // 2) + np.floor(y / 8), y).astype(np.float32)
+    p = (synth.uniform01(c["seed"] + 3, (n,)) < np.float32(0.5)).astype(np.float32)
+    if c["pneg"]:
+        p = 2 * p - 1
+    return {"x": x.astype(np.float32), "y": y.astype(np.float32), "t": t, "p": p.astype(np.float32)}
+
+
+def gen_events():
+    # the reference's `datasets/` has no __init__.py and would lose against the installed
+    # HuggingFace `datasets` package, so load its two files by path
+    def _load(name):
+        sp = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, "datasets", name + ".py"))
+        mod = importlib.util.module_from_spec(sp)
+        sp.loader.exec_module(mod)
+        return mod
+    sys.modules.setdefault("matplotlib.pyplot", __import__("types").ModuleType("matplotlib.pyplot"))
+    ref_rep = _load("representations")
+    draw_events_accumulation_image = _load("visualize").draw_events_accumulation_image
+    out = {"meta": meta(cases=EVENT_CASES)}
+    for c in EVENT_CASES:
+        ev = synth_raw_events(c)
+        grid = ref_rep.events_to_voxel_grid({k: v.copy() for k, v in ev.items()}, (c["bins"], c["H"], c["W"]), normalize=True)
+        raw = ref_rep.events_to_voxel_grid({k: v.copy() for k, v in ev.items()}, (c["bins"], c["H"], c["W"]), normalize=False)
+        img = draw_events_accumulation_image({k: v.copy() for k, v in ev.items()}, (c["W"], c["H"]))
+        n = c["name"]
+        if grid.numel() <= 70000:
+            out[f"{n}.grid"] = grid.numpy()
+            out[f"{n}.raw"] = raw.numpy()
+        else:
+            out[f"{n}.grid.stride7"] = grid.reshape(-1)[::7].numpy()
+            out[f"{n}.raw.stride7"] = raw.reshape(-1)[::7].numpy()
+        out[f"{n}.mask"] = np.packbits(img > 0)
+        out[f"{n}.mask_count"] = np.array([int((img > 0).sum())])
+        print(n, float(grid.abs().sum()), int((img > 0).sum()))
+    save("events.npz", **out)
+
+
+GROUPS = {"events": gen_events, "post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -104,3 +104,21 @@ def split(flat, counts):
         out.append(flat[o:o + int(c)])
         o += int(c)
     return out
+
+
+def synth_raw_events(c):
+    """Same recipe as tests/golden/gen_golden.py::synth_raw_events."""
+    n, H, W = c["n"], c["H"], c["W"]
+    u = synth.uniform01(c["seed"], (n,)).astype(np.float64)
+    t = 1.5e9 + np.cumsum(u * 1e-4 + 1e-6)
+    x = synth.uniform01(c["seed"] + 1, (n,)) * np.float32(W - 1)
+    y = synth.uniform01(c["seed"] + 2, (n,)) * np.float32(H - 1)
+    if not c["frac"]:
+        x, y = np.floor(x), np.floor(y)
+    hot = synth.uniform01(c["seed"] + 4, (n,)) < np.float32(0.3)
+    x = np.where(hot, np.float32(W // 2) + np.floor(x / 8), x).astype(np.float32)
+    y = np.where(hot, np.float32(H // 2) + np.floor(y / 8), y).astype(np.float32)
+    p = (synth.uniform01(c["seed"] + 3, (n,)) < np.float32(0.5)).astype(np.float32)
+    if c["pneg"]:
+        p = 2 * p - 1
+    return {"x": x.astype(np.float32), "y": y.astype(np.float32), "t": t, "p": p.astype(np.float32)}

@@ -449,3 +449,38 @@ def test_detect_generic_path_dense_and_negative(oracle):
         for b in range(2):
             assert np.array_equal(_np(d.positions[b, :cnt[b]]), exp_pos[b])
         assert np.array_equal(_np(d.nms), exp_nms)
+
+
+# ------------------------------------------------------------------ event representation (next row 8f-2)
+EVENTS = Golden("events")
+
+
+def test_voxel_grid_and_events_mask(oracle):
+    from importlib import import_module
+    from helpers import synth_raw_events
+    rep = import_module(pkg.__name__ + ".datasets.representations")
+    cases = [EVENTS.cases[n] for n in ("int_p01", "frac_pm1", "full")]
+    for c in cases:
+        ev = synth_raw_events(c)
+        size = (c["bins"], c["H"], c["W"])
+        keep = {k: v.copy() for k, v in ev.items()}
+        grid = _np(rep.events_to_voxel_grid(ev, size, normalize=True))
+        raw = _np(rep.events_to_voxel_grid(ev, size, normalize=False))
+        assert all(np.array_equal(ev[k], keep[k]) for k in ev)  # the caller's dict is left alone
+        name = c["name"]
+        # fp32 atomics: equal to the reference up to summation order
+        np.testing.assert_allclose(raw, oracle.voxel_grid(ev, size, normalize=False), atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(grid, oracle.voxel_grid(ev, size, normalize=True), atol=2e-5, rtol=1e-5)
+        if f"{name}.grid" in EVENTS:
+            np.testing.assert_allclose(grid, EVENTS[f"{name}.grid"], atol=2e-5, rtol=1e-5)
+        else:
+            np.testing.assert_allclose(grid.reshape(-1)[::7], EVENTS[f"{name}.grid.stride7"], atol=2e-5, rtol=1e-5)
+        assert (raw != 0).sum() == (oracle.voxel_grid(ev, size, normalize=False) != 0).sum()
+        mask = _np(rep.events_mask_batch([ev], (c["W"], c["H"])))[0, 0]
+        exp = np.unpackbits(EVENTS[f"{name}.mask"])[:c["H"] * c["W"]].astype(bool).reshape(c["H"], c["W"])
+        assert np.array_equal(mask, exp)  # integer counts: bit exact
+    # batched call == per-sample calls
+    small = [synth_raw_events(EVENTS.cases["int_p01"]), synth_raw_events(dict(EVENTS.cases["int_p01"], seed=99, n=1000))]
+    gb = _np(rep.events_to_voxel_grid_batch(small, (5, 40, 48), normalize=False))
+    for b, e in enumerate(small):
+        np.testing.assert_allclose(gb[b], oracle.voxel_grid(e, (5, 40, 48), normalize=False), atol=2e-5, rtol=1e-5)

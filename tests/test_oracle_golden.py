@@ -260,3 +260,27 @@ def test_e2e_full_size(oracle, name):
         la = r["log_assignment"]
         assert list(la[None].shape) == E2E[f"{name}.m.la_shapes"][b].tolist()
         np.testing.assert_allclose(la[::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b], atol=5e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ event representation (next row 8f-2)
+EVENTS = Golden("events")
+
+
+@pytest.mark.parametrize("name", list(EVENTS.cases))
+def test_voxel_grid_and_mask(oracle, name):
+    from helpers import synth_raw_events
+    c = EVENTS.cases[name]
+    ev = synth_raw_events(c)
+    size = (c["bins"], c["H"], c["W"])
+    raw = oracle.voxel_grid(ev, size, normalize=False)
+    grid = oracle.voxel_grid(ev, size, normalize=True)
+    if f"{name}.grid" in EVENTS:
+        assert np.array_equal(raw, EVENTS[f"{name}.raw"])  # same accumulation order as the reference
+        np.testing.assert_allclose(grid, EVENTS[f"{name}.grid"], atol=1e-5, rtol=1e-5)
+    else:
+        # 60k events: torch's put_(accumulate=True) no longer adds in plain event order
+        np.testing.assert_allclose(raw.reshape(-1)[::7], EVENTS[f"{name}.raw.stride7"], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(grid.reshape(-1)[::7], EVENTS[f"{name}.grid.stride7"], atol=1e-5, rtol=1e-5)
+    mask = oracle.events_mask(ev, (c["W"], c["H"]))
+    exp = np.unpackbits(EVENTS[f"{name}.mask"])[:c["H"] * c["W"]].astype(bool).reshape(c["H"], c["W"])
+    assert np.array_equal(mask, exp)
