@@ -25,6 +25,11 @@ class DetectParams(ctypes.Structure):
                 ("nms_iters", ctypes.c_int32)]
 
 
+class MetricParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "cap0", "cap1", "D", "cols", "H0", "W0", "H1", "W1", "kp_yx", "n_mma", "n_vdd")] + \
+               [("mma_thr", c_float * 4), ("vdd_thr", c_float * 4)]
+
+
 class LgLayer(ctypes.Structure):
     _names = ("Wqkv", "bqkv", "Wo", "bo", "sf0_w", "sf0_b", "sln_g", "sln_b", "sf3_w", "sf3_b",
               "Wqk", "bqk", "Wv", "bv", "Wco", "bco", "cf0_w", "cf0_b", "cln_g", "cln_b", "cf3_w", "cf3_b")
@@ -68,6 +73,8 @@ SIGNATURES = {
     "einx_voxel_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     "einx_events_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "einx_metrics_ws_bytes": (c_size_t, [ctypes.POINTER(MetricParams)]),
+    "einx_pair_metrics": (c_int, [ctypes.POINTER(MetricParams)] + [c_void_p] * 13),
     "einx_lg_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "einx_lightglue": (c_int, [ctypes.POINTER(LgWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

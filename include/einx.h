@@ -201,6 +201,29 @@ int einx_voxel_grid(const float* x, const float* y, const double* t, const float
 int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host, int B, int H, int W, void* ws, uint8_t* mask,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics of the reference's test harness (the step after the path)
+ *   MatchingRatio            core/metrics/matching_metrics.py:30-51
+ *   MeanMatchingAccuracy@t   core/metrics/matching_metrics.py:84-156   (points ordering "yx")
+ *   ValidDescriptorsDistance core/metrics/keypoints_metrics.py:160-290 (repeat./distance/angle @t)
+ * Inputs are the device-side batch results of the path: keypoints [B,cap,3], descriptors
+ * [B,cap,D], counts, matched keypoints [B,cap0,cols] + nmatch (einx_gather_matches), optional
+ * homography [B,9] (NULL = identity, as test_events-image_same-time.py:146 uses).
+ * out: [B, 1 + n_mma + 3*n_vdd] float64 = MR, MMA@t..., (Repeatability, ValidDistance, Angle)@t...
+ * ---------------------------------------------------------------------------------------- */
+typedef struct einx_metric_params {
+  int32_t B, cap0, cap1, D, cols;
+  int32_t H0, W0, H1, W1; /* img1_shape, img2_shape */
+  int32_t kp_yx;          /* 1: keypoints are (y,x,..) (the extractors' "yx" ordering) */
+  int32_t n_mma, n_vdd;
+  float mma_thr[4];
+  float vdd_thr[4];
+} einx_metric_params;
+size_t einx_metrics_ws_bytes(const einx_metric_params* p);
+int einx_pair_metrics(const einx_metric_params* p, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                      const int32_t* n, const int32_t* m, const float* mk0, const float* mk1, const int32_t* nmatch,
+                      const float* homography, void* ws, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

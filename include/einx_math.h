@@ -170,6 +170,27 @@ EINX_HD float einx_logsigmoidf(float x) {
 /* exact GELU (erf form): 0.5 x (1 + erf(x / sqrt 2)). */
 EINX_HD float einx_geluf(float x) { return 0.5f * x * (1.0f + einx_erff(x * 0.707106781186547524f)); }
 
+/* acos(x) (cephes-style asin polynomial), ~2 ulp; |x| > 1 gives NaN like libm.
+ * Reference: torch.acos in core/metrics/keypoints_metrics.py:241-247. */
+EINX_HD float einx_asin_poly(float z, float x) {
+  /* asin(x) = x + x z P(z), z = x^2, |x| <= 0.5 */
+  float p = 4.2163199048e-2f;
+  p = fmaf(p, z, 2.4181311049e-2f);
+  p = fmaf(p, z, 4.5470025998e-2f);
+  p = fmaf(p, z, 7.4953002686e-2f);
+  p = fmaf(p, z, 1.6666752422e-1f);
+  return fmaf(x * z, p, x);
+}
+EINX_HD float einx_acosf(float x) {
+  const float ax = fabsf(x);
+  if (!(ax <= 1.0f)) return einx_u2f(0x7fc00000u);
+  if (ax <= 0.5f) return 1.57079632679489662f - einx_asin_poly(x * x, x);
+  const float z = 0.5f * (1.0f - ax);
+  const float s = sqrtf(z);
+  const float r = 2.0f * einx_asin_poly(z, s);
+  return x > 0.0f ? r : 3.14159265358979324f - r;
+}
+
 /* order-preserving map float -> uint32 (for radix selection / packed arg-max keys). */
 EINX_HD uint32_t einx_ordered_key(float f) {
   uint32_t u = einx_f2u(f);

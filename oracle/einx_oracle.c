@@ -873,3 +873,108 @@ EXPORT void orc_events_mask(const float* x, const float* y, long long n, int H, 
   }
   free(img);
 }
+
+/* =======================================================================================
+ * Evaluation metrics of the reference's harness (the step after the path).
+ * ===================================================================================== */
+static void orc_warp(const float* h, float x, float y, float* ox, float* oy) {
+  const float a = fmaf(h[2], 1.0f, fmaf(h[1], y, h[0] * x));
+  const float b = fmaf(h[5], 1.0f, fmaf(h[4], y, h[3] * x));
+  const float c = fmaf(h[8], 1.0f, fmaf(h[7], y, h[6] * x));
+  *ox = a / c;
+  *oy = b / c;
+}
+
+/* MatchingRatio (matching_metrics.py:30-51), MeanMatchingAccuracy (:84-156),
+ * ValidDescriptorsDistance (keypoints_metrics.py:160-290) for one pair.
+ * k0 [n,3], k1 [m,3] keypoints ((y,x,p) if kp_yx), d0/d1 descriptors, mk0/mk1 [M,cols] matches,
+ * hom 3x3 row-major or NULL (identity).  out = MR, MMA@t.., (Rep, ValidDist, Angle)@t.. */
+EXPORT void orc_pair_metrics(const float* k0, int n, const float* k1, int m, const float* d0, const float* d1, int D, const float* mk0,
+                             const float* mk1, int M, int cols, const float* hom, int H0, int W0, int H1, int W1, int kp_yx,
+                             const float* mma_thr, int n_mma, const float* vdd_thr, int n_vdd, double* out) {
+  float h[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, hi[9];
+  if (hom) memcpy(h, hom, sizeof(h));
+  {
+    const float c00 = h[4] * h[8] - h[5] * h[7], c01 = h[5] * h[6] - h[3] * h[8], c02 = h[3] * h[7] - h[4] * h[6];
+    const float det = h[0] * c00 + h[1] * c01 + h[2] * c02;
+    hi[0] = c00 / det; hi[1] = (h[2] * h[7] - h[1] * h[8]) / det; hi[2] = (h[1] * h[5] - h[2] * h[4]) / det;
+    hi[3] = c01 / det; hi[4] = (h[0] * h[8] - h[2] * h[6]) / det; hi[5] = (h[2] * h[3] - h[0] * h[5]) / det;
+    hi[6] = c02 / det; hi[7] = (h[1] * h[6] - h[0] * h[7]) / det; hi[8] = (h[0] * h[4] - h[1] * h[3]) / det;
+  }
+  const int xi = kp_yx ? 1 : 0, yi = kp_yx ? 0 : 1;
+  int o = 0;
+  out[o++] = (double)M / ((double)(n < m ? n : m) + 1e-8);
+  for (int t = 0; t < n_mma; ++t) {
+    int good = 0;
+    for (int i = 0; i < M; ++i) {
+      float wx, wy;
+      orc_warp(h, mk0[i * cols + xi], mk0[i * cols + yi], &wx, &wy);
+      const float dx = wx - mk1[i * cols + xi], dy = wy - mk1[i * cols + yi];
+      if (sqrtf(dx * dx + dy * dy) <= mma_thr[t]) ++good;
+    }
+    out[o++] = M > 0 ? (double)((float)good / (float)M) : 0.0;
+  }
+  float* tw = (float*)malloc(sizeof(float) * 2 * (n + 1));
+  uint8_t* keep0 = (uint8_t*)malloc(n + 1);
+  uint8_t* keep1 = (uint8_t*)malloc(m + 1);
+  int N1 = 0, N2 = 0;
+  for (int i = 0; i < n; ++i) {
+    orc_warp(h, k0[i * 3 + xi], k0[i * 3 + yi], &tw[2 * i], &tw[2 * i + 1]);
+    keep0[i] = tw[2 * i] >= 0.0f && tw[2 * i] < (float)W1 && tw[2 * i + 1] >= 0.0f && tw[2 * i + 1] < (float)H1;
+    N1 += keep0[i];
+  }
+  for (int j = 0; j < m; ++j) {
+    float wx, wy;
+    orc_warp(hi, k1[j * 3 + xi], k1[j * 3 + yi], &wx, &wy);
+    keep1[j] = wx >= 0.0f && wx < (float)W0 && wy >= 0.0f && wy < (float)H0;
+    N2 += keep1[j];
+  }
+  for (int t = 0; t < n_vdd; ++t) {
+    int cnt = 0;
+    double sd = 0.0, sa = 0.0;
+    for (int side = 0; side < 2; ++side) {
+      const int ns = side == 0 ? n : m, no = side == 0 ? m : n;
+      for (int i = 0; i < ns; ++i) {
+        if (!(side == 0 ? keep0[i] : keep1[i])) continue;
+        float best = INFINITY;
+        int bj = -1;
+        for (int j = 0; j < no; ++j) {
+          if (!(side == 0 ? keep1[j] : keep0[j])) continue;
+          const int a0 = side == 0 ? i : j, b1 = side == 0 ? j : i;
+          const float dx = tw[2 * a0] - k1[b1 * 3 + xi], dy = tw[2 * a0 + 1] - k1[b1 * 3 + yi];
+          const float dd = sqrtf(fmaf(dy, dy, dx * dx));
+          if (dd < best) {
+            best = dd;
+            bj = j;
+          }
+        }
+        if (bj < 0 || !(best <= vdd_thr[t])) continue;
+        const float* v1 = d0 + (size_t)(side == 0 ? i : bj) * D;
+        const float* v2 = d1 + (size_t)(side == 0 ? bj : i) * D;
+        float sq = 0, dot = 0, n1 = 0, n2 = 0;
+        for (int c = 0; c < D; ++c) {
+          const float df = v1[c] - v2[c];
+          sq = fmaf(df, df, sq);
+          dot = fmaf(v1[c], v2[c], dot);
+          n1 = fmaf(v1[c], v1[c], n1);
+          n2 = fmaf(v2[c], v2[c], n2);
+        }
+        ++cnt;
+        sd += sqrtf(sq);
+        sa += einx_acosf(dot / (sqrtf(n1) * sqrtf(n2))) * 57.29577951308232f;
+      }
+    }
+    double rep = 0, vd = 0, ang = 0;
+    if (N1 != 0 && N2 != 0) {
+      rep = (double)((float)cnt / (float)(N1 + N2));
+      vd = sd / (double)cnt;
+      ang = sa / (double)cnt;
+    }
+    out[o++] = rep;
+    out[o++] = vd;
+    out[o++] = ang;
+  }
+  free(tw);
+  free(keep0);
+  free(keep1);
+}

@@ -407,3 +407,18 @@ def events_mask(events, resolution):
     mask = np.empty((H, W), np.uint8)
     lib().orc_events_mask(_f(x), _f(y), ctypes.c_longlong(len(x)), H, W, mask.ctypes.data_as(c_u8))
     return mask.astype(bool)
+
+
+# ------------------------------------------------------------------------------ evaluation metrics
+def pair_metrics(k0, k1, d0, d1, mk0, mk1, size0, size1, hom=None, mma_thr=(1, 3), vdd_thr=(1, 3), kp_yx=True):
+    """MR, MMA@t, VDD (repeatability, distance, angle)@t for one pair (core/metrics/*)."""
+    k0, k1, d0, d1 = _c(k0), _c(k1), _c(d0), _c(d1)
+    mk0, mk1 = _c(mk0), _c(mk1)
+    cols = mk0.shape[1] if mk0.ndim == 2 and mk0.shape[0] else 3
+    mt, vt = _c(list(mma_thr)), _c(list(vdd_thr))
+    out = np.zeros((1 + len(mma_thr) + 3 * len(vdd_thr),), np.float64)
+    h = None if hom is None else _c(hom).reshape(9)
+    lib().orc_pair_metrics(_f(k0), k0.shape[0], _f(k1), k1.shape[0], _f(d0), _f(d1), d0.shape[1], _f(mk0), _f(mk1), mk0.shape[0], cols, _f(h),
+                           int(size0[0]), int(size0[1]), int(size1[0]), int(size1[1]), int(kp_yx), _f(mt), len(mma_thr), _f(vt), len(vdd_thr),
+                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out

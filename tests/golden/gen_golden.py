@@ -528,7 +528,52 @@ def gen_events():
     save("events.npz", **out)
 
 
-GROUPS = {"events": gen_events, "post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
+# =========================================================================================
+# metrics: MatchingRatio, MeanMatchingAccuracy, ValidDescriptorsDistance (core/metrics)
+# =========================================================================================
+METRIC_CASES = [
+    dict(name="identity", seed=81, n=300, m=280, D=64, hom=None),
+    dict(name="homography", seed=82, n=400, m=350, D=256, hom=[1.02, 0.015, -3.0, -0.01, 0.98, 2.5, 1e-5, -2e-5, 1.0]),
+    dict(name="nomatch", seed=83, n=50, m=60, D=32, hom=None, M=0),
+]
+
+
+def metric_inputs(c):
+    n, m, D = c["n"], c["m"], c["D"]
+    H, W = 260, 346
+    k0 = np.stack([synth.uniform(c["seed"], (n,), 4, H - 4), synth.uniform(c["seed"] + 1, (n,), 4, W - 4), synth.uniform01(c["seed"] + 2, (n,))], 1)
+    # image-1 keypoints: noisy copies of a share of image-0 keypoints (so neighbours within 1-3 px exist) plus random ones
+    share = min(n, m) * 2 // 3
+    k1 = np.stack([synth.uniform(c["seed"] + 3, (m,), 4, H - 4), synth.uniform(c["seed"] + 4, (m,), 4, W - 4), synth.uniform01(c["seed"] + 5, (m,))], 1)
+    k1[:share, :2] = k0[:share, :2] + synth.uniform(c["seed"] + 6, (share, 2), -2.5, 2.5)
+    d0 = synth.synth_unit_descriptors(c["seed"] + 7, n, D)
+    d1 = synth.synth_unit_descriptors(c["seed"] + 8, m, D)
+    d1[:share] = d0[:share] * np.float32(0.8) + d1[:share] * np.float32(0.6)
+    M = c.get("M", share // 2)
+    mk0 = k0[:M].copy()
+    mk1 = k1[:M].copy()
+    return [a.astype(np.float32) for a in (k0, k1, d0, d1, mk0, mk1)]
+
+
+def gen_metrics():
+    from core.metrics.keypoints_metrics import ValidDescriptorsDistance
+    from core.metrics.matching_metrics import MatchingRatio, MeanMatchingAccuracy
+    out = {"meta": meta(cases=METRIC_CASES)}
+    for c in METRIC_CASES:
+        k0, k1, d0, d1, mk0, mk1 = [torch.from_numpy(a) for a in metric_inputs(c)]
+        Hm = torch.eye(3) if c["hom"] is None else torch.tensor(c["hom"], dtype=torch.float32).reshape(3, 3)
+        vals = {}
+        vals.update(MatchingRatio("MR").update_one(mk0, mk1, k0, k1))
+        for t in (1, 3):
+            vals.update(MeanMatchingAccuracy(f"MMA@{t}", threshold=t).update_one(mk0, mk1, Hm))
+        vals.update(ValidDescriptorsDistance("VDD", [1, 3]).update_one(k0, k1, d0, d1, (260, 346), (260, 346), Hm))
+        names = ["MR", "MMA@1", "MMA@3"] + [f"VDD_{p}@{t}" for t in (1, 3) for p in ("Repeatability", "ValidDistance", "Angle")]
+        out[f"{c['name']}.values"] = np.array([vals[k] for k in names], np.float64)
+        print(c["name"], {k: round(vals[k], 5) for k in names})
+    save("metrics.npz", **out)
+
+
+GROUPS = {"metrics": gen_metrics, "events": gen_events, "post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -122,3 +122,20 @@ def synth_raw_events(c):
     if c["pneg"]:
         p = 2 * p - 1
     return {"x": x.astype(np.float32), "y": y.astype(np.float32), "t": t, "p": p.astype(np.float32)}
+
+
+def metric_inputs(c):
+    """Same recipe as tests/golden/gen_golden.py::metric_inputs."""
+    n, m, D = c["n"], c["m"], c["D"]
+    H, W = 260, 346
+    k0 = np.stack([synth.uniform(c["seed"], (n,), 4, H - 4), synth.uniform(c["seed"] + 1, (n,), 4, W - 4), synth.uniform01(c["seed"] + 2, (n,))], 1)
+    share = min(n, m) * 2 // 3
+    k1 = np.stack([synth.uniform(c["seed"] + 3, (m,), 4, H - 4), synth.uniform(c["seed"] + 4, (m,), 4, W - 4), synth.uniform01(c["seed"] + 5, (m,))], 1)
+    k1[:share, :2] = k0[:share, :2] + synth.uniform(c["seed"] + 6, (share, 2), -2.5, 2.5)
+    d0 = synth.synth_unit_descriptors(c["seed"] + 7, n, D)
+    d1 = synth.synth_unit_descriptors(c["seed"] + 8, m, D)
+    d1[:share] = d0[:share] * np.float32(0.8) + d1[:share] * np.float32(0.6)
+    M = c.get("M", share // 2)
+    mk0 = k0[:M].copy()
+    mk1 = k1[:M].copy()
+    return [a.astype(np.float32) for a in (k0, k1, d0, d1, mk0, mk1)]

@@ -484,3 +484,50 @@ def test_voxel_grid_and_events_mask(oracle):
     gb = _np(rep.events_to_voxel_grid_batch(small, (5, 40, 48), normalize=False))
     for b, e in enumerate(small):
         np.testing.assert_allclose(gb[b], oracle.voxel_grid(e, (5, 40, 48), normalize=False), atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ evaluation metrics (next row 8f-1)
+METRICS = Golden("metrics")
+
+
+@pytest.mark.parametrize("name", list(METRICS.cases))
+def test_metric_classes_vs_reference(oracle, name):
+    """reference-named metric classes (update_one) -> metrics.hip -> the reference's own numbers."""
+    from importlib import import_module
+    from helpers import metric_inputs
+    mm = import_module(pkg.__name__ + ".core.metrics.matching_metrics")
+    km = import_module(pkg.__name__ + ".core.metrics.keypoints_metrics")
+    c = METRICS.cases[name]
+    k0, k1, d0, d1, mk0, mk1 = [_t(a) for a in metric_inputs(c)]
+    Hm = torch.eye(3) if c["hom"] is None else torch.tensor(c["hom"], dtype=torch.float32).reshape(3, 3)
+    vals = {}
+    vals.update(mm.MatchingRatio("MR").update_one(mk0, mk1, k0, k1))
+    for t in (1, 3):
+        vals.update(mm.MeanMatchingAccuracy(f"MMA@{t}", threshold=t).update_one(mk0, mk1, Hm.to(DEV)))
+    vals.update(km.ValidDescriptorsDistance("VDD", [1, 3]).update_one(k0, k1, d0, d1, (260, 346), (260, 346), Hm.to(DEV)))
+    names = ["MR", "MMA@1", "MMA@3"] + [f"VDD_{p}@{t}" for t in (1, 3) for p in ("Repeatability", "ValidDistance", "Angle")]
+    got = np.array([vals[k] for k in names])
+    exp = METRICS[f"{name}.values"]
+    np.testing.assert_allclose(got[[0, 1, 2, 3, 6]], exp[[0, 1, 2, 3, 6]], atol=1e-7, rtol=1e-6)
+    np.testing.assert_allclose(got[[4, 7]], exp[[4, 7]], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(got[[5, 8]], exp[[5, 8]], atol=2e-3, rtol=1e-5)
+    orc = oracle.pair_metrics(*metric_inputs(c), (260, 346), (260, 346), c["hom"])
+    np.testing.assert_allclose(got, orc, atol=1e-6, rtol=1e-6)
+
+
+def test_batch_metrics_on_pipeline_output(oracle):
+    """metrics of a whole EIM batch on the device == oracle metrics of each pair's outputs."""
+    from importlib import import_module
+    nm = import_module(pkg.__name__ + ".core.metrics._native_metrics")
+    c = dict(E2E.cases["sp_mnn"])
+    model, _ = _build(c, E2E)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    ev, mask, img = _inputs(c)
+    evb, imb, mr = model.forward_batched(_t(ev), _t(img), _t(mask))
+    out = _np(nm.batch_metrics(evb, imb, mr))
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    for b in range(c["B"]):
+        exp = oracle.pair_metrics(_np(ef["sparse_positions"][b]), _np(imf["sparse_positions"][b]), _np(ef["sparse_descriptors"][b]),
+                                  _np(imf["sparse_descriptors"][b]), _np(m["matched_kpts0"][b]), _np(m["matched_kpts1"][b]), (260, 346), (260, 346))
+        np.testing.assert_allclose(out[b], exp, atol=1e-6, rtol=1e-6, equal_nan=True)

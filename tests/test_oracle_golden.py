@@ -284,3 +284,20 @@ def test_voxel_grid_and_mask(oracle, name):
     mask = oracle.events_mask(ev, (c["W"], c["H"]))
     exp = np.unpackbits(EVENTS[f"{name}.mask"])[:c["H"] * c["W"]].astype(bool).reshape(c["H"], c["W"])
     assert np.array_equal(mask, exp)
+
+
+# ------------------------------------------------------------------ evaluation metrics (next row 8f-1)
+METRICS = Golden("metrics")
+
+
+@pytest.mark.parametrize("name", list(METRICS.cases))
+def test_pair_metrics(oracle, name):
+    from helpers import metric_inputs
+    c = METRICS.cases[name]
+    k0, k1, d0, d1, mk0, mk1 = metric_inputs(c)
+    got = oracle.pair_metrics(k0, k1, d0, d1, mk0, mk1, (260, 346), (260, 346), c["hom"])
+    exp = METRICS[f"{name}.values"]
+    # MR, MMA, repeatability: counts -> exact up to fp32 division; distances 1e-5; angles 2e-3 deg
+    np.testing.assert_allclose(got[[0, 1, 2, 3, 6]], exp[[0, 1, 2, 3, 6]], atol=1e-7, rtol=1e-6)
+    np.testing.assert_allclose(got[[4, 7]], exp[[4, 7]], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(got[[5, 8]], exp[[5, 8]], atol=2e-3, rtol=1e-5)
