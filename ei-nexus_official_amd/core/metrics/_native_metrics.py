@@ -58,7 +58,8 @@ def single_pair(points1, points2, desc1, desc2, matched1, matched2, size0, size1
     """update_one-style entry: per-pair tensors of any length -> dict of python floats."""
     dev = points1.device
     k0, k1 = _pad3(points1.float())[None].contiguous(), _pad3(points2.float())[None].contiguous()
-    cap0, cap1 = max(k0.shape[1], 1), max(k1.shape[1], 1)
+    M = int(matched1.shape[0]) if matched1 is not None else 0
+    cap0, cap1 = max(k0.shape[1], M, 1), max(k1.shape[1], 1)  # matched rows share image 0's capacity in the ABI
     D = desc1.shape[-1] if desc1 is not None else 4
 
     def fit(t, cap, width):
@@ -69,7 +70,6 @@ def single_pair(points1, points2, desc1, desc2, matched1, matched2, size0, size1
     k0, k1 = fit(k0[0], cap0, 3), fit(k1[0], cap1, 3)
     d0, d1 = fit(desc1, cap0, D), fit(desc2, cap1, D)
     cols = matched1.shape[-1] if matched1 is not None and matched1.numel() else 3
-    M = int(matched1.shape[0]) if matched1 is not None else 0
     mk0, mk1 = fit(matched1, cap0, cols), fit(matched2, cap0, cols)
     cnt = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)  # noqa: E731
     hom = None if homography is None else homography.reshape(1, 3, 3)
