@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="also materialise the dense descriptor maps (reference-complete dict)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--with-metrics", action="store_true", help="also compute MR/MMA/VDD on the device each step (metrics.hip) and all-reduce their sums")
     ap.add_argument("--kernel-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
@@ -101,11 +102,20 @@ def main():
 
     acc = pkg.shard.MetricAccumulator(dev)  # pairs, keypoints(ev), keypoints(im), matches, ...
 
+    metric_sums = torch.zeros(9, dtype=torch.float64, device=dev)
+    metric_rows = []
+    batch_metrics = importlib.import_module(pkg.__name__ + ".core.metrics._native_metrics").batch_metrics
+
     def step(accumulate=False):
         img.copy_(img_src)  # SuperPoint scales its input in place (reference quirk), so refresh it
         ef, imf, m = model(ev, img, mask)
+        res = None
+        if args.with_metrics:  # harness metrics of the reference's test script, computed on the device
+            res = batch_metrics(ef._batched, imf._batched, model._last_match)
         if accumulate:
             acc.add_batch(ef, imf, m)
+            if res is not None:
+                metric_rows.append(res)  # [B,9] per step; summed after the timed region
         return ef, imf, m
 
     if args.kernel_only:
@@ -129,6 +139,10 @@ def main():
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     acc.all_reduce()  # the one collective of the job: metric accumulators (RCCL over xGMI when world > 1)
+    if args.with_metrics and metric_rows:
+        metric_sums = torch.nan_to_num(torch.cat(metric_rows)).sum(0)
+    if args.with_metrics and distributed:
+        dist.all_reduce(metric_sums, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     stats = acc.as_dict()
     pairs_total = max(stats["pairs"], 1.0)
@@ -205,7 +219,8 @@ def main():
                        "parallelism": f"dp{world} (pairs sharded, metric all-reduce only)", "log_assignment": bool(args.log_assignment),
                        "dense_outputs": bool(args.dense),
                        "mean_keypoints": [round(stats["keypoints0"] / pairs_total, 1), round(stats["keypoints1"] / pairs_total, 1)],
-                       "mean_matches": round(stats["matches"] / pairs_total, 1)},
+                       "mean_matches": round(stats["matches"] / pairs_total, 1),
+                       "harness_metrics_mean": ([round(v, 5) for v in (metric_sums / pairs_total).tolist()] if args.with_metrics else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

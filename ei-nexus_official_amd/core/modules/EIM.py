@@ -87,6 +87,7 @@ class EIM(nn.Module):
                     eng.redetect(bf, eng.grow_nms_iters())
             if mr is not None:
                 mr = self.matcher.match_batched(ev, im)
+        self._last_match = mr  # device-side MatchResult of this call (consumed by core.metrics batch_metrics)
         n, m = host[0].tolist(), host[1].tolist()
         events_feats = ev.materialize(n)
         image_feats = im.materialize(m)

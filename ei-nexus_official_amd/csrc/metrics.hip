@@ -19,8 +19,9 @@ struct MetArgs {
   float* p1;     // [B,cap1,2] keypoints1 (x,y)
   uint8_t* keep0;
   uint8_t* keep1;
-  int32_t* icnt;  // [B][2 + 2*4 + 4]: N1, N2, count1@t.., count2@t.., mma_good@t..
-  double* dsum;   // [B][2*4]: sumdist@t.., sumangle@t..
+  int32_t* icnt;  // [B][16]: N1, N2, (unused 2..9), mma_good@t.. at 10..
+  float* near0;   // [B,cap0,3] per kept keypoint of image 0: nearest distance, descriptor distance, angle
+  float* near1;   // [B,cap1,3] same for image 1
   double* out;
   einx_metric_params p;
 };
@@ -58,7 +59,7 @@ __device__ __forceinline__ void inverse3(const float* h, float* inv) {
   inv[8] = (h[0] * h[4] - h[1] * h[3]) / det;
 }
 
-constexpr int ICNT = 16, DSUM = 8;
+constexpr int ICNT = 16;
 
 __global__ void metric_prepare_kernel(const MetArgs a) {
   const int b = blockIdx.y;
@@ -103,7 +104,10 @@ __global__ __launch_bounds__(256) void metric_nearest_kernel(const MetArgs a) {
   const int cs = SIDE == 0 ? a.p.cap0 : a.p.cap1, co = SIDE == 0 ? a.p.cap1 : a.p.cap0;
   const uint8_t* keep_s = (SIDE == 0 ? a.keep0 : a.keep1) + (size_t)b * cs;
   const uint8_t* keep_o = (SIDE == 0 ? a.keep1 : a.keep0) + (size_t)b * co;
-  if (!keep_s[i]) return;
+  if (!keep_s[i]) {
+    if (lane == 0) ((SIDE == 0 ? a.near0 : a.near1) + ((size_t)b * cs + i) * 3)[0] = einx_u2f(0x7f800000u);
+    return;
+  }
   const float* ps = (SIDE == 0 ? a.tw0 : a.p1) + ((size_t)b * cs + i) * 2;
   const float* po = (SIDE == 0 ? a.p1 : a.tw0) + (size_t)b * co * 2;
   const float sx = ps[0], sy = ps[1];
@@ -129,7 +133,11 @@ __global__ __launch_bounds__(256) void metric_nearest_kernel(const MetArgs a) {
       bj = oj;
     }
   }
-  if (bj == 0x7fffffff) return;
+  float* nout = (SIDE == 0 ? a.near0 : a.near1) + ((size_t)b * cs + i) * 3;
+  if (bj == 0x7fffffff) {
+    if (lane == 0) nout[0] = einx_u2f(0x7f800000u);
+    return;
+  }
   // descriptor distance and angle of the pair (keypoints_metrics.py:233-247)
   const int D = a.p.D;
   const float* da = (SIDE == 0 ? a.d0 : a.d1) + ((size_t)b * cs + i) * D;
@@ -154,14 +162,9 @@ __global__ __launch_bounds__(256) void metric_nearest_kernel(const MetArgs a) {
     n2 += __shfl_xor(n2, off, 64);
   }
   if (lane == 0) {
-    const float dist = sqrtf(sq);
-    const float ang = einx_acosf(dot / (sqrtf(n1) * sqrtf(n2))) * 57.29577951308232f;
-    for (int t = 0; t < a.p.n_vdd; ++t)
-      if (best <= a.p.vdd_thr[t]) {
-        atomicAdd(&a.icnt[b * ICNT + 2 + SIDE * 4 + t], 1);
-        atomicAdd(&a.dsum[b * DSUM + t], (double)dist);
-        atomicAdd(&a.dsum[b * DSUM + 4 + t], (double)ang);
-      }
+    nout[0] = best;
+    nout[1] = sqrtf(sq);
+    nout[2] = einx_acosf(dot / (sqrtf(n1) * sqrtf(n2))) * 57.29577951308232f;
   }
 }
 
@@ -183,28 +186,66 @@ __global__ void metric_mma_kernel(const MetArgs a) {
     if (d <= a.p.mma_thr[k]) atomicAdd(&a.icnt[b * ICNT + 10 + k], 1);
 }
 
-__global__ void metric_finalize_kernel(const MetArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.p.B) return;
+// one workgroup per pair: fixed-order (deterministic) reduction of the per-keypoint records
+__global__ __launch_bounds__(256) void metric_finalize_kernel(const MetArgs a) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
   const int n = min(a.n[b], a.p.cap0), m = min(a.m[b], a.p.cap1), M = min(a.nmatch[b], a.p.cap0);
   const int nout = 1 + a.p.n_mma + 3 * a.p.n_vdd;
   double* o = a.out + (size_t)b * nout;
   const int32_t* ic = a.icnt + b * ICNT;
-  const double* ds = a.dsum + b * DSUM;
-  o[0] = (double)M / ((double)(n < m ? n : m) + 1e-8);  // MatchingRatio
-  for (int k = 0; k < a.p.n_mma; ++k) o[1 + k] = M > 0 ? (double)((float)ic[10 + k] / (float)M) : 0.0;  // mask.float().mean()
+  auto block_sum = [&](double v) {
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (tid < off) sh[tid] += sh[tid + off];
+      __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+  };
+  if (tid == 0) {
+    o[0] = (double)M / ((double)(n < m ? n : m) + 1e-8);  // MatchingRatio
+    for (int k = 0; k < a.p.n_mma; ++k) o[1 + k] = M > 0 ? (double)((float)ic[10 + k] / (float)M) : 0.0;  // mask.float().mean()
+  }
   const int N1 = ic[0], N2 = ic[1];
   for (int t = 0; t < a.p.n_vdd; ++t) {
-    double rep = 0.0, vd = 0.0, ang = 0.0;
-    if (N1 != 0 && N2 != 0) {
-      const int c = ic[2 + t] + ic[6 + t];
-      rep = (double)((float)c / (float)(N1 + N2));
-      vd = ds[t] / (double)c;       // 0/0 -> NaN exactly like the reference when nothing is within t
-      ang = ds[4 + t] / (double)c;
+    double c = 0.0, sd = 0.0, sa = 0.0;
+    const float thr = a.p.vdd_thr[t];
+    if (a.p.n_vdd > 0) {
+      for (int i = tid; i < n; i += 256) {
+        const float* r = a.near0 + ((size_t)b * a.p.cap0 + i) * 3;
+        if (r[0] <= thr) {
+          c += 1.0;
+          sd += (double)r[1];
+          sa += (double)r[2];
+        }
+      }
+      for (int j = tid; j < m; j += 256) {
+        const float* r = a.near1 + ((size_t)b * a.p.cap1 + j) * 3;
+        if (r[0] <= thr) {
+          c += 1.0;
+          sd += (double)r[1];
+          sa += (double)r[2];
+        }
+      }
     }
-    o[1 + a.p.n_mma + 3 * t + 0] = rep;
-    o[1 + a.p.n_mma + 3 * t + 1] = vd;
-    o[1 + a.p.n_mma + 3 * t + 2] = ang;
+    c = block_sum(c);
+    sd = block_sum(sd);
+    sa = block_sum(sa);
+    if (tid == 0) {
+      double rep = 0.0, vd = 0.0, ang = 0.0;
+      if (N1 != 0 && N2 != 0) {
+        rep = (double)((float)c / (float)(N1 + N2));
+        vd = sd / c;  // 0/0 -> NaN exactly like the reference when nothing is within t
+        ang = sa / c;
+      }
+      o[1 + a.p.n_mma + 3 * t + 0] = rep;
+      o[1 + a.p.n_mma + 3 * t + 1] = vd;
+      o[1 + a.p.n_mma + 3 * t + 2] = ang;
+    }
   }
 }
 
@@ -215,7 +256,8 @@ size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 EINX_EXPORT size_t einx_metrics_ws_bytes(const einx_metric_params* p) {
   if (!p || p->B <= 0) return 0;
   const size_t B = p->B;
-  return al(B * p->cap0 * 8) + al(B * p->cap1 * 8) + al(B * p->cap0) + al(B * p->cap1) + al(B * ICNT * 4) + al(B * DSUM * 8) + 256;
+  return al(B * p->cap0 * 8) + al(B * p->cap1 * 8) + al(B * p->cap0) + al(B * p->cap1) + al(B * ICNT * 4) + al(B * p->cap0 * 12) +
+         al(B * p->cap1 * 12) + 256;
 }
 
 EINX_EXPORT int einx_pair_metrics(const einx_metric_params* p, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
@@ -251,8 +293,10 @@ EINX_EXPORT int einx_pair_metrics(const einx_metric_params* p, const float* kpts
   q += al(B * p->cap1);
   a.icnt = (int32_t*)q;
   q += al(B * ICNT * 4);
-  a.dsum = (double*)q;
-  if (hipMemsetAsync(a.icnt, 0, al(B * ICNT * 4) + al(B * DSUM * 8), s) != hipSuccess) {
+  a.near0 = (float*)q;
+  q += al(B * p->cap0 * 12);
+  a.near1 = (float*)q;
+  if (hipMemsetAsync(a.icnt, 0, al(B * ICNT * 4), s) != hipSuccess) {
     einx_set_error("einx_pair_metrics: memset failed");
     return EINX_ERR_LAUNCH;
   }
@@ -269,7 +313,7 @@ EINX_EXPORT int einx_pair_metrics(const einx_metric_params* p, const float* kpts
     hipLaunchKernelGGL(metric_mma_kernel, dim3((unsigned)einx_cdiv(p->cap0, 256), (unsigned)B), dim3(256), 0, s, a);
     EINX_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(metric_finalize_kernel, dim3((unsigned)einx_cdiv((int)B, 64)), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(metric_finalize_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

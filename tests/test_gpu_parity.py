@@ -531,3 +531,54 @@ def test_batch_metrics_on_pipeline_output(oracle):
         exp = oracle.pair_metrics(_np(ef["sparse_positions"][b]), _np(imf["sparse_positions"][b]), _np(ef["sparse_descriptors"][b]),
                                   _np(imf["sparse_descriptors"][b]), _np(m["matched_kpts0"][b]), _np(m["matched_kpts1"][b]), (260, 346), (260, 346))
         np.testing.assert_allclose(out[b], exp, atol=1e-6, rtol=1e-6, equal_nan=True)
+
+
+# ------------------------------------------------------------------ other front doors and edge cases
+def test_image_image_matcher_and_build_model(oracle):
+    """ImageImageMatcher (core/modules/ImageImageMatcher.py) through build_model; both sides use the
+    image extractor; first image takes a mask."""
+    c = E2E.cases["sp_mnn"]
+    cfg = pkg.configs.to_attr(c["cfg"])
+    cfg.name = "ImageImageMatcher"
+    model = pkg.build_model(cfg, DEV, None)
+    sd = {k: v for k, v in state_dict_for(c, E2E).items() if not k.startswith("event_extractor")}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    model.eval()
+    for ext in (model.image_extractor.extractor,):
+        ext.dense_outputs = False
+    img0 = synth.synth_image(31, 2, 100, 124)
+    img1 = synth.synth_image(32, 2, 100, 124)
+    mask0 = synth.uniform01(33, (2, 1, 100, 124)) < np.float32(0.7)
+    f0, f1, m = model(_t(img0), _t(img1), mask=_t(mask0))
+    sub = sub_dict(sd, "image_extractor.extractor.")
+    o0 = oracle.extractor_forward("superpointv1", sub, img0.copy(), mask0, top_k=1024)
+    o1 = oracle.extractor_forward("superpointv1", sub, img1.copy(), None, top_k=1024)
+    _assert_feats_equal_oracle(f0, o0)
+    _assert_feats_equal_oracle(f1, o1)
+    for b in range(2):
+        exp = oracle.mnn(o0["sparse_descriptors"][b], o1["sparse_descriptors"][b], want_la=False)
+        assert np.array_equal(_np(m["matches0"][b])[0], exp["matches0"])
+
+
+def test_xy_ordering_threshold_and_single_image(oracle):
+    """ordering='xy', an active detection_threshold (capacity = whole map) and B=1 odd-sized input."""
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.ordering = "xy"
+        sec.detection_threshold = 0.02
+        sec.detection_top_k = 200
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sdn = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=21)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    ev, mask = synth.synth_events(41, 1, 5, 75, 93)
+    img = synth.synth_image(41, 1, 75, 93)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oe = oracle.extractor_forward("vgg", sub_dict(sdn, "event_extractor.extractor."), ev.copy(), mask, top_k=200, det_thr=0.02, ordering="xy")
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sdn, "image_extractor.extractor."), img.copy(), None, top_k=200, det_thr=0.02,
+                                  ordering="xy")
+    _assert_feats_equal_oracle(ef, oe)
+    _assert_feats_equal_oracle(imf, oi)
+    p = _np(ef["sparse_positions"][0])
+    assert p[:, 0].max() > 75  # first column is x for 'xy' ordering (W=93 > H=75)
