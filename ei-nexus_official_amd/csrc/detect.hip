@@ -360,7 +360,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
   __shared__ float cval[SEL_LCAP];
   __shared__ int cidx[SEL_LCAP];
   __shared__ int sh_bad;
-  __shared__ unsigned sh_pre, sh_rk, sh_mink;
+  __shared__ unsigned sh_pre, sh_rk;
   const int b = blockIdx.x;
   const int N = a.Hp * a.Wp;
   const float* m = a.map + (size_t)b * N;

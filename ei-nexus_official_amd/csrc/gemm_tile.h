@@ -77,17 +77,25 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
     commit();
     __syncthreads();
     if (k0 + BK < K) issue(k0 + BK);
+    // software-pipelined fragment reads: step kk+1's operands are requested before step kk's MFMAs
+    float av[2][2], bv[2][2];
+    auto load_frag = [&](int kk, int buf) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
+    };
+    load_frag(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float av[2], bv[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) av[mt] = As[aoff + mt * 32 * PITCH + kk * 2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bv[nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
+      if (kk + 1 < BK / 2) load_frag(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], f.acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt)
+          f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][mt], bv[kk & 1][nt], f.acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();  // LDS reusable by the caller's epilogue

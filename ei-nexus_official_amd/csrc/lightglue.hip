@@ -200,11 +200,13 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = einx_expf(m_run - m_new);
+      // v_exp_f32 (2^x, ~1 ulp): LightGlue is compared at 1e-4, so the 20-instruction exact-order
+      // einx_expf is not needed here; exp(-inf) = 0 handles masked keys and the first block
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896341f);
       float psum = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = einx_expf(s[r] - m_new);
+        s[r] = __builtin_amdgcn_exp2f((s[r] - m_new) * 1.44269504088896341f);
         psum += s[r];
       }
       l_run = l_run * alpha + psum;
