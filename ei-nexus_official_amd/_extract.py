@@ -74,8 +74,13 @@ class BatchedFeats:
             out["dense_positions"] = [torch.stack([first, second, sc[b, 0]], -1).reshape(-1, 3) for b in range(self.B)]
         cap = self.det.cap
         ns = [min(int(c), cap) for c in counts_host]
-        out["sparse_descriptors"] = [self.sparse_desc[b, :ns[b]] for b in range(self.B)]
-        out["sparse_positions"] = [self.det.positions[b, :ns[b]] for b in range(self.B)]
+        if all(v == cap for v in ns):
+            # common case (every image filled its top-k quota): one unbind instead of B slicing calls
+            out["sparse_descriptors"] = list(self.sparse_desc.unbind(0))
+            out["sparse_positions"] = list(self.det.positions.unbind(0))
+        else:
+            out["sparse_descriptors"] = [self.sparse_desc[b, :ns[b]] for b in range(self.B)]
+            out["sparse_positions"] = [self.det.positions[b, :ns[b]] for b in range(self.B)]
         out._batched = self
         return out
 

@@ -55,6 +55,18 @@ def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None):
         for k in extra:
             out[k] = []
     B = len(n_host)
+    cap0, cap1 = r.matches0.shape[1], r.matches1.shape[1]
+    if all(v == cap0 for v in n_host) and all(v == cap1 for v in m_host) and all(v > 0 for v in nmatch_host) and cap0 > 0 and cap1 > 0:
+        # common case: every image filled its keypoint quota -> whole-batch views, per-pair work only
+        # where the length really differs (matched keypoints)
+        out["matches0"] = list(r.matches0[:, None, :].unbind(0))
+        out["matches1"] = list(r.matches1[:, None, :].unbind(0))
+        out["matching_scores0"] = list(r.scores0[:, None, :].unbind(0))
+        out["matching_scores1"] = list(r.scores1[:, None, :].unbind(0))
+        out["matched_kpts0"] = [r.mk0[b, :nmatch_host[b], :cols] for b in range(B)]
+        out["matched_kpts1"] = [r.mk1[b, :nmatch_host[b], :cols] for b in range(B)]
+        out["log_assignment"] = [None] * B if r.la is None else list(r.la[:, None].unbind(0))
+        return out
     for b in range(B):
         n, m = n_host[b], m_host[b]
         if n == 0 or m == 0:
