@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--with-metrics", action="store_true", help="also compute MR/MMA/VDD on the device each step (metrics.hip) and all-reduce their sums")
+    ap.add_argument("--layer-table", action="store_true", help="tuning aid: time every conv layer of both extractors standalone and exit")
     ap.add_argument("--kernel-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
@@ -118,6 +119,38 @@ def main():
                 metric_rows.append(res)  # [B,9] per step; summed after the timed region
         return ef, imf, m
 
+    if args.layer_table:
+        rows = []
+        for side, ext, x0 in (("event", model.event_extractor.extractor, ev), ("image", model.image_extractor.extractor, img_src)):
+            eng = ext.engine()
+            pads = pkg.native.padder_pads(260, 346, ext.cell_size)
+            Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
+            chains = [("bb", eng.backbone), ("det", eng.det_head), ("desc", eng.desc_head)]
+            feats = None
+            for cname, layers in chains:
+                t_in = x0 if cname == "bb" else feats
+                for li, layer in enumerate(layers):
+                    fold = (pads[2], pads[0], Hp, Wp) if (cname == "bb" and li == 0) else None
+                    out = layer(t_in, fold=fold)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        layer(t_in, fold=fold)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    dur = e0.elapsed_time(e1) / 5 * 1e-3
+                    H_, W_ = (Hp, Wp) if fold else t_in.shape[-2:]
+                    fl = conv_layer_flops(layer.cin, layer.cout, layer.ks, H_, W_) * B
+                    rows.append((f"{side}.{cname}{li}", layer.cin, layer.cout, layer.ks, int(H_), int(W_), bool(layer.pool), round(dur * 1e6, 1),
+                                 round(fl / dur / 1e12, 1)))
+                    t_in = out
+                if cname == "bb":
+                    feats = t_in
+        for r in rows:
+            print("%-14s cin=%3d cout=%3d ks=%d %3dx%3d pool=%d  %8.1f us  %6.1f TFLOP/s" % r)
+        print("total conv us", round(sum(r[7] for r in rows), 1))
+        return
     if args.kernel_only:
         args.steps, args.warmup, args.no_cpu_baseline = 0, 0, True
     for _ in range(args.warmup):

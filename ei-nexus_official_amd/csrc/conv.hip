@@ -209,7 +209,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
     // 36 K-steps (CK/2 channel pairs x taps), software pipelined: the LDS fragments of step t+1
     // are requested before the MFMAs of step t so that no MFMA group waits on a fresh ds_read.
     constexpr int STEPS = (CK / 2) * TAPS;
-    float av[2][kMT], bv[2][kNT];
+    constexpr int PF = 2;  // fragment prefetch distance in K-steps (LDS latency under 8-16 waves/CU > 1 step)
+    float av[PF + 1][kMT], bv[PF + 1][kNT];
     auto load_frag = [&](int st, int buf) {
       const int kp = st / TAPS, tap = st % TAPS;
       const int ky = tap / KS, kx = tap % KS;
@@ -218,16 +219,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
 #pragma unroll
       for (int nt = 0; nt < kNT; ++nt) bv[buf][nt] = in_tile[bBase[nt] + kp * 2 * PLANE + ky * PW + kx];
     };
-    load_frag(0, 0);
+#pragma unroll
+    for (int st = 0; st < PF && st < STEPS; ++st) load_frag(st, st % (PF + 1));
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-      if (st + 1 < STEPS) load_frag(st + 1, (st + 1) & 1);
+      if (st + PF < STEPS) load_frag(st + PF, (st + PF) % (PF + 1));
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < kNT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][mt], bv[st & 1][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % (PF + 1)][mt], bv[st % (PF + 1)][nt], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -429,9 +431,11 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   }
   a.tilesX = einx_cdiv(W, cfgs[best].tw);
   a.tilesY = einx_cdiv(H, cfgs[best].th);
-  // Wave layouts: 8 waves (2 channel groups x 4 pixel groups, one 32x64 accumulator block each)
-  // for the 256-slot tiles, 6 waves (2 x 3) for the 192-slot tiles: two waves per SIMD from one
-  // workgroup hide each other's LDS/epilogue latency at half the accumulator registers per wave.
+  // Wave layouts (measured per layer, bench.py --layer-table): 8 waves (2 channel groups x 4 pixel
+  // groups, one 32x64 accumulator block each) for the 256-slot tiles -- two waves per SIMD from one
+  // workgroup hide each other's LDS/epilogue latency at half the accumulator registers per wave;
+  // 4 waves of 1x3 tiles for the 192-slot tiles (6 waves load the 4 SIMDs unevenly: -25 %) and
+  // 4 waves for the 1x1 heads.
   if (d->pool) {
     switch (best) {
       case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s); break;
@@ -442,8 +446,8 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     switch (best) {
       case 0:
         // thin first layers (1 / 5 input channels): stage only the channel pairs that exist
-        if (d->cin <= 2) launch<3, 8, 32, 1, 4, 2, 2, 2, false>(a, B, s);
-        else if (d->cin <= 6) launch<3, 8, 32, 1, 4, 2, 2, 6, false>(a, B, s);
+        if (d->cin <= 2) launch<3, 8, 32, 2, 4, 1, 2, 2, false>(a, B, s);
+        else if (d->cin <= 6) launch<3, 8, 32, 2, 4, 1, 2, 6, false>(a, B, s);
         else launch<3, 8, 32, 2, 4, 1, 2, 8, false>(a, B, s);
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
