@@ -418,7 +418,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   // candidate tile shapes (all 4 waves): A (8,32) 1x4 waves of 2x2 tiles; B (12,16) and C (22,8)
   // 2x2 waves of 1x3 tiles (192 pixel slots); D (11,22) like A.  Pooled layers need even tile dims
   // so that every 2x2 window lives inside one tile.
-  static const TileCfg cfgs[4] = {{8, 32, 256}, {12, 16, 192}, {22, 8, 192}, {11, 22, 256}};
+  static const TileCfg cfgs[5] = {{8, 32, 256}, {12, 16, 192}, {22, 8, 192}, {11, 22, 256}, {11, 11, 128}};
   int best = 0;
   double bw = 1e30;
   for (int i = 0; i < 4; ++i) {
@@ -428,6 +428,12 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
       bw = wst;
       best = i;
     }
+  }
+  // small maps: when the launch would not even give every CU two workgroups, halve the tile
+  // (11x11, 128 pixel slots) so the 256 CUs are loaded evenly (33x44 map, 128 channels: 384 -> 768)
+  if (!d->pool) {
+    const long blocks = (long)einx_cdiv(H, cfgs[best].th) * einx_cdiv(W, cfgs[best].tw) * B * (a.CoutPad / kCoutTile);
+    if (blocks < 640 && tile_waste(H, W, cfgs[4]) <= bw * 1.05 + 1e-9) best = 4;
   }
   a.tilesX = einx_cdiv(W, cfgs[best].tw);
   a.tilesY = einx_cdiv(H, cfgs[best].th);
@@ -452,7 +458,8 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
       case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;
-      default: launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s); break;
+      case 3: launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s); break;
+      default: launch<3, 11, 11, 2, 2, 1, 2, 8, false>(a, B, s); break;
     }
   }
   EINX_CHECK_LAUNCH();
