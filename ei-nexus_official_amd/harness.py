@@ -1,0 +1,53 @@
+"""Evaluation harness with the call pattern of the reference's test_events-image_same-time.py:130-283
+(SURVEY.md section 8a row H), entirely on the device:
+
+    raw events --(events.hip)--> voxel grid + events mask
+               --(EIM: conv/detect/desc/mnn|lightglue kernels)--> keypoints, descriptors, matches
+               --(metrics.hip)--> MR, MMA@1/3, VDD@1/3 per pair  --> means (all-reduced across ranks)
+
+HomographyEstimation / RelativePoseEstimation (cv2 RANSAC on the CPU in the reference) are out of scope.
+"""
+import torch
+
+from .core.metrics._native_metrics import batch_metrics, metric_names
+from .datasets.representations import events_mask_batch, events_to_voxel_grid_batch
+
+
+class SameTimeEvaluator:
+    def __init__(self, model, bins, resolution=(346, 260), mma_thr=(1, 3), vdd_thr=(1, 3)):
+        """model: EIM (eval mode); bins: voxel-grid channels; resolution: (W, H) like MVSECDataset.RESOLUTION."""
+        self.model = model
+        self.bins = int(bins)
+        self.resolution = tuple(int(v) for v in resolution)
+        self.mma_thr, self.vdd_thr = tuple(mma_thr), tuple(vdd_thr)
+        self.names = metric_names(self.mma_thr, self.vdd_thr)
+        self.sums = None
+        self.counts = None
+        self.pairs = 0
+
+    @torch.no_grad()
+    def step(self, events_list, images, homography=None):
+        """events_list: B dicts {"x","y","t","p"} of numpy arrays; images: [B,1,H,W] float (0..255) on the device
+        (scaled in place by SuperPoint exactly like the reference).  Returns the per-pair metric rows [B,K] (device)."""
+        W, H = self.resolution
+        dev = images.device
+        events_rep = events_to_voxel_grid_batch(events_list, (self.bins, H, W), normalize=True, device=dev)
+        events_mask = events_mask_batch(events_list, (W, H), device=dev)
+        self.last_inputs = (events_rep, events_mask)  # what the extractors saw (fp32 atomics: run-to-run last-bit noise)
+        ef, imf, matches = self.model(events_rep, images, events_mask)
+        rows = batch_metrics(ef._batched, imf._batched, self.model._last_match, homography, self.mma_thr, self.vdd_thr)
+        ok = ~torch.isnan(rows)
+        z = torch.nan_to_num(rows)
+        self.sums = z.sum(0) if self.sums is None else self.sums + z.sum(0)
+        self.counts = ok.sum(0).double() if self.counts is None else self.counts + ok.sum(0).double()
+        self.pairs += rows.shape[0]
+        return rows, (ef, imf, matches)
+
+    def result(self):
+        """Mean of every metric over the pairs seen so far; sums are all-reduced when a process group is up."""
+        s, c = self.sums.clone(), self.counts.clone()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(s)
+            torch.distributed.all_reduce(c)
+        mean = (s / c.clamp_min(1)).tolist()
+        return dict(zip(self.names, mean))

@@ -582,3 +582,43 @@ def test_xy_ordering_threshold_and_single_image(oracle):
     _assert_feats_equal_oracle(imf, oi)
     p = _np(ef["sparse_positions"][0])
     assert p[:, 0].max() > 75  # first column is x for 'xy' ordering (W=93 > H=75)
+
+
+def test_same_time_harness_end_to_end(oracle):
+    """row H: raw events -> voxel grid + mask -> EIM -> metrics, all on the device, against the
+    oracle chain.  The voxel grid uses fp32 atomics (summation order), so the comparison is done on
+    the harness' own voxel grid fed to the oracle extractors (bit-exact from there on)."""
+    from helpers import synth_raw_events
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 128
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sdn = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=31)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    H, W, B = 100, 124, 2
+    evs = [synth_raw_events(dict(seed=300 + b, n=6000, H=H, W=W, bins=5, frac=False, pneg=False)) for b in range(B)]
+    img = synth.synth_image(77, B, H, W)
+    evalr = pkg.SameTimeEvaluator(model, bins=5, resolution=(W, H))
+    rows, (ef, imf, m) = evalr.step(evs, _t(img))
+    rows = _np(rows)
+    # oracle chain from the same voxel grid / mask
+    grid = _np(evalr.last_inputs[0])
+    mask = np.stack([oracle.events_mask(e, (W, H)) for e in evs])[:, None]
+    assert np.array_equal(_np(evalr.last_inputs[1]), mask)
+    for b in range(B):
+        np.testing.assert_allclose(grid[b], oracle.voxel_grid(evs[b], (5, H, W)), atol=2e-5, rtol=1e-5)
+    oe = oracle.extractor_forward("vgg", sub_dict(sdn, "event_extractor.extractor."), grid.copy(), mask, top_k=128)
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sdn, "image_extractor.extractor."), img.copy(), None, top_k=128)
+    _assert_feats_equal_oracle(ef, oe)
+    _assert_feats_equal_oracle(imf, oi)
+    for b in range(B):
+        r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
+        mk0, mk1 = oracle.matched_kpts(oe["sparse_positions"][b], oi["sparse_positions"][b], r["matches0"], 3)
+        exp = oracle.pair_metrics(oe["sparse_positions"][b], oi["sparse_positions"][b], oe["sparse_descriptors"][b], oi["sparse_descriptors"][b],
+                                  mk0, mk1, (H, W), (H, W))
+        np.testing.assert_allclose(rows[b], exp, atol=1e-6, rtol=1e-6, equal_nan=True)
+    res = evalr.result()
+    assert set(res) == {"MR", "MMA@1", "MMA@3", "VDD_Repeatability@1", "VDD_ValidDistance@1", "VDD_Angle@1", "VDD_Repeatability@3",
+                        "VDD_ValidDistance@3", "VDD_Angle@3"}
