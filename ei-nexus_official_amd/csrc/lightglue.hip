@@ -135,8 +135,9 @@ struct AttnArgs {
   float scale;
 };
 
-constexpr int AKB = 64;  // keys staged per round
-constexpr int KPITCH = DH + 1;
+constexpr int AKB = 64;   // keys staged per round
+constexpr int KPITCH = 68;  // K rows padded to 68 floats: 16-byte aligned for ds_read_b128, and the 32 rows a
+                            // half-wave reads start on 16 distinct 4-bank groups (conflict-free)
 
 __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[AKB * KPITCH];
@@ -148,10 +149,18 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int q = q0 + wave * 32 + l31;
   const bool qv = q < nq;
-  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * D + h * DH;
+  // MFMA K-step t pairs head dims (t, t+32): lane half h supplies dim t + 32h, so a lane's K fragments
+  // for four consecutive steps are one 16-byte LDS read
+  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * D + h * DH + 32 * half;
   float qreg[32];
 #pragma unroll
-  for (int t = 0; t < 32; ++t) qreg[t] = Qrow[2 * t + half];
+  for (int t = 0; t < 32; t += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Qrow + t);
+    qreg[t] = v[0];
+    qreg[t + 1] = v[1];
+    qreg[t + 2] = v[2];
+    qreg[t + 3] = v[3];
+  }
   const float* Kb = a.K + (size_t)b * a.capk * D + h * DH;
   const float* Vb = a.V + (size_t)b * a.capk * D + h * DH;
   f32x16 o[2];
@@ -160,25 +169,36 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[mt][r] = 0.0f;
   const float NEG = -einx_u2f(0x7f800000u);
+  const float sl2 = a.scale * 1.44269504088896341f;  // softmax in base 2: exp(x) = 2^(x log2 e)
   float m_run = NEG, l_run = 0.0f;
 
-  for (int kb0 = 0; kb0 < nk; kb0 += AKB) {
-    __syncthreads();
-    // stage 64 keys x 64 dims of K and V: 1024 float4 each, 4 per thread
+  // K/V block staging through registers: block kb0+64 is in flight while block kb0 is consumed
+  f32x4 rk[4], rv[4];
+  auto issue = [&](int kb0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int fidx = tid + i * 256;
       const int row = fidx >> 4, c4 = fidx & 15;
-      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (kb0 + row < nk) {
-        kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)(kb0 + row) * D + c4 * 4);
-        vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)(kb0 + row) * D + c4 * 4);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Ks[row * KPITCH + c4 * 4 + t] = kv[t];
-      *reinterpret_cast<f32x4*>(Vs + row * DH + c4 * 4) = vv;
+      const int key = min(kb0 + row, nk - 1);  // clamped: rows past nk are masked after the QK product
+      rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * D + c4 * 4);
+      rv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * D + c4 * 4);
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int fidx = tid + i * 256;
+      const int row = fidx >> 4, c4 = fidx & 15;
+      *reinterpret_cast<f32x4*>(Ks + row * KPITCH + c4 * 4) = rk[i];
+      *reinterpret_cast<f32x4*>(Vs + row * DH + c4 * 4) = rv[i];
+    }
+  };
+  issue(0);
+  for (int kb0 = 0; kb0 < nk; kb0 += AKB) {
     __syncthreads();
+    commit();
+    __syncthreads();
+    if (kb0 + AKB < nk) issue(kb0 + AKB);
 #pragma unroll
     for (int sub = 0; sub < AKB / 32; ++sub) {
       const int kbase = kb0 + sub * 32;
@@ -186,27 +206,33 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+      const float* krow = Ks + (sub * 32 + l31) * KPITCH + 32 * half;
+      f32x4 kf[2];
+      kf[0] = *reinterpret_cast<const f32x4*>(krow);
 #pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        const float av = Ks[(sub * 32 + l31) * KPITCH + 2 * t + half];
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qreg[t], s, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        if (u + 1 < 8) kf[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(krow + 4 * (u + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u & 1][t], qreg[4 * u + t], s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       float mx = NEG;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kbase + crow(r, half);
-        s[r] = key < nk ? s[r] * a.scale : NEG;
+        s[r] = key < nk ? s[r] * sl2 : NEG;
         mx = fmaxf(mx, s[r]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      // v_exp_f32 (2^x, ~1 ulp): LightGlue is compared at 1e-4, so the 20-instruction exact-order
-      // einx_expf is not needed here; exp(-inf) = 0 handles masked keys and the first block
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896341f);
+      // v_exp_f32 (2^x, ~1 ulp): LightGlue is compared at 1e-4, so the exact-order einx_expf is not
+      // needed here; 2^(-inf) = 0 handles masked keys and the first block
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f((s[r] - m_new) * 1.44269504088896341f);
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
         psum += s[r];
       }
       l_run = l_run * alpha + psum;
@@ -215,14 +241,20 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+      const float* vbase = Vs + (size_t)(sub * 32 + 4 * half) * DH + l31;
+      float vf[2][2];
+      vf[0][0] = vbase[crow(0, 0) * DH];
+      vf[0][1] = vbase[crow(0, 0) * DH + 32];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int krow = sub * 32 + crow(r, half);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const float av = Vs[krow * DH + mt * 32 + l31];
-          o[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[r], o[mt], 0, 0, 0);
+        if (r + 1 < 16) {
+          vf[(r + 1) & 1][0] = vbase[crow(r + 1, 0) * DH];
+          vf[(r + 1) & 1][1] = vbase[crow(r + 1, 0) * DH + 32];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r & 1][0], s[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r & 1][1], s[r], o[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
