@@ -262,3 +262,13 @@ def lightglue(weights, pb0, pb1, want_la=True, want_ref=False):
                            _ptr(r.matches1), _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _ptr(r.ref0), _ptr(r.ref1), _stream(pb0.desc)),
           "einx_lightglue")
     return r
+
+
+def linear(x, w, bias, out=None, accumulate=False):
+    """y = x @ w.T + bias on the fp32 matrix cores (einx_linear); accumulate: y += ..."""
+    _dev_check(x, w, bias, out)
+    M, K = x.shape
+    Nn = w.shape[0]
+    y = out if out is not None else torch.empty((M, Nn), dtype=F32, device=x.device)
+    check(lib().einx_linear(_ptr(x), M, K, _ptr(w), _ptr(bias), Nn, _ptr(y), int(accumulate), _stream(x)), "einx_linear")
+    return y

@@ -111,6 +111,7 @@ class LightGlue(nn.Module):
         self.log_assignment = nn.ModuleList([MatchAssignment(d) for _ in range(n)])
         self.token_confidence = nn.ModuleList([TokenConfidence(d) for _ in range(n - 1)])
         self.want_log_assignment = True
+        self.fold_message_projection = True  # inference-time weight folding (see _pack); False = layer by layer as written
         self._packed = None
 
     def _apply(self, fn, *a, **k):
@@ -138,15 +139,36 @@ class LightGlue(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        d = c.descriptor_dim
+
+        def fold(ffn0, proj):
+            """ffn0(cat[x, proj(ctx)]) == cat[x, ctx] @ [W0a | W0b Wp]^T + (b0 + W0b bp): fold the message
+            projection into the FFN's first Linear once, at load time (saves one GEMM per block)."""
+            W0, b0 = ffn0.weight.detach(), ffn0.bias.detach()
+            W0b = W0[:, d:].contiguous()
+            Wf = W0.clone()
+            zero = torch.zeros(d, dtype=torch.float32, device=W0.device)
+            Wf[:, d:] = N.linear(W0b, proj.weight.detach().t().contiguous(), zero)  # W0b @ Wp
+            bf = b0.clone().reshape(-1, 1).contiguous()
+            N.linear(W0b, proj.bias.detach().reshape(1, -1).contiguous(), zero[:1], out=bf, accumulate=True)  # b0 + W0b @ bp
+            return Wf.contiguous(), bf.reshape(-1).contiguous()
+
         layers = (_lib.LgLayer * c.n_layers)()
         for i, tl in enumerate(self.transformers):
             s, x, L = tl.self_attn, tl.cross_attn, layers[i]
-            L.Wqkv, L.bqkv, L.Wo, L.bo = p(s.Wqkv.weight), p(s.Wqkv.bias), p(s.out_proj.weight), p(s.out_proj.bias)
-            L.sf0_w, L.sf0_b, L.sln_g, L.sln_b = p(s.ffn[0].weight), p(s.ffn[0].bias), p(s.ffn[1].weight), p(s.ffn[1].bias)
-            L.sf3_w, L.sf3_b = p(s.ffn[3].weight), p(s.ffn[3].bias)
+            L.Wqkv, L.bqkv = p(s.Wqkv.weight), p(s.Wqkv.bias)
             L.Wqk, L.bqk, L.Wv, L.bv = p(x.to_qk.weight), p(x.to_qk.bias), p(x.to_v.weight), p(x.to_v.bias)
-            L.Wco, L.bco = p(x.to_out.weight), p(x.to_out.bias)
-            L.cf0_w, L.cf0_b, L.cln_g, L.cln_b = p(x.ffn[0].weight), p(x.ffn[0].bias), p(x.ffn[1].weight), p(x.ffn[1].bias)
+            if self.fold_message_projection:
+                sw, sb = fold(s.ffn[0], s.out_proj)
+                xw, xb = fold(x.ffn[0], x.to_out)
+                L.Wo, L.bo, L.Wco, L.bco = None, None, None, None
+                L.sf0_w, L.sf0_b, L.cf0_w, L.cf0_b = p(sw), p(sb), p(xw), p(xb)
+            else:
+                L.Wo, L.bo, L.Wco, L.bco = p(s.out_proj.weight), p(s.out_proj.bias), p(x.to_out.weight), p(x.to_out.bias)
+                L.sf0_w, L.sf0_b, L.cf0_w, L.cf0_b = p(s.ffn[0].weight), p(s.ffn[0].bias), p(x.ffn[0].weight), p(x.ffn[0].bias)
+            L.sln_g, L.sln_b = p(s.ffn[1].weight), p(s.ffn[1].bias)
+            L.sf3_w, L.sf3_b = p(s.ffn[3].weight), p(s.ffn[3].bias)
+            L.cln_g, L.cln_b = p(x.ffn[1].weight), p(x.ffn[1].bias)
             L.cf3_w, L.cf3_b = p(x.ffn[3].weight), p(x.ffn[3].bias)
         w = _lib.LgWeights()
         if isinstance(self.input_proj, nn.Linear):

@@ -64,7 +64,7 @@ struct GemmArgs {
   const float* W;
   const float* bias;
   float* Y;
-  const int32_t* cnt;
+  const int32_t* cnt;  // per-batch row counts, or null: every batch has `cap` rows
   int cap, ldx, ldx2, Ksplit, K, N, ldy;
   float div;
 };
@@ -73,7 +73,7 @@ template <int EPI>
 __global__ __launch_bounds__(THREADS) void lg_gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int b = blockIdx.z;
-  const int n = min(g.cnt[b], g.cap);
+  const int n = g.cnt ? min(g.cnt[b], g.cap) : g.cap;
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   if (i0 >= n) return;
   Frag f;
@@ -441,15 +441,40 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
 }
 
 // ffn(cat[x,msg]) + residual, in place on s.x
-int ffn(hipStream_t st, const Side& s, int B, const float* w0, const float* b0, const float* g, const float* be, const float* w3,
-        const float* b3) {
-  if (gemm(st, EPI_BIAS, s, B, s.x, D, s.msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
+int ffn(hipStream_t st, const Side& s, int B, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
+        const float* w3, const float* b3) {
+  if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
   hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
   if (hipGetLastError() != hipSuccess) return -1;
   return gemm(st, EPI_RESID, s, B, s.h, 2 * D, nullptr, 0, 0x7fffffff, 2 * D, w3, b3, D, s.x, D);
 }
 
 }  // namespace
+
+EINX_EXPORT int einx_linear(const float* x, int M, int K, const float* w, const float* bias, int N, float* y, int accumulate, void* stream) {
+  EINX_CHECK_ARG(x && w && bias && y, "null pointer");
+  EINX_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0, "bad shape (K must be a multiple of 4)");
+  GemmArgs g;
+  g.X = x;
+  g.X2 = nullptr;
+  g.W = w;
+  g.bias = bias;
+  g.Y = y;
+  g.cnt = nullptr;
+  g.cap = M;
+  g.ldx = K;
+  g.ldx2 = 0;
+  g.Ksplit = 0x7fffffff;
+  g.K = K;
+  g.N = N;
+  g.ldy = N;
+  g.div = 1.0f;
+  const dim3 grid((unsigned)einx_cdiv(N, BN), (unsigned)einx_cdiv(M, BM), 1);
+  if (accumulate) hipLaunchKernelGGL(lg_gemm_kernel<EPI_RESID>, grid, dim3(THREADS), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, (hipStream_t)stream, g);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
 
 EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) {
   if (B <= 0 || cap0 <= 0 || cap1 <= 0 || d != D) return 0;
@@ -514,8 +539,12 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
                          s.cap, s.q, s.k, s.v);
       LG_CHECK(0);
       LG_CHECK(attn(st, B, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
-      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
-      LG_CHECK(ffn(st, s, B, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+      if (L.Wo) {
+        LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
+        LG_CHECK(ffn(st, s, B, s.msg, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+      } else {  // out_proj folded into the FFN's first Linear at load time: message = context
+        LG_CHECK(ffn(st, s, B, s.ctx, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+      }
     }
     for (int sd = 0; sd < 2; ++sd) {
       Side& s = *sides[sd];
@@ -526,8 +555,12 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
     LG_CHECK(attn(st, B, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));
     for (int sd = 0; sd < 2; ++sd) {
       Side& s = *sides[sd];
-      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wco, L.bco, D, s.msg, D));
-      LG_CHECK(ffn(st, s, B, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+      if (L.Wco) {
+        LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wco, L.bco, D, s.msg, D));
+        LG_CHECK(ffn(st, s, B, s.msg, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+      } else {
+        LG_CHECK(ffn(st, s, B, s.ctx, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+      }
     }
   }
   // ---- assignment ------------------------------------------------------------------------------

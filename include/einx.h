@@ -156,6 +156,12 @@ int einx_gather_matches(const float* kpts0, const float* kpts1, const int64_t* m
 /* ------------------------------------------------------------------------------------------
  * LightGlue  (K8, K9)   core/modules/matchers/lightglue.py:522-716
  * ---------------------------------------------------------------------------------------- */
+/* y[M,N] (+)= x[M,K] w[N,K]^T + bias[N]   (torch.nn.functional.linear; also used at load time to
+ * fold LightGlue's out_proj / to_out into the following FFN Linear).  accumulate != 0: y += ... */
+int einx_linear(const float* x, int M, int K, const float* w, const float* bias, int N, float* y, int accumulate, void* stream);
+
+/* Wo / Wco may be NULL: the message projection has then been folded into sf0_w / cf0_w
+ * (x' = ffn(cat[x, context]) with W0' = [W0a | W0b Wo], b0' = b0 + W0b bo). */
 typedef struct einx_lg_layer {
   /* SelfBlock (:240-272) */
   const float *Wqkv, *bqkv, *Wo, *bo, *sf0_w, *sf0_b, *sln_g, *sln_b, *sf3_w, *sf3_b;

@@ -622,3 +622,24 @@ def test_same_time_harness_end_to_end(oracle):
     res = evalr.result()
     assert set(res) == {"MR", "MMA@1", "MMA@3", "VDD_Repeatability@1", "VDD_ValidDistance@1", "VDD_Angle@1", "VDD_Repeatability@3",
                         "VDD_ValidDistance@3", "VDD_Angle@3"}
+
+
+def test_lightglue_weight_folding_is_equivalent():
+    """fold_message_projection (out_proj / to_out folded into the FFN's first Linear at load time)
+    must not change the assignment and may move floats only at rounding level."""
+    from helpers import lg_inputs
+    c = LG.cases["d256"]
+    lg, _ = _lg_model(c)
+    d0, d1, k0, k1 = lg_inputs(c)
+    size = torch.tensor([260, 346])
+    f0 = {"sparse_descriptors": _t(d0)[None], "sparse_positions": _t(k0)[None], "image_size": [size]}
+    f1 = {"sparse_descriptors": _t(d1)[None], "sparse_positions": _t(k1)[None], "image_size": [size]}
+    lg.fold_message_projection = True
+    lg.refresh()
+    a = lg(f0, f1)
+    lg.fold_message_projection = False
+    lg.refresh()
+    b = lg(f0, f1)
+    assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
+    np.testing.assert_allclose(_np(a["log_assignment"]), _np(b["log_assignment"]), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(_np(a["ref_descriptors0"]), _np(b["ref_descriptors0"]), atol=2e-5, rtol=1e-5)
