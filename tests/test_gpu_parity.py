@@ -641,5 +641,5 @@ def test_lightglue_weight_folding_is_equivalent():
     lg.refresh()
     b = lg(f0, f1)
     assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
-    np.testing.assert_allclose(_np(a["log_assignment"]), _np(b["log_assignment"]), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(_np(a["log_assignment"]), _np(b["log_assignment"]), atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(_np(a["ref_descriptors0"]), _np(b["ref_descriptors0"]), atol=2e-5, rtol=1e-5)
