@@ -1,11 +1,14 @@
-"""Drop-in for the reference's `core.modules` package (core/modules/__init__.py:1-12)."""
+"""Native drop-in for the reference package `core.modules` (its __init__ exposes `build_model`,
+core/modules/__init__.py:5-12): model name -> constructor, same NotImplementedError for unknown names."""
 from .EIM import EIM
 from .ImageImageMatcher import ImageImageMatcher
 
+_MODELS = {"EIM": EIM, "ImageImageMatcher": ImageImageMatcher}
+
 
 def build_model(config, device, logger):
-    if config.name == "EIM":
-        return EIM(config, device, logger)
-    if config.name == "ImageImageMatcher":
-        return ImageImageMatcher(config, device, logger)
-    raise NotImplementedError(f"Unsupported model: {config.name}")
+    try:
+        ctor = _MODELS[config.name]
+    except KeyError:
+        raise NotImplementedError(f"Unsupported model: {config.name}") from None
+    return ctor(config, device, logger)
