@@ -146,15 +146,17 @@ class ExtractorEngine:
         for layer in self.desc_head:
             d = layer(d)
         raw = d
-        prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
         bf = BatchedFeats()
         bf.kind, bf.cell, bf.B = self.kind, self.cell, B
         bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
-        bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
         bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
-        self.redetect(bf, nms_iters)
+        # dense by-products first: they depend only on `raw`, so they run under the other stream's
+        # convolutions instead of lengthening the latency-bound detection tail at the end of the step
         if self.cell == 8:
             bf.coarse = N.normalize_map(raw, scale)
+        prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
+        bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
+        self.redetect(bf, nms_iters)
         if dense:
             if self.cell == 8:
                 bf.normalized = N.upsample_normalize(raw, (Hp, Wp), pads, scale)

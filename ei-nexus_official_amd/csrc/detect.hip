@@ -368,41 +368,78 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
   if (tid == 0) sh_bad = 0;
   __syncthreads();
   // ---- sweep 1: ordered compaction of non-zeros into LDS ---------------------------------------
-  int nz = 0;
-  const bool vec = (N % 4 == 0) && ((reinterpret_cast<size_t>(m) & 15) == 0);
-  for (int i0 = 0; i0 < N; i0 += SEL_THREADS * 4) {
-    const int i = i0 + tid * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+  // Each of the 16 waves owns one contiguous slice of the map: count its non-zeros, one block-level
+  // prefix over the 16 counts, then compact the slice at its offset with wave-local ballots only
+  // (no block barrier inside the loops; the second read of the slice comes from L2).
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NWAVES = SEL_THREADS / 64;
+  const int per_wave = ((N + NWAVES - 1) / NWAVES + 255) & ~255;  // multiple of 256 = 64 lanes x 4
+  const int w0 = wave * per_wave, w1 = min(N, w0 + per_wave);
+  const bool vec = (reinterpret_cast<size_t>(m) & 15) == 0;
+  auto load4 = [&](int i, float* v) {
     if (vec && i + 3 < N) {
       const f32x4 q = *reinterpret_cast<const f32x4*>(m + i);
       v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
     } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) if (i + t < N) v[t] = m[i + t];
+      for (int t = 0; t < 4; ++t) v[t] = (i + t < N) ? m[i + t] : 0.0f;
     }
-    int c = 0;
-    bool neg = false;
+  };
+  int cnt_w = 0;
+  bool neg = false;
+  for (int i0 = w0; i0 < w1; i0 += 256) {
+    float v[4];
+    load4(i0 + lane * 4, v);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      c += (v[t] != 0.0f) ? 1 : 0;
+      cnt_w += (v[t] != 0.0f) ? 1 : 0;
       neg = neg || (v[t] < 0.0f) || (v[t] != v[t]);
     }
-    if (neg) sh_bad = 1;
-    int total;
-    int pos = nz + block_excl_scan(c, &total, scratch);
+  }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (v[t] != 0.0f) {
-        if (pos < SEL_LCAP) {
-          cval[pos] = v[t];
-          cidx[pos] = i + t;
-        }
-        ++pos;
-      }
-    nz += total;
+  for (int off = 32; off >= 1; off >>= 1) cnt_w += __shfl_xor(cnt_w, off, 64);
+  if (neg) sh_bad = 1;
+  if (lane == 0) scratch[wave] = cnt_w;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < NWAVES; ++w) {
+      const int t = scratch[w];
+      scratch[w] = run;
+      run += t;
+    }
+    scratch[16] = run;
   }
   __syncthreads();
-  if (sh_bad || nz > SEL_LCAP) {  // uniform across the block
+  const int nz = scratch[16];
+  if (!sh_bad && nz <= SEL_LCAP) {
+    int pos_w = scratch[wave];
+    for (int i0 = w0; i0 < w1; i0 += 256) {
+      float v[4];
+      const int i = i0 + lane * 4;
+      load4(i, v);
+      int c = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c += (v[t] != 0.0f) ? 1 : 0;
+      int incl = c;  // wave-inclusive scan of the per-lane counts
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      int pos = pos_w + incl - c;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (v[t] != 0.0f) {
+          cval[pos] = v[t];
+          cidx[pos] = i + t;
+          ++pos;
+        }
+      pos_w += __shfl(incl, 63, 64);
+    }
+  }
+  __syncthreads();
+  if (sh_bad || nz > SEL_LCAP) {  // uniform across the block: dense map or negative values
     select_compact_generic(a, hist, scratch);
     return;
   }
