@@ -643,3 +643,30 @@ def test_lightglue_weight_folding_is_equivalent():
     assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
     np.testing.assert_allclose(_np(a["log_assignment"]), _np(b["log_assignment"]), atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(_np(a["ref_descriptors0"]), _np(b["ref_descriptors0"]), atol=2e-5, rtol=1e-5)
+
+
+def test_small_helper_functions(oracle):
+    """logits_to_prob / depth_to_space / remove_border_points / get_dense_* with the reference's
+    signatures (silk magicpoint_test.py:60-101 properties: softmax sums to one, score shape)."""
+    from importlib import import_module
+    du = import_module(pkg.__name__ + ".core.modules.utils.detector_util")
+    dd = import_module(pkg.__name__ + ".core.modules.utils.descriptor_util")
+    logits = synth.normalish(5, (3, 65, 16, 16))
+    prob = du.logits_to_prob(_t(logits))
+    eprob, escore = oracle.logits_to_score(logits)
+    assert np.array_equal(_np(prob), eprob)
+    np.testing.assert_allclose(_np(prob).sum(1), 1.0, atol=1e-6)
+    score = du.depth_to_space(prob, cell_size=8)
+    assert tuple(score.shape) == (3, 1, 128, 128)
+    assert np.array_equal(_np(score), escore)
+    l1 = synth.normalish(6, (2, 1, 20, 24))
+    p1 = du.logits_to_prob(_t(l1))
+    assert np.array_equal(_np(p1), oracle.logits_to_score(l1)[0])
+    assert du.depth_to_space(p1, cell_size=1) is p1  # cell-1: the same tensor (reference aliasing)
+    m = _t(synth.uniform01(7, (1, 1, 8, 8)))
+    assert not _np(du.remove_border_points(m, 4)).any()  # silk utils_test.py:17-29
+    dpos = du.get_dense_positions(score, ordering="yx")
+    assert tuple(dpos.shape) == (3, 128 * 128, 3)
+    assert _np(dpos[0, 129]).tolist()[:2] == [1.5, 1.5] and float(dpos[1, 5, 2]) == float(score[1, 0, 0, 5])
+    nd = dd.normalize_descriptors(_t(synth.normalish(8, (2, 16, 4, 5))), 1.0)
+    assert tuple(dd.get_dense_descriptors(nd).shape) == (2, 20, 16)
