@@ -670,3 +670,49 @@ def test_small_helper_functions(oracle):
     assert _np(dpos[0, 129]).tolist()[:2] == [1.5, 1.5] and float(dpos[1, 5, 2]) == float(score[1, 0, 0, 5])
     nd = dd.normalize_descriptors(_t(synth.normalish(8, (2, 16, 4, 5))), 1.0)
     assert tuple(dd.get_dense_descriptors(nd).shape) == (2, 20, 16)
+
+
+@pytest.mark.parametrize("matcher", ["MNN", "LightGlue"])
+def test_ragged_keypoint_counts_in_a_batch(oracle, matcher):
+    """pairs with different keypoint counts (one event sample has almost no events -> far fewer than k
+    keypoints) go through the same batched launches; every pair must equal its own per-pair oracle run."""
+    cfg = pkg.default_config("SP_MNN" if matcher == "MNN" else "SP_LG", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 150
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sdn = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=41)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    B, H, W = 3, 120, 152
+    ev, mask = synth.synth_events(61, B, 5, H, W)
+    keep = np.zeros_like(mask[1])
+    keep[:, 40:52, 60:80] = True  # sample 1: events only in a small window -> few keypoints
+    mask[1] &= keep
+    ev[1] *= mask[1]
+    img = synth.synth_image(61, B, H, W)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    counts = [int(p.shape[0]) for p in ef["sparse_positions"]]
+    assert counts[1] < 150 and counts[0] == 150 and counts[1] > 0
+    oe = oracle.extractor_forward("vgg", sub_dict(sdn, "event_extractor.extractor."), ev.copy(), mask, top_k=150)
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sdn, "image_extractor.extractor."), img.copy(), None, top_k=150)
+    _assert_feats_equal_oracle(ef, oe)
+    _assert_feats_equal_oracle(imf, oi)
+    for b in range(B):
+        k0, k1 = oe["sparse_positions"][b], oi["sparse_positions"][b]
+        d0, d1 = oe["sparse_descriptors"][b], oi["sparse_descriptors"][b]
+        if matcher == "MNN":
+            r = oracle.mnn(d0, d1)
+            assert np.array_equal(_np(m["matches0"][b])[0], r["matches0"])
+            assert np.array_equal(_np(m["matches1"][b])[0], r["matches1"])
+            np.testing.assert_allclose(_np(m["log_assignment"][b])[0], r["log_assignment"], atol=1e-5)
+            cols = 3
+        else:
+            r = oracle.lightglue(sub_dict(sdn, "matcher.matcher."), k0, d0, k1, d1, size0=(H, W), size1=(H, W))
+            assert np.array_equal(_np(m["matches0"][b])[0], r["matches0"])
+            np.testing.assert_allclose(_np(m["matching_scores0"][b])[0], r["matching_scores0"], atol=FTOL)
+            np.testing.assert_allclose(_np(m["log_assignment"][b])[0], r["log_assignment"], atol=2e-4, rtol=1e-4)
+            cols = 2
+        mk0, mk1 = oracle.matched_kpts(k0, k1, r["matches0"], cols)
+        assert np.array_equal(_np(m["matched_kpts0"][b]), mk0) and np.array_equal(_np(m["matched_kpts1"][b]), mk1)
+        assert tuple(m["matches0"][b].shape) == (1, len(k0)) and tuple(m["log_assignment"][b].shape) == (1, len(k0) + 1, len(k1) + 1)
