@@ -79,7 +79,11 @@ SIGNATURES = {
     "einx_lg_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "einx_lightglue": (c_int, [ctypes.POINTER(LgWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p]),
+                               c_void_p, c_void_p, c_int, c_void_p]),
+    "einx_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "einx_similarity": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "einx_normalize_keypoints": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "einx_random_positions": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

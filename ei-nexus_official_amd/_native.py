@@ -240,8 +240,9 @@ def gather_matches(r, kpts0, kpts1, n, cols):
     return r
 
 
-def lightglue(weights, pb0, pb1, want_la=True, want_ref=False):
-    """weights: _lib.LgWeights; pb0/pb1: PairBatch (kpts [B,cap,3], desc [B,cap,Din], counts)."""
+def lightglue(weights, pb0, pb1, want_la=True, want_ref=False, all_layers=False):
+    """weights: _lib.LgWeights; pb0/pb1: PairBatch (kpts [B,cap,3], desc [B,cap,Din], counts).
+    all_layers: ref0/ref1 are [B,n_layers,cap,d] (training-mode ref_descriptors) instead of [B,cap,d]."""
     _dev_check(pb0.kpts, pb0.desc, pb0.counts, pb1.kpts, pb1.desc, pb1.counts)
     B, cap0, cap1 = pb0.B, pb0.cap, pb1.cap
     L = lib()
@@ -254,14 +255,62 @@ def lightglue(weights, pb0, pb1, want_la=True, want_ref=False):
     r.scores0 = torch.empty((B, cap0), dtype=F32, device=dev)
     r.scores1 = torch.empty((B, cap1), dtype=F32, device=dev)
     r.la = torch.empty((B, cap0 + 1, cap1 + 1), dtype=F32, device=dev) if want_la else None
-    r.ref0 = torch.empty((B, cap0, d), dtype=F32, device=dev) if want_ref else None
-    r.ref1 = torch.empty((B, cap1, d), dtype=F32, device=dev) if want_ref else None
+    nl = int(weights.n_layers)
+    if want_ref and all_layers:
+        r.ref0 = torch.zeros((B, nl, cap0, d), dtype=F32, device=dev)
+        r.ref1 = torch.zeros((B, nl, cap1, d), dtype=F32, device=dev)
+    else:
+        r.ref0 = torch.empty((B, cap0, d), dtype=F32, device=dev) if want_ref else None
+        r.ref1 = torch.empty((B, cap1, d), dtype=F32, device=dev) if want_ref else None
     (h0, w0), (h1, w1) = pb0.image_size, pb1.image_size
     check(L.einx_lightglue(ctypes.byref(weights), _ptr(pb0.kpts), _ptr(pb0.desc), _ptr(pb0.counts), cap0, _ptr(pb1.kpts), _ptr(pb1.desc),
                            _ptr(pb1.counts), cap1, B, float(h0), float(w0), float(h1), float(w1), _ptr(ws), _ptr(r.matches0),
-                           _ptr(r.matches1), _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _ptr(r.ref0), _ptr(r.ref1), _stream(pb0.desc)),
+                           _ptr(r.matches1), _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _ptr(r.ref0), _ptr(r.ref1),
+                           nl if (want_ref and all_layers) else 1, _stream(pb0.desc)),
           "einx_lightglue")
     return r
+
+
+def similarity(desc0, n, desc1, m):
+    """[B,cap0,cap1] descriptor similarity (MNN.py:88); zero outside the first n[b] x m[b] block."""
+    _dev_check(desc0, desc1, n, m)
+    B, cap0, D = desc0.shape
+    cap1 = desc1.shape[1]
+    sim = torch.empty((B, cap0, cap1), dtype=F32, device=desc0.device)
+    check(lib().einx_similarity(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, _ptr(sim), _stream(desc0)), "einx_similarity")
+    return sim
+
+
+def normalize_rows(x, scale):
+    """F.normalize(x, dim=1) * scale for a [R,C] matrix."""
+    _dev_check(x)
+    R, C = x.shape
+    out = torch.empty_like(x)
+    if R:
+        check(lib().einx_normalize_rows(_ptr(x), R, C, float(scale), _ptr(out), _stream(x)), "einx_normalize_rows")
+    return out
+
+
+def normalize_keypoints(kpts, size, out_cols=2):
+    """lightglue.py:137-148 on [..., cols>=2] keypoints -> [..., out_cols] (zeros beyond column 1)."""
+    _dev_check(kpts)
+    cols = kpts.shape[-1]
+    rows = kpts.numel() // cols
+    out = torch.empty(tuple(kpts.shape[:-1]) + (out_cols,), dtype=F32, device=kpts.device)
+    if rows:
+        check(lib().einx_normalize_keypoints(_ptr(kpts), rows, cols, float(size[0]), float(size[1]), _ptr(out), out_cols, _stream(kpts)),
+              "einx_normalize_keypoints")
+    return out
+
+
+def random_positions(u, size):
+    """u [R,2] uniform draws -> [R,3] = (u0*size0, u1*size1, 0)  (Matchers.py:80-91)."""
+    _dev_check(u)
+    R = u.shape[0]
+    out = torch.empty((R, 3), dtype=F32, device=u.device)
+    if R:
+        check(lib().einx_random_positions(_ptr(u), R, float(size[0]), float(size[1]), _ptr(out), _stream(u)), "einx_random_positions")
+    return out
 
 
 def linear(x, w, bias, out=None, accumulate=False):

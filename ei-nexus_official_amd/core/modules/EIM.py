@@ -63,9 +63,7 @@ class EIM(nn.Module):
             ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
             im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
         mr = None
-        if self.matcher.matcher is not None:
-            if not self.matcher.freeze:
-                raise NotImplementedError("einx: set matcher.freeze: true (the trainable matcher branch is out of scope)")
+        if self.matcher.matcher is not None and self.matcher.freeze:
             mr = self.matcher.match_batched(ev, im)
         return ev, im, mr
 
@@ -96,6 +94,11 @@ class EIM(nn.Module):
             n = [min(v, ev.det.cap) for v in n]
             m = [min(v, im.det.cap) for v in m]
             matches = self.matcher.materialize(mr, n, m, host[4].tolist())
+        elif self.matcher.matcher is not None:
+            # un-frozen matcher (EIM.py:92-95 -> Matchers.py:204-222): random padding to max_points_num and
+            # one stacked call; like the reference it rewrites sparse_positions / sparse_descriptors of
+            # the two feature dicts in place
+            matches = self.matcher(events_feats, image_feats)
         return events_feats, image_feats, matches
 
     def count_parameters(self, model):

@@ -19,11 +19,27 @@ def from_batched(bf):
 
 def from_feats(feats):
     """Accepts the reference-style dict (lists of per-image tensors, or stacked tensors)."""
+    pos, desc = feats["sparse_positions"], feats["sparse_descriptors"]
+    if torch.is_tensor(pos) and pos.dim() == 3 and pos.shape[1] > 0:
+        # stacked [B,n,*] tensors (the un-frozen Matcher branch, Matchers.py:145-149): used as they are
+        B, n = int(pos.shape[0]), int(pos.shape[1])
+        pb = PairBatch()
+        if pos.shape[2] == 3:
+            pb.kpts = pos.to(torch.float32).contiguous()
+        else:
+            pb.kpts = torch.zeros((B, n, 3), dtype=torch.float32, device=pos.device)
+            pb.kpts[:, :, :pos.shape[2]] = pos
+        pb.desc = desc.to(torch.float32).contiguous()
+        pb.counts_host = [n] * B
+        pb.counts = torch.full((B,), n, dtype=torch.int32, device=pos.device)
+        size = feats["image_size"][0]
+        pb.image_size = (int(size[0]), int(size[1]))
+        pb.cap, pb.B = n, B
+        return pb
     if isinstance(feats, FeatsDict) and feats._batched is not None:
         pb = from_batched(feats._batched)
         pb.counts_host = [int(p.shape[0]) for p in feats["sparse_positions"]]
         return pb
-    pos, desc = feats["sparse_positions"], feats["sparse_descriptors"]
     if torch.is_tensor(pos):
         pos, desc = list(pos), list(desc)
     B = len(pos)
@@ -91,3 +107,22 @@ def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None):
         out["matched_kpts1"].append(r.mk1[b, :M, :cols])
         out["log_assignment"].append(None if r.la is None else r.la[b, :n + 1, :m + 1][None])
     return out
+
+
+def stacked_outputs(r, nmatch_host, cols, mk0=None, mk1=None):
+    """The reference matchers' own return value for a stacked batch with b > 1
+    (MNN.py:103-118,131-140; lightglue.py:675-687,700-712): whole-batch tensors plus per-pair lists
+    of matched keypoints.  A pair without any match makes the reference's torch.stack([]) raise."""
+    if any(v == 0 for v in nmatch_host):
+        raise RuntimeError("stack expects a non-empty TensorList")
+    mk0 = r.mk0 if mk0 is None else mk0
+    mk1 = r.mk1 if mk1 is None else mk1
+    B = len(nmatch_host)
+    return {
+        "matches0": r.matches0, "matches1": r.matches1, "matching_scores0": r.scores0, "matching_scores1": r.scores1,
+        "matched_kpts0": [mk0[b, :nmatch_host[b], :cols] for b in range(B)],
+        "matched_kpts1": [mk1[b, :nmatch_host[b], :cols] for b in range(B)],
+        "log_assignment": r.la,
+    }
+
+

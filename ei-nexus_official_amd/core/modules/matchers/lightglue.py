@@ -14,7 +14,7 @@ from torch import nn
 
 from .... import _lib
 from .... import _native as N
-from ._batched import from_feats, materialize_matches
+from ._batched import from_feats, materialize_matches, stacked_outputs
 
 
 class _Conf(dict):
@@ -185,28 +185,60 @@ class LightGlue(nn.Module):
         self._packed = (w, layers, keep)
         return self._packed
 
-    def match_batched(self, pb0, pb1):
+    def match_batched(self, pb0, pb1, all_layers=False):
         if pb0.desc.shape[-1] != self.conf.input_dim or pb1.desc.shape[-1] != self.conf.input_dim:
             raise AssertionError("descriptor dimension does not match conf.input_dim")
         w = self._pack()[0]
-        r = N.lightglue(w, pb0, pb1, want_la=self.want_log_assignment, want_ref=True)
+        r = N.lightglue(w, pb0, pb1, want_la=self.want_log_assignment, want_ref=True, all_layers=all_layers)
         return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 2)
 
     @torch.no_grad()
     def forward(self, feats0, feats1):
+        """B == 1: the per-pair dict (matched keypoints in pixel coordinates, lightglue.py:689-698).
+        B > 1 (stacked [B,n,*] inputs): whole-batch tensors and per-pair matched keypoints in
+        *normalised* coordinates, as lightglue.py:675-687 returns them.  In training mode
+        (`self.training`) ref_descriptors hold every layer's output [B,L,n,d] (:626-629,709-710);
+        forward values only -- autograd / the loss are outside this build."""
+        pos0, pos1 = feats0["sparse_positions"], feats1["sparse_positions"]
+        stacked = torch.is_tensor(pos0) and pos0.dim() == 3 and torch.is_tensor(pos1) and pos1.dim() == 3
+        if stacked:
+            if feats0["sparse_descriptors"].shape[-1] != self.conf.input_dim or feats1["sparse_descriptors"].shape[-1] != self.conf.input_dim:
+                raise AssertionError("descriptor dimension does not match conf.input_dim")
+            if pos0.shape[0] > 1 and (pos0.numel() == 0 or pos1.numel() == 0):
+                f = feats0["sparse_descriptors"]
+                B, n, m = pos0.shape[0], pos0.shape[1], pos1.shape[1]
+                print("No keypoints found in either image")
+                return {"matches0": f.new_full((B, n), -1), "matches1": f.new_full((B, m), -1), "matching_scores0": f.new_zeros((B, n)),
+                        "matching_scores1": f.new_zeros((B, m)), "matched_kpts0": [f.new_zeros((n, 3))] * B,
+                        "matched_kpts1": [f.new_zeros((m, 3))] * B, "similarity": f.new_zeros((B, n, m)),
+                        "log_assignment": f.new_zeros((B, n + 1, m + 1))}
         pb0, pb1 = from_feats(feats0), from_feats(feats1)
-        r = self.match_batched(pb0, pb1)
-        nm = r.nmatch.cpu().tolist()
+        all_layers = bool(self.training)
+        r = self.match_batched(pb0, pb1, all_layers=all_layers)
         n = pb0.counts_host or pb0.counts.cpu().tolist()
         m = pb1.counts_host or pb1.counts.cpu().tolist()
-        lists = materialize_matches(r, n, m, nm, 2)
-        if pb0.B != 1:
-            raise NotImplementedError("einx LightGlue.forward mirrors the reference's per-pair (B=1) call; use Matcher for batches")
-        out = {k: v[0] for k, v in lists.items()}
-        if n[0] and m[0]:
-            d = self.conf.descriptor_dim
-            out["ref_descriptors0"] = r.ref0[0, :n[0]][None, None]
-            out["ref_descriptors1"] = r.ref1[0, :m[0]][None, None]
-            out["prune0"] = torch.ones_like(out["matching_scores0"]) * self.conf.n_layers
-            out["prune1"] = torch.ones_like(out["matching_scores1"]) * self.conf.n_layers
+        L = self.conf.n_layers
+        if pb0.B == 1:
+            nm = r.nmatch.cpu().tolist()
+            out = {k: v[0] for k, v in materialize_matches(r, n, m, nm, 2).items()}
+            if n[0] and m[0]:
+                ref0 = r.ref0 if all_layers else r.ref0[:, None]
+                ref1 = r.ref1 if all_layers else r.ref1[:, None]
+                out["ref_descriptors0"] = ref0[:, :, :n[0]]
+                out["ref_descriptors1"] = ref1[:, :, :m[0]]
+                out["prune0"] = torch.ones_like(out["matching_scores0"]) * L
+                out["prune1"] = torch.ones_like(out["matching_scores1"]) * L
+            return out
+        if not (stacked and len(set(n)) == 1 and len(set(m)) == 1):
+            raise NotImplementedError("einx LightGlue.forward with B > 1 takes stacked [B,n,*] tensors (as the reference does); "
+                                      "use Matcher for ragged batches")
+        # b > 1: matched keypoints are gathered from the normalised coordinates (reference behaviour)
+        k0 = N.normalize_keypoints(pb0.kpts, pb0.image_size, out_cols=3)
+        k1 = N.normalize_keypoints(pb1.kpts, pb1.image_size, out_cols=3)
+        N.gather_matches(r, k0, k1, pb0.counts, 2)
+        out = stacked_outputs(r, r.nmatch.cpu().tolist(), 2)
+        out["ref_descriptors0"] = r.ref0 if all_layers else r.ref0[:, None]
+        out["ref_descriptors1"] = r.ref1 if all_layers else r.ref1[:, None]
+        out["prune0"] = torch.ones_like(r.scores0) * L
+        out["prune1"] = torch.ones_like(r.scores1) * L
         return out

@@ -84,6 +84,28 @@ __global__ __launch_bounds__(256) void desc_sample_kernel(const float* raw, int 
   }
 }
 
+// one wave per row of a [R,C] matrix: F.normalize(x, dim=1) * scale; lane l accumulates columns
+// l, l+64, ... (sequential fmaf) then the xor butterfly, like the sparse descriptor kernels
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* x, int R, int C, float scale, float* out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* r = x + (size_t)row * C;
+  float part = 0.0f;
+  for (int c = lane; c < C; c += 64) part = fmaf(r[c], r[c], part);
+  const float den = fmaxf(sqrtf(wave_butterfly_sum(part)), 1e-12f);
+  float* o = out + (size_t)row * C;
+  for (int c = lane; c < C; c += 64) o[c] = scale * (r[c] / den);
+}
+
+__global__ void random_positions_kernel(const float* u, int R, float s0, float s1, float* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= R) return;
+  out[t * 3 + 0] = u[t * 2 + 0] * s0;
+  out[t * 3 + 1] = u[t * 2 + 1] * s1;
+  out[t * 3 + 2] = 0.0f;
+}
+
 // thread per pixel, channels walked sequentially (fmaf chain c = 0..D-1)
 __global__ void normalize_map_kernel(const float* raw, int B, int D, int P, float scale, float* out) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +180,22 @@ EINX_EXPORT int einx_normalize_map(const float* raw, int B, int D, int P, float 
   EINX_CHECK_ARG(B > 0 && D > 0 && P > 0, "bad shape");
   const size_t n = (size_t)B * P;
   hipLaunchKernelGGL(normalize_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, B, D, P, scale, out);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_normalize_rows(const float* x, int R, int C, float scale, float* out, void* stream) {
+  EINX_CHECK_ARG(x && out, "null pointer");
+  EINX_CHECK_ARG(R > 0 && C > 0, "bad shape");
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)einx_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, scale, out);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_random_positions(const float* u, int R, float size0, float size1, float* out, void* stream) {
+  EINX_CHECK_ARG(u && out, "null pointer");
+  EINX_CHECK_ARG(R > 0, "bad shape");
+  hipLaunchKernelGGL(random_positions_kernel, dim3((unsigned)einx_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, u, R, size0, size1, out);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

@@ -360,12 +360,23 @@ __global__ void lg_finalize_kernel(const unsigned long long* rowkey, const unsig
   }
 }
 
-__global__ void lg_copy_rows_kernel(const float* src, float* dst, const int32_t* cnt, int cap, int width) {
+// dst_bstride: elements between consecutive batches of dst (cap*width for a plain [B,cap,width] copy)
+__global__ void lg_copy_rows_kernel(const float* src, float* dst, const int32_t* cnt, int cap, int width, size_t dst_bstride) {
   const int b = blockIdx.y;
   const int n = min(cnt[b], cap);
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)n * width) return;
-  dst[(size_t)b * cap * width + t] = src[(size_t)b * cap * width + t];
+  dst[(size_t)b * dst_bstride + t] = src[(size_t)b * cap * width + t];
+}
+
+// normalize_keypoints (lightglue.py:137-148): (kpt - size/2) / (max(size)/2), first two columns
+__global__ void lg_normalize_kpts_kernel(const float* kpts, int cols, size_t total, float s0, float s1, float* out, int out_cols) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const float sc = fmaxf(s0, s1) / 2.0f;
+  out[t * out_cols + 0] = (kpts[t * cols + 0] - s0 / 2.0f) / sc;
+  out[t * out_cols + 1] = (kpts[t * cols + 1] - s1 / 2.0f) / sc;
+  for (int c = 2; c < out_cols; ++c) out[t * out_cols + c] = 0.0f;
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -476,6 +487,16 @@ EINX_EXPORT int einx_linear(const float* x, int M, int K, const float* w, const 
   return EINX_OK;
 }
 
+EINX_EXPORT int einx_normalize_keypoints(const float* kpts, int rows, int cols, float h, float w, float* out, int out_cols,
+                                         void* stream) {
+  EINX_CHECK_ARG(kpts && out, "null pointer");
+  EINX_CHECK_ARG(rows > 0 && cols >= 2 && out_cols >= 2, "bad shape");
+  hipLaunchKernelGGL(lg_normalize_kpts_kernel, dim3((unsigned)einx_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, kpts, cols,
+                     (size_t)rows, h, w, out, out_cols);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
 EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) {
   if (B <= 0 || cap0 <= 0 || cap1 <= 0 || d != D) return 0;
   (void)input_dim;
@@ -485,13 +506,15 @@ EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_
 EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0,
                                const float* kpts1, const float* desc1, const int32_t* m, int cap1, int B, float h0, float w0, float h1,
                                float w1, void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la,
-                               float* ref0, float* ref1, void* stream) {
+                               float* ref0, float* ref1, int ref_layers, void* stream) {
   EINX_CHECK_ARG(w && kpts0 && desc0 && n && kpts1 && desc1 && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
   EINX_CHECK_ARG(w->d == D && w->heads == HEADS, "kernels are built for d=256, 4 heads of 64");
   EINX_CHECK_ARG(w->n_layers >= 1 && w->layers, "no layers");
   EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0, "bad shape");
   EINX_CHECK_ARG(w->input_dim % 4 == 0 && w->input_dim > 0, "input_dim must be a multiple of 4");
   EINX_CHECK_ARG((w->input_dim == D) == (w->in_w == nullptr), "input_proj must be given exactly when input_dim != d");
+  EINX_CHECK_ARG(ref_layers == 0 || ref_layers == 1 || ref_layers == w->n_layers, "ref_layers must be 0/1 (last layer) or n_layers");
+  const bool all_layers = ref_layers > 1;
   hipStream_t st = (hipStream_t)stream;
   Side s0{}, s1{};
   s0.kpts = kpts0;
@@ -522,7 +545,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
       LG_CHECK(gemm(st, EPI_BIAS, s, B, s.desc, w->input_dim, nullptr, 0, 0x7fffffff, w->input_dim, w->in_w, w->in_b, D, s.x, D));
     } else {
       const size_t per = (size_t)s.cap * D;
-      hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.desc, s.x, s.cnt, s.cap, D);
+      hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.desc, s.x, s.cnt, s.cap, D, per);
       LG_CHECK(0);
     }
     hipLaunchKernelGGL(lg_posenc_kernel, dim3((unsigned)einx_cdiv(s.cap * 32, 256), (unsigned)B), dim3(256), 0, st, s.kpts, s.cnt, s.cap,
@@ -561,6 +584,13 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
       } else {
         LG_CHECK(ffn(st, s, B, s.ctx, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
       }
+      float* ref = sd == 0 ? ref0 : ref1;
+      if (ref && all_layers) {  // training-mode output: every layer's descriptors (lightglue.py:626-629)
+        const size_t per = (size_t)s.cap * D;
+        hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.x, ref + (size_t)li * per,
+                           s.cnt, s.cap, D, per * (size_t)w->n_layers);
+        LG_CHECK(0);
+      }
     }
   }
   // ---- assignment ------------------------------------------------------------------------------
@@ -571,9 +601,10 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
                        w->match_b, s.cert, s.dust);
     LG_CHECK(0);
     float* ref = sd == 0 ? ref0 : ref1;
-    if (ref) {
+    if (ref && !all_layers) {
       const size_t per = (size_t)s.cap * D;
-      hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.x, ref, s.cnt, s.cap, D);
+      hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.x, ref, s.cnt, s.cap, D,
+                         per);
       LG_CHECK(0);
     }
   }

@@ -36,6 +36,7 @@ struct MnnArgs {
 };
 
 // MODE 0: arg-max keys.  MODE 1: per-chunk softmax statistics.  MODE 2: write log_assignment.
+// MODE 3: write the raw similarity tile to a.la as [B,cap0,cap1] (MNN.py:88 `similarity`).
 // LG: values are LightGlue's assignment scores (needs rowlse/collse from MODE 1 + mnn_lse_kernel).
 template <int MODE, bool LG = false>
 __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
@@ -172,6 +173,20 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
         o[1] = s;
       }
     }
+  } else if (MODE == 3) {
+    float* sim = a.la + (size_t)b * a.cap0 * a.cap1;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + row_of(mt, r);
+        if (i >= n) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int j = j0 + col_of(nt);
+          if (j < m) sim[(size_t)i * a.cap1 + j] = f.acc[mt][nt][r];
+        }
+      }
   } else {
     const size_t pitch = (size_t)a.cap1 + 1;
     float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;

@@ -76,6 +76,30 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
   return EINX_OK;
 }
 
+EINX_EXPORT int einx_similarity(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B,
+                                int D, float* sim, void* stream) {
+  EINX_CHECK_ARG(desc0 && desc1 && n && m && sim, "null pointer");
+  EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0 && D > 0 && D % 4 == 0, "bad shape (D must be a multiple of 4)");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sim, 0, (size_t)B * cap0 * cap1 * sizeof(float), s) != hipSuccess) {
+    einx_set_error("einx_similarity: memset failed");
+    return EINX_ERR_LAUNCH;
+  }
+  MnnArgs a{};
+  a.d0 = desc0;
+  a.d1 = desc1;
+  a.n = n;
+  a.m = m;
+  a.cap0 = cap0;
+  a.cap1 = cap1;
+  a.D = D;
+  a.la = sim;
+  const dim3 grid((unsigned)einx_cdiv(cap1, BN), (unsigned)einx_cdiv(cap0, BM), (unsigned)B);
+  hipLaunchKernelGGL(mnn_tile_kernel<3>, grid, dim3(THREADS), 0, s, a);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
 EINX_EXPORT int einx_gather_matches(const float* kpts0, const float* kpts1, const int64_t* matches0, const int32_t* n, int cap0, int cap1,
                                     int B, int cols, float* out0, float* out1, int32_t* nmatch, void* stream) {
   EINX_CHECK_ARG(kpts0 && kpts1 && matches0 && n && out0 && out1 && nmatch, "null pointer");

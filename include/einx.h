@@ -131,6 +131,14 @@ int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int
 /* normalize_descriptors over channels of a dense map (descriptor_util.py:21-28). [B,D,P] */
 int einx_normalize_map(const float* raw, int B, int D, int P, float scale, float* out, void* stream);
 
+/* F.normalize(x, dim=1) * scale on a row-major [R,C] matrix: the random padding descriptors of the
+ * trainable matcher branch (core/modules/Matchers.py:114-131) */
+int einx_normalize_rows(const float* x, int R, int C, float scale, float* out, void* stream);
+
+/* random padding keypoints of the same branch (Matchers.py:80-91): u [R,2] uniform draws ->
+ * out [R,3] = (u0*size0, u1*size1, 0) */
+int einx_random_positions(const float* u, int R, float size0, float size1, float* out, void* stream);
+
 /* upsample_descriptors: bilinear resize to (Hp,Wp) + normalize, written cropped to the
  * unpadded window [B,D,H,W] (descriptor_util.py:131-138 + Padder.unpad util.py:34-50) */
 int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int h0, int w0, int H, int W,
@@ -146,6 +154,11 @@ int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int 
 size_t einx_mnn_ws_bytes(int B, int cap0, int cap1);
 int einx_mnn(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
              void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, void* stream);
+
+/* similarity = einsum("bnd,bmd->bnm") (MNN.py:88), returned by the reference's un-frozen Matcher
+ * branch (Matchers.py:204-222).  sim [B,cap0,cap1]; entries outside [n[b], m[b]] are zero. */
+int einx_similarity(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
+                    float* sim, void* stream);
 
 /* matched keypoint gather in ascending keypoint-0 order (MNN.py:119-129, lightglue.py:690-698)
  * kpts0 [B,cap0,3], kpts1 [B,cap1,3]; cols = 3 (MNN) or 2 (LightGlue);
@@ -182,15 +195,22 @@ typedef struct einx_lg_weights {
   const einx_lg_layer* layers; /* host array of n_layers */
 } einx_lg_weights;
 
+/* normalize_keypoints (lightglue.py:137-148): kpts [rows,cols>=2] -> out [rows,out_cols>=2] with
+ * out[:, :2] = (kpt - (h,w)/2) / (max(h,w)/2) and zeros in further columns.  The batched (B>1)
+ * LightGlue call returns matched keypoints in these coordinates (lightglue.py:677-687). */
+int einx_normalize_keypoints(const float* kpts, int rows, int cols, float h, float w, float* out, int out_cols, void* stream);
+
 size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);
 /* kpts [B,cap,3] (first two columns used), desc [B,cap,input_dim], counts device int32.
  * size0/size1: image sizes (H,W) used by normalize_keypoints (:137-148).
  * outputs as einx_mnn; scores are exp(max log-assignment) for mutual matches (:402-418);
- * ref0/ref1: optional [B,cap,d] last-layer descriptors (ref_descriptors), or NULL. */
+ * ref0/ref1: optional ref_descriptors, or NULL.  ref_layers 0/1: [B,cap,d], the last layer
+ * (eval, lightglue.py:626-629); ref_layers == n_layers: [B,n_layers,cap,d], every layer
+ * (what the reference stacks when self.training, lightglue.py:626-629,709-710). */
 int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0, const float* kpts1,
                    const float* desc1, const int32_t* m, int cap1, int B, float h0, float w0, float h1, float w1, void* ws,
                    int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, float* ref0, float* ref1,
-                   void* stream);
+                   int ref_layers, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Event representation (the step before the path)

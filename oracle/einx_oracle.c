@@ -423,6 +423,17 @@ EXPORT void orc_normalize_map(const float* raw, int B, int D, int P, float scale
     }
 }
 
+/* F.normalize(x, dim=1) * scale on a row-major [R,C] matrix: the random padding descriptors of
+ * the un-frozen Matcher branch (core/modules/Matchers.py:114-131); reduction order as the sparse
+ * descriptor kernels (lane_butterfly_sumsq). */
+EXPORT void orc_normalize_rows(const float* x, int R, int C, float scale, float* out) {
+  for (int r = 0; r < R; ++r) {
+    const float* v = x + (size_t)r * C;
+    const float den = fmaxf(sqrtf(lane_butterfly_sumsq(v, C, 1)), 1e-12f);
+    for (int c = 0; c < C; ++c) out[(size_t)r * C + c] = scale * (v[c] / den);
+  }
+}
+
 /* upsample_descriptors (descriptor_util.py:131-138): bilinear resize (align_corners=False,
  * no antialias: src = max((dst+0.5)*in/out-0.5, 0), upper neighbour clamped) + normalize.
  * raw: [B,D,hc,wc] -> out: [B,D,Ho,Wo].  Interpolation as ATen upsample_bilinear2d:

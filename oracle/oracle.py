@@ -389,6 +389,84 @@ def matched_kpts(kpts0, kpts1, matches0, cols):
     return kpts0[sel][:, :cols], kpts1[matches0[sel]][:, :cols]
 
 
+# ------------------------------------------------------------------------------ un-frozen Matcher branch
+def normalize_rows(x, scale):
+    x = _c(x)
+    out = np.empty_like(x)
+    if x.shape[0]:
+        lib().orc_normalize_rows(_f(x), x.shape[0], x.shape[1], ctypes.c_float(scale), _f(out))
+    return out
+
+
+def normalize_keypoints(kpts, size):
+    """lightglue.py:137-148: (kpt - size/2) / (max(size)/2), first two columns."""
+    k = _c(kpts)[..., :2]
+    sh = np.array([np.float32(size[0]) / np.float32(2), np.float32(size[1]) / np.float32(2)], np.float32)
+    sc = np.float32(max(size[0], size[1])) / np.float32(2)
+    return ((k - sh) / sc).astype(np.float32)
+
+
+def pad_positions(pos, length, u, image_size, mode="random"):
+    """Matcher.pad_sparse_positions_to_length (Matchers.py:67-98).  u: the [length-n,2] uniform draws
+    the reference takes from torch.rand; padding rows = (u0*size0, u1*size1, 0)."""
+    pos = _c(pos)
+    n = pos.shape[0]
+    if n > length:
+        return pos[:length]
+    if n == length:
+        return pos
+    r = length - n
+    if mode == "zeros":
+        pad = np.zeros((r, 3), np.float32)
+    else:
+        u = _c(u)
+        pad = np.concatenate([u * np.array([image_size[0], image_size[1]], np.float32), np.zeros((r, 1), np.float32)], 1)
+    return np.concatenate([pos, pad.astype(np.float32)], 0)
+
+
+def pad_descriptors(desc, length, g, scale, mode="random"):
+    """Matcher.pad_sparse_descriptors_to_length (Matchers.py:100-131).  g: the [length-n,C] normal
+    draws (torch.randn); padding rows = F.normalize(g) * scale."""
+    desc = _c(desc)
+    n = desc.shape[0]
+    if n > length:
+        return desc[:length]
+    if n == length:
+        return desc
+    pad = np.zeros((length - n, desc.shape[1]), np.float32) if mode == "zeros" else normalize_rows(g, scale)
+    return np.concatenate([desc, pad], 0)
+
+
+def mnn_stacked(kpts0, desc0, kpts1, desc1):
+    """NearestNeighborMatcher.forward on stacked [B,n,*] inputs with B > 1 (MNN.py:88-140)."""
+    B = desc0.shape[0]
+    rs = [mnn(desc0[b], desc1[b], want_la=True, want_sim=True) for b in range(B)]
+    out = {k: np.stack([r[k] for r in rs]) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1",
+                                                    "log_assignment", "similarity")}
+    mk = [matched_kpts(kpts0[b], kpts1[b], rs[b]["matches0"], 3) for b in range(B)]
+    out["matched_kpts0"] = [a for a, _ in mk]
+    out["matched_kpts1"] = [b_ for _, b_ in mk]
+    return out
+
+
+def lightglue_stacked(sd, kpts0, desc0, kpts1, desc1, size0, size1, n_layers=9, training=True, prefix=""):
+    """LightGlue.forward on stacked inputs with B > 1 (lightglue.py:522-716): matched keypoints in
+    normalised coordinates (:677-687); ref_descriptors of every layer when training (:626-629)."""
+    B = desc0.shape[0]
+    cap = tuple(range(n_layers)) if training else (n_layers - 1,)
+    rs = [lightglue(sd, kpts0[b], desc0[b], kpts1[b], desc1[b], size0=size0, size1=size1, n_layers=n_layers, prefix=prefix,
+                    capture_layers=cap) for b in range(B)]
+    out = {k: np.stack([r[k] for r in rs]) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment")}
+    out["ref_descriptors0"] = np.stack([np.stack([r["layers"][i][0] for i in cap]) for r in rs])
+    out["ref_descriptors1"] = np.stack([np.stack([r["layers"][i][1] for i in cap]) for r in rs])
+    mk = [matched_kpts(normalize_keypoints(kpts0[b], size0), normalize_keypoints(kpts1[b], size1), rs[b]["matches0"], 2) for b in range(B)]
+    out["matched_kpts0"] = [a for a, _ in mk]
+    out["matched_kpts1"] = [b_ for _, b_ in mk]
+    out["prune0"] = np.full(out["matching_scores0"].shape, n_layers, np.float32)
+    out["prune1"] = np.full(out["matching_scores1"].shape, n_layers, np.float32)
+    return out
+
+
 # ------------------------------------------------------------------------------ event representation
 def voxel_grid(events, input_size, normalize=True):
     """events_to_voxel_grid (datasets/representations.py:67-124); events: dict of numpy arrays."""

@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: post desc mnn conv lg e2e
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -573,7 +573,88 @@ def gen_metrics():
     save("metrics.npz", **out)
 
 
-GROUPS = {"metrics": gen_metrics, "events": gen_events, "post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
+# =========================================================================================
+# train: forward pass of the un-frozen Matcher branch (Matchers.py:67-149,204-222): random padding
+# to max_points_num, stacking, ONE batched matcher call (MNN b>1 / LightGlue b>1 in training mode)
+# =========================================================================================
+TRAIN_CASES = [
+    dict(name="mnn", matcher="MNN", seed=81, counts0=[70, 96, 120], counts1=[96, 60, 101], L=96, D=256, tseed=1234, wseed=None),
+    dict(name="lg", matcher="LightGlue", seed=82, counts0=[80, 96, 110], counts1=[90, 50, 96], L=96, D=256, tseed=4321, wseed=8),
+]
+
+
+def train_inputs(c):
+    """per-sample ragged features: lists of [n_i,3] positions (y,x,score) and [n_i,D] descriptors"""
+    f = []
+    for side, counts in ((0, c["counts0"]), (1, c["counts1"])):
+        pos, desc = [], []
+        for i, n in enumerate(counts):
+            sd = c["seed"] * 100 + side * 10 + i
+            mc = dict(seed=sd, n=n, m=n, D=c["D"], scale=1.0, shared=0)
+            d0, _, k0, _ = mnn_inputs(mc)
+            k0[:, 1] = k0[:, 1] * np.float32(346.0 / 260.0)
+            pos.append(k0)
+            desc.append(d0)
+        f.append((pos, desc))
+    # make side 1 share structure with side 0 so that real matches exist: first rows are noisy copies
+    (p0, d0), (p1, d1) = f
+    for i in range(len(d0)):
+        s = min(len(d0[i]), len(d1[i])) // 2
+        mix = d0[i][:s] + np.float32(0.3) * d1[i][:s]
+        mix = mix / np.sqrt((mix.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(np.float32)
+        d1[i][:s] = mix.astype(np.float32)
+    return p0, d0, p1, d1
+
+
+def gen_train():
+    from core.modules.Matchers import Matcher as RefMatcher
+    out = {"meta": meta(cases=TRAIN_CASES)}
+    for c in TRAIN_CASES:
+        cfg = model_cfg(matcher=c["matcher"])
+        cfg["matcher"]["freeze"] = False
+        cfg["matcher"]["max_points_num"] = c["L"]
+        mm = RefMatcher(_ref_stubs.to_attr(cfg), logger=None, device="cpu")
+        keys = {}
+        if c["wseed"] is not None:
+            keys = load_synth_weights(mm.matcher, c["wseed"])
+        assert mm.matcher.training
+        p0, d0, p1, d1 = train_inputs(c)
+        size = torch.tensor([260, 346])
+        B = len(p0)
+        f0 = {"sparse_positions": [torch.from_numpy(a) for a in p0], "sparse_descriptors": [torch.from_numpy(a) for a in d0],
+              "image_size": [size] * B}
+        f1 = {"sparse_positions": [torch.from_numpy(a) for a in p1], "sparse_descriptors": [torch.from_numpy(a) for a in d1],
+              "image_size": [size] * B}
+        torch.manual_seed(c["tseed"])
+        with torch.no_grad():
+            r = mm(f0, f1)
+        n = c["name"]
+        out[f"{n}.in_pos0"] = r["input_feats0"]["sparse_positions"].numpy()
+        out[f"{n}.in_desc0"] = r["input_feats0"]["sparse_descriptors"].numpy()
+        out[f"{n}.in_pos1"] = r["input_feats1"]["sparse_positions"].numpy()
+        out[f"{n}.in_desc1"] = r["input_feats1"]["sparse_descriptors"].numpy()
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment"):
+            out[f"{n}.{k}"] = r[k].numpy()
+        for b in range(B):
+            out[f"{n}.matched_kpts0.{b}"] = r["matched_kpts0"][b].numpy()
+            out[f"{n}.matched_kpts1.{b}"] = r["matched_kpts1"][b].numpy()
+        if "similarity" in r:
+            out[f"{n}.similarity"] = r["similarity"].numpy()
+        if "ref_descriptors0" in r:
+            out[f"{n}.ref_shape"] = np.array(r["ref_descriptors0"].shape)
+            out[f"{n}.ref0_probe"] = r["ref_descriptors0"][:, :, ::8, ::16].numpy()
+            out[f"{n}.ref1_probe"] = r["ref_descriptors1"][:, :, ::8, ::16].numpy()
+            out[f"{n}.prune0"] = r["prune0"].numpy()
+        out[f"{n}.state_keys"] = np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)
+        sc = r["log_assignment"][:, :-1, :-1]
+        t2 = sc.topk(2, dim=2).values
+        out[f"{n}.row_gap_min"] = np.array([float((t2[..., 0] - t2[..., 1]).min())])
+        print(n, [int((r["matches0"][b] > -1).sum()) for b in range(B)], "matches; min row gap", out[f"{n}.row_gap_min"],
+              "keys", sorted(r.keys()))
+    save("train.npz", **out)
+
+
+GROUPS = {"train": gen_train, "metrics": gen_metrics, "events": gen_events, "post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

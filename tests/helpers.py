@@ -98,6 +98,27 @@ def lg_inputs(c):
     return d0, d1, k0, k1
 
 
+def train_inputs(c):
+    """Same recipe as tests/golden/gen_golden.py::train_inputs: ragged per-sample features."""
+    f = []
+    for side, counts in ((0, c["counts0"]), (1, c["counts1"])):
+        pos, desc = [], []
+        for i, n in enumerate(counts):
+            sd = c["seed"] * 100 + side * 10 + i
+            d0, _, k0, _ = mnn_inputs(dict(seed=sd, n=n, m=n, D=c["D"], scale=1.0, shared=0))
+            k0[:, 1] = k0[:, 1] * np.float32(346.0 / 260.0)
+            pos.append(k0)
+            desc.append(d0)
+        f.append((pos, desc))
+    (p0, d0), (p1, d1) = f
+    for i in range(len(d0)):
+        s = min(len(d0[i]), len(d1[i])) // 2
+        mix = d0[i][:s] + np.float32(0.3) * d1[i][:s]
+        mix = mix / np.sqrt((mix.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(np.float32)
+        d1[i][:s] = mix.astype(np.float32)
+    return p0, d0, p1, d1
+
+
 def split(flat, counts):
     out, o = [], 0
     for c in counts:

@@ -716,3 +716,174 @@ def test_ragged_keypoint_counts_in_a_batch(oracle, matcher):
         mk0, mk1 = oracle.matched_kpts(k0, k1, r["matches0"], cols)
         assert np.array_equal(_np(m["matched_kpts0"][b]), mk0) and np.array_equal(_np(m["matched_kpts1"][b]), mk1)
         assert tuple(m["matches0"][b].shape) == (1, len(k0)) and tuple(m["log_assignment"][b].shape) == (1, len(k0) + 1, len(k1) + 1)
+
+
+# ------------------------------------------------------------------ un-frozen Matcher branch
+TRAIN = Golden("train")
+
+
+def _unfrozen_matcher(name, L):
+    import json
+    c = dict(TRAIN.cases[name])
+    cfg = pkg.default_config("SP_MNN" if c["matcher"] == "MNN" else "SP_LG", event_channels=5)
+    cfg.matcher.freeze = False
+    cfg.matcher.max_points_num = L
+    mm = pkg.Matcher(cfg, device=DEV)
+    sd = None
+    if c["wseed"] is not None:
+        c["state_keys"] = json.loads(bytes(TRAIN[f"{name}.state_keys"]).decode())
+        sd = state_dict_for(c)
+        mm.matcher.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert mm.matcher.training  # Matchers.py:47-48: an un-frozen matcher is put in train mode
+    return mm, sd
+
+
+@pytest.mark.parametrize("name", list(TRAIN.cases))
+def test_unfrozen_matcher_vs_reference_golden(name):
+    """the reference's padded + stacked inputs (fixture) through the native batched call: whole-batch
+    tensors, per-pair matched keypoints, similarity (MNN) / all-layer ref_descriptors (LightGlue)."""
+    c = TRAIN.cases[name]
+    mm, _ = _unfrozen_matcher(name, c["L"])
+    P0, D0, P1, D1 = (TRAIN[f"{name}.in_{k}"] for k in ("pos0", "desc0", "pos1", "desc1"))
+    B = P0.shape[0]
+    size = torch.tensor([260, 346])
+    f0 = {"sparse_positions": [_t(P0[b]) for b in range(B)], "sparse_descriptors": [_t(D0[b]) for b in range(B)], "image_size": [size] * B}
+    f1 = {"sparse_positions": [_t(P1[b]) for b in range(B)], "sparse_descriptors": [_t(D1[b]) for b in range(B)], "image_size": [size] * B}
+    r = mm(f0, f1)
+    assert r["input_feats0"] is f0 and tuple(f0["sparse_positions"].shape) == (B, c["L"], 3)  # stacked in place, like the reference
+    assert np.array_equal(_np(r["matches0"]), TRAIN[f"{name}.matches0"]) and r["matches0"].dtype == torch.int64
+    assert np.array_equal(_np(r["matches1"]), TRAIN[f"{name}.matches1"])
+    np.testing.assert_allclose(_np(r["matching_scores0"]), TRAIN[f"{name}.matching_scores0"], atol=FTOL)
+    np.testing.assert_allclose(_np(r["matching_scores1"]), TRAIN[f"{name}.matching_scores1"], atol=FTOL)
+    np.testing.assert_allclose(_np(r["log_assignment"]), TRAIN[f"{name}.log_assignment"], atol=2e-4, rtol=1e-4)
+    for b in range(B):
+        np.testing.assert_allclose(_np(r["matched_kpts0"][b]), TRAIN[f"{name}.matched_kpts0.{b}"], atol=1e-6)
+        np.testing.assert_allclose(_np(r["matched_kpts1"][b]), TRAIN[f"{name}.matched_kpts1.{b}"], atol=1e-6)
+    if name == "mnn":
+        np.testing.assert_allclose(_np(r["similarity"]), TRAIN[f"{name}.similarity"], atol=1e-6)
+        assert "ref_descriptors0" not in r
+    else:
+        assert tuple(r["ref_descriptors0"].shape) == tuple(TRAIN[f"{name}.ref_shape"])  # [B, 9, L, 256]
+        np.testing.assert_allclose(_np(r["ref_descriptors0"])[:, :, ::8, ::16], TRAIN[f"{name}.ref0_probe"], atol=FTOL, rtol=FTOL)
+        np.testing.assert_allclose(_np(r["ref_descriptors1"])[:, :, ::8, ::16], TRAIN[f"{name}.ref1_probe"], atol=FTOL, rtol=FTOL)
+        assert np.array_equal(_np(r["prune0"]), TRAIN[f"{name}.prune0"])
+        # eval mode keeps only the last layer: [B,1,L,256], equal to the last slice of the training output
+        mm.matcher.eval()
+        f0e = {"sparse_positions": _t(P0), "sparse_descriptors": _t(D0), "image_size": [size] * B}
+        f1e = {"sparse_positions": _t(P1), "sparse_descriptors": _t(D1), "image_size": [size] * B}
+        re = mm.matcher(f0e, f1e)
+        assert tuple(re["ref_descriptors0"].shape) == (B, 1, c["L"], 256)
+        assert torch.equal(re["ref_descriptors0"][:, 0], r["ref_descriptors0"][:, -1])
+        assert torch.equal(re["matches0"], r["matches0"])
+
+
+@pytest.mark.parametrize("name", list(TRAIN.cases))
+def test_unfrozen_matcher_random_padding(oracle, name):
+    """ragged samples -> random padding to max_points_num.  The draws come from torch's generators
+    (device generator for the positions, CPU generator for the descriptors) in the reference's call
+    order, so re-seeding and re-drawing in the test predicts them; everything after the draws is
+    checked bit for bit against the oracle."""
+    from helpers import train_inputs
+    c = TRAIN.cases[name]
+    L = c["L"]
+    mm, sd = _unfrozen_matcher(name, L)
+    p0, d0, p1, d1 = train_inputs(c)
+    B = len(p0)
+    size = torch.tensor([260, 346], device=DEV)
+    f0 = {"sparse_positions": [_t(a) for a in p0], "sparse_descriptors": [_t(a) for a in d0], "image_size": [size] * B}
+    f1 = {"sparse_positions": [_t(a) for a in p1], "sparse_descriptors": [_t(a) for a in d1], "image_size": [size] * B}
+    torch.manual_seed(c["tseed"])
+    r = mm(f0, f1)
+    torch.manual_seed(c["tseed"])
+    exp = []
+    for pos, desc in ((p0, d0), (p1, d1)):
+        P, Dd = [], []
+        for i in range(B):
+            k = L - len(pos[i])
+            u = torch.rand(k, 2, device=DEV).cpu().numpy() if k > 0 else None
+            g = torch.randn(k, c["D"]).numpy() if k > 0 else None
+            P.append(oracle.pad_positions(pos[i], L, u, (260, 346)))
+            Dd.append(oracle.pad_descriptors(desc[i], L, g, 1.0))
+        exp.append((np.stack(P), np.stack(Dd)))
+    (P0, D0), (P1, D1) = exp
+    assert np.array_equal(_np(r["input_feats0"]["sparse_positions"]), P0)
+    assert np.array_equal(_np(r["input_feats1"]["sparse_positions"]), P1)
+    assert np.array_equal(_np(r["input_feats0"]["sparse_descriptors"]), D0)
+    assert np.array_equal(_np(r["input_feats1"]["sparse_descriptors"]), D1)
+    pad = P0[0, c["counts0"][0]:]
+    assert pad.shape[0] > 0 and np.all(pad[:, 2] == 0) and np.all(pad[:, 0] < 260) and np.all(pad[:, 1] < 346) and np.all(pad[:, :2] >= 0)
+    if name == "mnn":
+        o = oracle.mnn_stacked(P0, D0, P1, D1)
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "similarity"):
+            assert np.array_equal(_np(r[k]), o[k]), k
+        np.testing.assert_allclose(_np(r["log_assignment"]), o["log_assignment"], atol=1e-5)
+        for b in range(B):
+            assert np.array_equal(_np(r["matched_kpts0"][b]), o["matched_kpts0"][b])
+            assert np.array_equal(_np(r["matched_kpts1"][b]), o["matched_kpts1"][b])
+    else:
+        o = oracle.lightglue_stacked(sd, P0, D0, P1, D1, (260, 346), (260, 346), training=True)
+        assert np.array_equal(_np(r["matches0"]), o["matches0"]) and np.array_equal(_np(r["matches1"]), o["matches1"])
+        np.testing.assert_allclose(_np(r["matching_scores0"]), o["matching_scores0"], atol=FTOL)
+        np.testing.assert_allclose(_np(r["log_assignment"]), o["log_assignment"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(_np(r["ref_descriptors0"]), o["ref_descriptors0"], atol=FTOL, rtol=FTOL)
+        np.testing.assert_allclose(_np(r["ref_descriptors1"]), o["ref_descriptors1"], atol=FTOL, rtol=FTOL)
+        for b in range(B):
+            assert np.array_equal(_np(r["matched_kpts0"][b]), o["matched_kpts0"][b])  # normalised coordinates
+            assert np.array_equal(_np(r["matched_kpts1"][b]), o["matched_kpts1"][b])
+
+
+def test_unfrozen_matcher_inside_eim_and_zero_pad_mode(oracle):
+    """EIM.forward with matcher.freeze: false (EIM.py:92-95): extractor dicts are padded/stacked in
+    place and handed to one batched matcher call; pad_mode 'zeros' is deterministic."""
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 100
+    cfg.matcher.freeze = False
+    cfg.matcher.max_points_num = 128
+    cfg.matcher.pad_mode = "zeros"
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sdn = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=41)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    B, H, W = 2, 120, 152
+    ev, mask = synth.synth_events(62, B, 5, H, W)
+    img = synth.synth_image(62, B, H, W)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    assert m["input_feats0"] is ef and m["input_feats1"] is imf
+    assert tuple(ef["sparse_positions"].shape) == (B, 128, 3) and tuple(imf["sparse_descriptors"].shape) == (B, 128, 256)
+    oe = oracle.extractor_forward("vgg", sub_dict(sdn, "event_extractor.extractor."), ev.copy(), mask, top_k=100)
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sdn, "image_extractor.extractor."), img.copy(), None, top_k=100)
+    P0 = np.stack([oracle.pad_positions(p, 128, None, (H, W), mode="zeros") for p in oe["sparse_positions"]])
+    D0 = np.stack([oracle.pad_descriptors(d, 128, None, 1.0, mode="zeros") for d in oe["sparse_descriptors"]])
+    P1 = np.stack([oracle.pad_positions(p, 128, None, (H, W), mode="zeros") for p in oi["sparse_positions"]])
+    D1 = np.stack([oracle.pad_descriptors(d, 128, None, 1.0, mode="zeros") for d in oi["sparse_descriptors"]])
+    assert np.array_equal(_np(ef["sparse_positions"]), P0) and np.array_equal(_np(ef["sparse_descriptors"]), D0)
+    assert np.array_equal(_np(imf["sparse_positions"]), P1) and np.array_equal(_np(imf["sparse_descriptors"]), D1)
+    o = oracle.mnn_stacked(P0, D0, P1, D1)
+    assert tuple(m["matches0"].shape) == (B, 128) and tuple(m["similarity"].shape) == (B, 128, 128)
+    # the all-zero padding rows tie everywhere (similarity 0): the first index wins on both sides
+    for k in ("matches0", "matches1", "matching_scores0", "similarity"):
+        assert np.array_equal(_np(m[k]), o[k]), k
+
+
+def test_unfrozen_helpers_bit_exact(oracle):
+    N = pkg.native
+    x = synth.uniform(91, (37, 128), -1, 1)
+    x[5] = 0  # zero row -> eps clamp
+    assert np.array_equal(_np(N.normalize_rows(_t(x), 1.41)), oracle.normalize_rows(x, 1.41))
+    k = np.concatenate([synth.uniform(92, (3, 50, 2), 0, 260), synth.uniform01(93, (3, 50, 1))], -1).astype(np.float32)
+    got = _np(N.normalize_keypoints(_t(k), (260, 346)))
+    assert got.shape == (3, 50, 2) and np.array_equal(got, oracle.normalize_keypoints(k, (260, 346)))
+    got3 = _np(N.normalize_keypoints(_t(k), (260, 346), out_cols=3))
+    assert np.array_equal(got3[..., :2], got) and np.all(got3[..., 2] == 0)
+    u = synth.uniform01(94, (11, 2))
+    assert np.array_equal(_np(N.random_positions(_t(u), (260, 346))), oracle.pad_positions(np.zeros((0, 3), np.float32), 11, u, (260, 346)))
+    d0 = synth.synth_unit_descriptors(95, 70, 256, 1.0)
+    d1 = synth.synth_unit_descriptors(96, 200, 256, 1.0)
+    n = torch.tensor([70, 50], dtype=torch.int32, device=DEV)
+    m = torch.tensor([200, 130], dtype=torch.int32, device=DEV)
+    sim = _np(N.similarity(_t(np.stack([d0, d0])), n, _t(np.stack([d1, d1])), m))
+    exp = oracle.mnn(d0, d1, want_la=False, want_sim=True)["similarity"]
+    assert np.array_equal(sim[0], exp)
+    assert np.array_equal(sim[1, :50, :130], exp[:50, :130]) and np.all(sim[1, 50:] == 0) and np.all(sim[1, :, 130:] == 0)

@@ -4,7 +4,7 @@ of BASELINE.json's north_star) where conv/GEMM accumulation order legitimately d
 import numpy as np
 import pytest
 
-from helpers import Golden, lg_inputs, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth
+from helpers import Golden, lg_inputs, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth, train_inputs
 
 FTOL = 1e-4
 
@@ -196,6 +196,77 @@ def test_lightglue(oracle, name):
     mk0, mk1 = oracle.matched_kpts(k0, k1, r["matches0"], 2)
     assert np.array_equal(mk0, LG[f"{name}.matched_kpts0"])
     assert np.array_equal(mk1, LG[f"{name}.matched_kpts1"])
+
+
+# ------------------------------------------------------------------ un-frozen Matcher branch
+TRAIN = Golden("train")
+
+
+def _train_padded_by_oracle(oracle, c):
+    """Re-create the reference's padded + stacked matcher inputs: same torch CPU generator, same
+    seed, same draw order (per sample: rand(r,2) for the positions, then randn(r,C))."""
+    import torch
+    p0, d0, p1, d1 = train_inputs(c)
+    L = c["L"]
+    torch.manual_seed(c["tseed"])
+    sides = []
+    for pos, desc in ((p0, d0), (p1, d1)):
+        P, Dd = [], []
+        for i in range(len(pos)):
+            r = L - len(pos[i])
+            u = torch.rand(r, 2).numpy() if r > 0 else None
+            P.append(oracle.pad_positions(pos[i], L, u, (260, 346)))
+            g = torch.randn(r, c["D"]).numpy() if r > 0 else None
+            Dd.append(oracle.pad_descriptors(desc[i], L, g, 1.0))
+        sides.append((np.stack(P), np.stack(Dd)))
+    return sides
+
+
+@pytest.mark.parametrize("name", list(TRAIN.cases))
+def test_unfrozen_matcher_padding(oracle, name):
+    c = TRAIN.cases[name]
+    if TRAIN.meta["torch"] != __import__("torch").__version__:
+        pytest.skip("fixture drawn with another torch version: the generator stream is not comparable")
+    (P0, D0), (P1, D1) = _train_padded_by_oracle(oracle, c)
+    assert np.array_equal(P0, TRAIN[f"{name}.in_pos0"]) and np.array_equal(P1, TRAIN[f"{name}.in_pos1"])
+    np.testing.assert_allclose(D0, TRAIN[f"{name}.in_desc0"], atol=1e-6)
+    np.testing.assert_allclose(D1, TRAIN[f"{name}.in_desc1"], atol=1e-6)
+    # truncation (n > L) keeps the first L rows, shorter samples keep their rows and get score-0 padding
+    for i, n in enumerate(c["counts0"]):
+        assert np.all(P0[i, min(n, c["L"]):, 2] == 0)
+
+
+def test_unfrozen_matcher_mnn(oracle):
+    name = "mnn"
+    P0, D0, P1, D1 = (TRAIN[f"{name}.in_{k}"] for k in ("pos0", "desc0", "pos1", "desc1"))
+    r = oracle.mnn_stacked(P0, D0, P1, D1)
+    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        assert np.array_equal(r[k], TRAIN[f"{name}.{k}"]), k
+    np.testing.assert_allclose(r["log_assignment"], TRAIN[f"{name}.log_assignment"], atol=1e-5)
+    np.testing.assert_allclose(r["similarity"], TRAIN[f"{name}.similarity"], atol=1e-6)
+    for b in range(P0.shape[0]):
+        assert np.array_equal(r["matched_kpts0"][b], TRAIN[f"{name}.matched_kpts0.{b}"])
+        assert np.array_equal(r["matched_kpts1"][b], TRAIN[f"{name}.matched_kpts1.{b}"])
+
+
+def test_unfrozen_matcher_lightglue(oracle):
+    import json
+    name = "lg"
+    c = dict(TRAIN.cases[name])
+    c["state_keys"] = json.loads(bytes(TRAIN[f"{name}.state_keys"]).decode())
+    sd = state_dict_for(c)
+    P0, D0, P1, D1 = (TRAIN[f"{name}.in_{k}"] for k in ("pos0", "desc0", "pos1", "desc1"))
+    r = oracle.lightglue_stacked(sd, P0, D0, P1, D1, (260, 346), (260, 346), training=True)
+    assert np.array_equal(r["matches0"], TRAIN[f"{name}.matches0"]) and np.array_equal(r["matches1"], TRAIN[f"{name}.matches1"])
+    np.testing.assert_allclose(r["matching_scores0"], TRAIN[f"{name}.matching_scores0"], atol=FTOL)
+    np.testing.assert_allclose(r["log_assignment"], TRAIN[f"{name}.log_assignment"], atol=2e-4, rtol=1e-4)
+    assert tuple(r["ref_descriptors0"].shape) == tuple(TRAIN[f"{name}.ref_shape"])  # [B, n_layers, L, 256]
+    np.testing.assert_allclose(r["ref_descriptors0"][:, :, ::8, ::16], TRAIN[f"{name}.ref0_probe"], atol=FTOL, rtol=FTOL)
+    np.testing.assert_allclose(r["ref_descriptors1"][:, :, ::8, ::16], TRAIN[f"{name}.ref1_probe"], atol=FTOL, rtol=FTOL)
+    assert np.array_equal(r["prune0"], TRAIN[f"{name}.prune0"])
+    for b in range(P0.shape[0]):  # normalised coordinates (b > 1 quirk)
+        np.testing.assert_allclose(r["matched_kpts0"][b], TRAIN[f"{name}.matched_kpts0.{b}"], atol=1e-6)
+        np.testing.assert_allclose(r["matched_kpts1"][b], TRAIN[f"{name}.matched_kpts1.{b}"], atol=1e-6)
 
 
 # ------------------------------------------------------------------ end to end (full size 346x260)
