@@ -1,7 +1,7 @@
 // gemm_tile.h -- 128x128x32 fp32-MFMA "NT" tile engine shared by the matcher kernels.
 //   C[i][j] = sum_k A[i][k] * B[j][k]       (A: [M,K] row-major, B: [N,K] row-major)
-// 256 threads = 4 waves arranged 2(M) x 2(N); each wave owns a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x2_f32 accumulators.  K is consumed strictly ascending through one
+// WAVES waves arranged (WAVES/2)(M) x 2(N); each wave owns a (128/(WAVES/2)) x 64 sub-tile of
+// v_mfma_f32_32x32x2_f32 accumulators (8 waves: 32x64 = 1x2 tiles, 4 waves: 64x64 = 2x2).  K is consumed strictly ascending through one
 // accumulator chain per output, i.e. every C[i][j] is the k-ordered fmaf chain from +0 that
 // oracle/einx_oracle.c computes (orc_mnn / orc_linear).  Operand tiles are staged through LDS
 // with an odd row pitch (33) so the per-lane row-strided ds_read_b32 fragments are
@@ -11,12 +11,25 @@
 
 namespace einx_gemm {
 
-constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 1;
+#ifndef EINX_GEMM_WAVES
+#define EINX_GEMM_WAVES 8
+#endif
+#ifndef EINX_GEMM_BK
+#define EINX_GEMM_BK 32
+#endif
+constexpr int BM = 128, BN = 128, BK = EINX_GEMM_BK, PITCH = BK + 1;
 constexpr int LDS_FLOATS = (BM + BN) * PITCH;
-constexpr int THREADS = 256;
+constexpr int WAVES = EINX_GEMM_WAVES;   // waves are arranged (WAVES/2) along M x 2 along N
+constexpr int THREADS = WAVES * 64;
+constexpr int MT = BM / ((WAVES / 2) * 32);  // 32x32 MFMA tiles per wave along M (4 waves: 2, 8 waves: 1)
+constexpr int NT = 2;                        // ... along N (a wave always spans 64 columns)
+constexpr int WROWS = MT * 32;               // rows a wave owns
+constexpr int C4 = BK / 4;                   // float4 per operand row per K-slab
+constexpr int STAGE = 128 * C4 / THREADS;    // float4 per thread per operand per K-slab
+static_assert(WAVES == 4 || WAVES == 8, "tile engine is written for 4 or 8 waves");
 
 struct Frag {
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 };
 
 // A rows [i0, i0+128) valid while < Mvalid; B rows [j0, j0+128) valid while < Nvalid.
@@ -34,19 +47,19 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) f.acc[mt][nt][r] = 0.0f;
 
-  // staging: 128 rows x 8 float4 per operand = 1024 float4 -> 4 per thread per operand
-  f32x4 ra[4], rb[4];
+  // staging: 128 rows x 8 float4 per operand = 1024 float4 -> STAGE per thread per operand
+  f32x4 ra[STAGE], rb[STAGE];
   auto issue = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < STAGE; ++i) {
       const int fidx = tid + i * THREADS;
-      const int r = fidx >> 3, c4 = fidx & 7;
+      const int r = fidx / C4, c4 = fidx % C4;
       const int k = k0 + c4 * 4;
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       if (i0 + r < Mvalid && k < K)
@@ -59,9 +72,9 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < STAGE; ++i) {
       const int fidx = tid + i * THREADS;
-      const int r = fidx >> 3, c4 = fidx & 7;
+      const int r = fidx / C4, c4 = fidx % C4;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         As[r * PITCH + c4 * 4 + t] = ra[i][t];
@@ -69,7 +82,7 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
       }
     }
   };
-  const int aoff = (wm * 64 + l31) * PITCH + half;
+  const int aoff = (wm * WROWS + l31) * PITCH + half;
   const int boff = (wn * 64 + l31) * PITCH + half;
   issue(0);
   for (int k0 = 0; k0 < K; k0 += BK) {
@@ -78,12 +91,12 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
     __syncthreads();
     if (k0 + BK < K) issue(k0 + BK);
     // software-pipelined fragment reads: step kk+1's operands are requested before step kk's MFMAs
-    float av[2][2], bv[2][2];
+    float av[2][MT], bv[2][NT];
     auto load_frag = [&](int kk, int buf) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
+      for (int mt = 0; mt < MT; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
+      for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
     };
     load_frag(0, 0);
 #pragma unroll
@@ -91,9 +104,9 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
       if (kk + 1 < BK / 2) load_frag(kk + 1, (kk + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
           f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][mt], bv[kk & 1][nt], f.acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -104,7 +117,7 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
 // element coordinates inside the 128x128 tile for accumulator (mt, nt, r) of this lane
 __device__ __forceinline__ int row_of(int mt, int r) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  return (wave >> 1) * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  return (wave >> 1) * WROWS + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 __device__ __forceinline__ int col_of(int nt) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -81,20 +81,57 @@ __global__ __launch_bounds__(THREADS) void lg_gemm_kernel(const GemmArgs g) {
   const float* X2 = g.X2 ? g.X2 + (size_t)b * g.cap * g.ldx2 : nullptr;
   tile_nt(X, g.ldx, i0, n, g.W, g.K, j0, g.N, g.K, lds, f, X2, g.ldx2, g.Ksplit);
   float* Y = g.Y + (size_t)b * g.cap * g.ldy;
+  // epilogue: the bias of a lane's NT columns is loaded once; whole tiles take a guard-free path so
+  // that the residual loads / stores of all 16*MT rows are issued back to back instead of one
+  // load -> wait -> store round trip per element
+  float bj[NT];
+  int jj[NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int nt = 0; nt < NT; ++nt) {
+    const int j = j0 + col_of(nt);
+    jj[nt] = j < g.N ? j : -1;
+    bj[nt] = j < g.N ? g.bias[j] : 0.0f;
+  }
+  auto finish = [&](float acc, float bias, float old) {
+    float v = acc + bias;
+    if (EPI == EPI_DIV) v = v / g.div;
+    if (EPI == EPI_RESID) v = old + v;
+    return v;
+  };
+  if (i0 + BM <= n && j0 + BN <= g.N) {
+    float* yp[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yp[mt][r] = Y + (size_t)(i0 + row_of(mt, r)) * g.ldy + j0 + col_of(0);
+    float old[MT][16][NT];
+    if (EPI == EPI_RESID) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) old[mt][r][nt] = yp[mt][r][nt * 32];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) yp[mt][r][nt * 32] = finish(f.acc[mt][nt][r], bj[nt], EPI == EPI_RESID ? old[mt][r][nt] : 0.0f);
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = i0 + row_of(mt, r);
       if (i >= n) continue;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int j = j0 + col_of(nt);
-        if (j >= g.N) continue;
-        float v = f.acc[mt][nt][r] + g.bias[j];
-        if (EPI == EPI_DIV) v = v / g.div;
-        if (EPI == EPI_RESID) v = Y[(size_t)i * g.ldy + j] + v;
-        Y[(size_t)i * g.ldy + j] = v;
+      for (int nt = 0; nt < NT; ++nt) {
+        if (jj[nt] < 0) continue;
+        float* y = Y + (size_t)i * g.ldy + jj[nt];
+        *y = finish(f.acc[mt][nt][r], bj[nt], EPI == EPI_RESID ? *y : 0.0f);
       }
     }
 }
@@ -617,7 +654,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   a.cap1 = cap1;
   a.D = D;
   a.nc64 = einx_cdiv(cap1, 64);
-  a.nr64 = einx_cdiv(cap0, 64);
+  a.nr64 = einx_cdiv(cap0, WROWS);
   char* q = (char*)mnn_ws;
   a.rowkey = (unsigned long long*)q;
   q += al((size_t)B * cap0 * 8);

@@ -23,7 +23,7 @@ struct MnnArgs {
   unsigned long long* rowkey;  // [B,cap0]
   unsigned long long* colkey;  // [B,cap1]
   float* rowstat;              // [B,cap0,nc64,2]  (max, sumexp) per 64-column chunk
-  float* colstat;              // [B,cap1,nr64,2]
+  float* colstat;              // [B,cap1,nr64,2]  per WROWS-row chunk (nr64 = cdiv(cap0, WROWS))
   float* rowlse;               // [B,cap0,2] (max, log-sum-exp)
   float* collse;               // [B,cap1,2]
   float* la;                   // [B,cap0+1,cap1+1]
@@ -53,14 +53,14 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
 
   if (LG && MODE != 1) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = min(i0 + row_of(mt, r), n - 1);
         const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
         const float c0 = a.cert0[(size_t)b * a.cap0 + i];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const int j = min(j0 + col_of(nt), m - 1);
           const float cm = a.collse[((size_t)b * a.cap1 + j) * 2], cl = a.collse[((size_t)b * a.cap1 + j) * 2 + 1];
           const float sv = f.acc[mt][nt][r];
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
   if (MODE == 0) {
     // ---- column arg-max over this wave's 64 rows (ascending i, strict > keeps the first) ----
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
       const int j = j0 + col_of(nt);
       float bv = NEG;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = i0 + row_of(mt, r);
@@ -98,14 +98,14 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
     }
     // ---- row arg-max over this wave's 64 columns ---------------------------------------------
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + row_of(mt, r);
         float bv = NEG;
         int bj = 0x7fffffff;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const int j = j0 + col_of(nt);
           const float v = f.acc[mt][nt][r];
           if (j < m && (bj == 0x7fffffff || v > bv)) {
@@ -126,10 +126,10 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
       }
   } else if (MODE == 1) {
     const int wave = threadIdx.x >> 6;
-    const int cchunk = (j0 >> 6) + (wave & 1), rchunk = (i0 >> 6) + (wave >> 1);
+    const int cchunk = (j0 >> 6) + (wave & 1), rchunk = i0 / WROWS + (wave >> 1);
     // rows: (max, sum exp(v-max)) over this wave's 64 columns
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + row_of(mt, r);
@@ -151,23 +151,23 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
       }
     // columns: over this wave's 64 rows
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
       const int j = j0 + col_of(nt);
       float mx = NEG;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (i0 + row_of(mt, r) < n) mx = fmaxf(mx, f.acc[mt][nt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float s = 0.0f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (i0 + row_of(mt, r) < n) s += einx_expf(f.acc[mt][nt][r] - mx);
       s += __shfl_xor(s, 32, 64);
-      if (half == 0 && j < m && rchunk * 64 < n) {
+      if (half == 0 && j < m && rchunk * WROWS < n) {
         float* o = a.colstat + (((size_t)b * a.cap1 + j) * a.nr64 + rchunk) * 2;
         o[0] = mx;
         o[1] = s;
@@ -176,13 +176,13 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
   } else if (MODE == 3) {
     float* sim = a.la + (size_t)b * a.cap0 * a.cap1;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + row_of(mt, r);
         if (i >= n) continue;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const int j = j0 + col_of(nt);
           if (j < m) sim[(size_t)i * a.cap1 + j] = f.acc[mt][nt][r];
         }
@@ -191,14 +191,14 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
     const size_t pitch = (size_t)a.cap1 + 1;
     float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + row_of(mt, r);
         if (i >= n) continue;
         const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const int j = j0 + col_of(nt);
           if (j >= m) continue;
           const float cm = a.collse[((size_t)b * a.cap1 + j) * 2], cl = a.collse[((size_t)b * a.cap1 + j) * 2 + 1];
@@ -226,7 +226,7 @@ __global__ void mnn_lse_kernel(const MnnArgs a) {
     a.rowlse[((size_t)b * a.cap0 + t) * 2 + 1] = einx_logf(s);
   }
   if (t < m) {
-    const int chunks = (n + 63) / 64;
+    const int chunks = (n + WROWS - 1) / WROWS;
     const float* st = a.colstat + ((size_t)b * a.cap1 + t) * a.nr64 * 2;
     float mx = NEG;
     for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, st[2 * c]);

@@ -16,7 +16,7 @@ using namespace einx_gemm;
 
 EINX_EXPORT size_t einx_mnn_ws_bytes(int B, int cap0, int cap1) {
   if (B <= 0 || cap0 <= 0 || cap1 <= 0) return 0;
-  const size_t nc64 = (size_t)einx_cdiv(cap1, 64), nr64 = (size_t)einx_cdiv(cap0, 64);
+  const size_t nc64 = (size_t)einx_cdiv(cap1, 64), nr64 = (size_t)einx_cdiv(cap0, WROWS);
   size_t bytes = 0;
   bytes += align256((size_t)B * cap0 * 8) + align256((size_t)B * cap1 * 8);
   bytes += align256((size_t)B * cap0 * nc64 * 8) + align256((size_t)B * cap1 * nr64 * 8);
@@ -38,7 +38,7 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
   a.cap1 = cap1;
   a.D = D;
   a.nc64 = einx_cdiv(cap1, 64);
-  a.nr64 = einx_cdiv(cap0, 64);
+  a.nr64 = einx_cdiv(cap0, WROWS);
   char* p = (char*)ws;
   a.rowkey = (unsigned long long*)p;
   p += align256((size_t)B * cap0 * 8);
