@@ -30,4 +30,4 @@ void einx_set_error(const char* fmt, ...);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static inline int einx_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline __host__ __device__ int einx_cdiv(int a, int b) { return (a + b - 1) / b; }

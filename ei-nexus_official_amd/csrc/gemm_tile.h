@@ -32,14 +32,45 @@ struct Frag {
   f32x16 acc[MT][NT];
 };
 
-// A rows [i0, i0+128) valid while < Mvalid; B rows [j0, j0+128) valid while < Nvalid.
-// K must be a multiple of 4 (rows are 16-byte aligned); K tail beyond a multiple of 32 is
-// zero-filled.  lds: LDS_FLOATS floats.
-// Optional second A source: columns k >= Ksplit come from A2[i][k - Ksplit] (Ksplit % 32 == 0),
-// which evaluates cat([A, A2], -1) @ B^T without materialising the concatenation.
-__device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, int i0, int Mvalid, const float* __restrict__ B, int ldb,
-                                        int j0, int Nvalid, int K, float* lds, Frag& f, const float* __restrict__ A2 = nullptr,
-                                        int lda2 = 0, int Ksplit = 0x7fffffff) {
+// One tile's operands.  A rows [i0, i0+128) valid while < Mvalid; B rows [j0, j0+128) valid while
+// < Nvalid.  K must be a multiple of 4 (rows are 16-byte aligned); a K tail beyond a multiple of
+// BK is zero-filled.  Optional second A source: columns k >= Ksplit come from A2[i][k - Ksplit]
+// (Ksplit % BK == 0), which evaluates cat([A, A2], -1) @ B^T without materialising the concatenation.
+struct Src {
+  const float* A;
+  const float* A2;
+  const float* B;
+  int lda, lda2, ldb, i0, Mvalid, j0, Nvalid;
+};
+
+// register image of one K-slab of both operands (global -> registers -> LDS)
+struct Stage {
+  f32x4 ra[STAGE], rb[STAGE];
+};
+
+__device__ __forceinline__ void issue_slab(const Src& s, int k0, int K, int Ksplit, Stage& st) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < STAGE; ++i) {
+    const int fidx = tid + i * THREADS;
+    const int r = fidx / C4, c4 = fidx % C4;
+    const int k = k0 + c4 * 4;
+    f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+    if (s.i0 + r < s.Mvalid && k < K)
+      va = (k < Ksplit) ? *reinterpret_cast<const f32x4*>(s.A + (size_t)(s.i0 + r) * s.lda + k)
+                        : *reinterpret_cast<const f32x4*>(s.A2 + (size_t)(s.i0 + r) * s.lda2 + (k - Ksplit));
+    if (s.j0 + r < s.Nvalid && k < K) vb = *reinterpret_cast<const f32x4*>(s.B + (size_t)(s.j0 + r) * s.ldb + k);
+    st.ra[i] = va;
+    st.rb[i] = vb;
+  }
+}
+
+// Runs one tile.  Precondition: issue_slab(cur, 0, ...) has been called into `st`.  While the last
+// K-slab is on the matrix cores the first slab of `next` (if has_next) is requested into `st`, so a
+// persistent kernel's next tile starts without an exposed global-memory round trip and its loads
+// also fly under the caller's epilogue.  lds: LDS_FLOATS floats; no trailing barrier.
+__device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, float* lds, Frag& f, Stage& st, const Src& next,
+                                            bool has_next) {
   float* As = lds;
   float* Bs = lds + BM * PITCH;
   const int tid = threadIdx.x;
@@ -52,24 +83,6 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) f.acc[mt][nt][r] = 0.0f;
-
-  // staging: 128 rows x 8 float4 per operand = 1024 float4 -> STAGE per thread per operand
-  f32x4 ra[STAGE], rb[STAGE];
-  auto issue = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < STAGE; ++i) {
-      const int fidx = tid + i * THREADS;
-      const int r = fidx / C4, c4 = fidx % C4;
-      const int k = k0 + c4 * 4;
-      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-      if (i0 + r < Mvalid && k < K)
-        va = (k < Ksplit) ? *reinterpret_cast<const f32x4*>(A + (size_t)(i0 + r) * lda + k)
-                          : *reinterpret_cast<const f32x4*>(A2 + (size_t)(i0 + r) * lda2 + (k - Ksplit));
-      if (j0 + r < Nvalid && k < K) vb = *reinterpret_cast<const f32x4*>(B + (size_t)(j0 + r) * ldb + k);
-      ra[i] = va;
-      rb[i] = vb;
-    }
-  };
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < STAGE; ++i) {
@@ -77,19 +90,53 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
       const int r = fidx / C4, c4 = fidx % C4;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        As[r * PITCH + c4 * 4 + t] = ra[i][t];
-        Bs[r * PITCH + c4 * 4 + t] = rb[i][t];
+        As[r * PITCH + c4 * 4 + t] = st.ra[i][t];
+        Bs[r * PITCH + c4 * 4 + t] = st.rb[i][t];
       }
     }
   };
   const int aoff = (wm * WROWS + l31) * PITCH + half;
   const int boff = (wn * 64 + l31) * PITCH + half;
-  issue(0);
+  // Whole tiles (the common case) reload through a predicate-free path: a uniform base pointer that
+  // advances with k0 (scalar registers) plus a per-thread element offset that never changes, so a
+  // K-slab costs the loads themselves and no vector address arithmetic, compares or selects.
+  const bool whole = cur.i0 + BM <= cur.Mvalid && cur.j0 + BN <= cur.Nvalid && K % BK == 0 && (cur.A2 == nullptr || Ksplit % BK == 0);
+  unsigned offa[STAGE], offa2[STAGE], offb[STAGE];
+#pragma unroll
+  for (int i = 0; i < STAGE; ++i) {
+    const int fidx = tid + i * THREADS;
+    const int r = fidx / C4, c4 = fidx % C4;
+    offa[i] = (unsigned)(r * cur.lda + c4 * 4);
+    offa2[i] = (unsigned)(r * cur.lda2 + c4 * 4);
+    offb[i] = (unsigned)(r * cur.ldb + c4 * 4);
+  }
+  const float* a_tile = cur.A + (size_t)cur.i0 * cur.lda;
+  const float* a2_tile = cur.A2 ? cur.A2 + (size_t)cur.i0 * cur.lda2 : nullptr;
+  const float* b_tile = cur.B + (size_t)cur.j0 * cur.ldb;
+  auto issue_whole = [&](int k) {
+    const float* bk = b_tile + k;
+    if (k < Ksplit) {
+      const float* ak = a_tile + k;
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) st.ra[i] = *reinterpret_cast<const f32x4*>(ak + offa[i]);
+    } else {
+      const float* ak = a2_tile + (k - Ksplit);
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) st.ra[i] = *reinterpret_cast<const f32x4*>(ak + offa2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < STAGE; ++i) st.rb[i] = *reinterpret_cast<const f32x4*>(bk + offb[i]);
+  };
   for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
+    __syncthreads();  // the previous slab's (or tile's) fragment reads are done
     commit();
     __syncthreads();
-    if (k0 + BK < K) issue(k0 + BK);
+    if (k0 + BK < K) {  // in flight under the MFMAs below
+      if (whole) issue_whole(k0 + BK);
+      else issue_slab(cur, k0 + BK, K, Ksplit, st);
+    } else if (has_next) {
+      issue_slab(next, 0, K, Ksplit, st);
+    }
     // software-pipelined fragment reads: step kk+1's operands are requested before step kk's MFMAs
     float av[2][MT], bv[2][NT];
     auto load_frag = [&](int kk, int buf) {
@@ -111,9 +158,35 @@ __device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, in
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+
+// single-tile form used by the one-tile-per-workgroup kernels
+__device__ __forceinline__ void tile_nt(const float* __restrict__ A, int lda, int i0, int Mvalid, const float* __restrict__ B, int ldb,
+                                        int j0, int Nvalid, int K, float* lds, Frag& f, const float* __restrict__ A2 = nullptr,
+                                        int lda2 = 0, int Ksplit = 0x7fffffff) {
+  Src s;
+  s.A = A;
+  s.A2 = A2;
+  s.B = B;
+  s.lda = lda;
+  s.lda2 = lda2;
+  s.ldb = ldb;
+  s.i0 = i0;
+  s.Mvalid = Mvalid;
+  s.j0 = j0;
+  s.Nvalid = Nvalid;
+  Stage st;
+  issue_slab(s, 0, K, Ksplit, st);
+  tile_nt_run(s, K, Ksplit, lds, f, st, s, false);
   __syncthreads();  // LDS reusable by the caller's epilogue
 }
 
+// row_of(mt, r) = row_base() + row_step(mt, r): lane-dependent part + compile-time part
+__device__ __forceinline__ int row_base() {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return (wave >> 1) * WROWS + 4 * (lane >> 5);
+}
+__host__ __device__ constexpr int row_step(int mt, int r) { return mt * 32 + (r & 3) + 8 * (r >> 2); }
 // element coordinates inside the 128x128 tile for accumulator (mt, nt, r) of this lane
 __device__ __forceinline__ int row_of(int mt, int r) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

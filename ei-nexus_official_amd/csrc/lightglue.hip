@@ -65,75 +65,123 @@ struct GemmArgs {
   const float* bias;
   float* Y;
   const int32_t* cnt;  // per-batch row counts, or null: every batch has `cap` rows
-  int cap, ldx, ldx2, Ksplit, K, N, ldy;
+  int cap, ldx, ldx2, Ksplit, K, N, ldy, B;
   float div;
 };
 
+// Persistent workgroups: the launch holds as many workgroups as the chip runs at once (a multiple
+// of 8) and each walks a list of 128x128 tiles.  Workgroups w and w+8 share an XCD (round-robin
+// dispatch), so the tile list of XCD x is built from whole A-row groups: the tilesN tiles that read
+// the same 128 rows of X are computed on one XCD at about the same time and X is fetched into that
+// L2 once.  The next tile's first K-slab is requested during the current tile's last K-slab, so its
+// latency and the epilogue's stores overlap instead of serialising per tile.
 template <int EPI>
-__global__ __launch_bounds__(THREADS) void lg_gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(const GemmArgs g) {  // two workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  const int b = blockIdx.z;
-  const int n = g.cnt ? min(g.cnt[b], g.cap) : g.cap;
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-  if (i0 >= n) return;
-  Frag f;
-  const float* X = g.X + (size_t)b * g.cap * g.ldx;
-  const float* X2 = g.X2 ? g.X2 + (size_t)b * g.cap * g.ldx2 : nullptr;
-  tile_nt(X, g.ldx, i0, n, g.W, g.K, j0, g.N, g.K, lds, f, X2, g.ldx2, g.Ksplit);
-  float* Y = g.Y + (size_t)b * g.cap * g.ldy;
-  // epilogue: the bias of a lane's NT columns is loaded once; whole tiles take a guard-free path so
-  // that the residual loads / stores of all 16*MT rows are issued back to back instead of one
-  // load -> wait -> store round trip per element
-  float bj[NT];
-  int jj[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int j = j0 + col_of(nt);
-    jj[nt] = j < g.N ? j : -1;
-    bj[nt] = j < g.N ? g.bias[j] : 0.0f;
-  }
-  auto finish = [&](float acc, float bias, float old) {
-    float v = acc + bias;
-    if (EPI == EPI_DIV) v = v / g.div;
-    if (EPI == EPI_RESID) v = old + v;
-    return v;
+  const int tilesN = einx_cdiv(g.N, BN), tilesM = einx_cdiv(g.cap, BM);
+  const int groups = tilesM * g.B;                       // A-row groups
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int local_tiles = einx_cdiv(groups, 8) * tilesN;  // tiles in this XCD's list
+  // tile L of this XCD's list -> operands; false when the tile does not exist / has no valid rows
+  auto locate = [&](int L, Src& s, int& bb, int& nn) {
+    const int grp = (L / tilesN) * 8 + xcd;
+    if (grp >= groups) return false;
+    const int b = grp / tilesM, ti = grp % tilesM;
+    const int n = g.cnt ? min(g.cnt[b], g.cap) : g.cap;
+    if (ti * BM >= n) return false;
+    s.A = g.X + (size_t)b * g.cap * g.ldx;
+    s.A2 = g.X2 ? g.X2 + (size_t)b * g.cap * g.ldx2 : nullptr;
+    s.B = g.W;
+    s.lda = g.ldx;
+    s.lda2 = g.ldx2;
+    s.ldb = g.K;
+    s.i0 = ti * BM;
+    s.Mvalid = n;
+    s.j0 = (L % tilesN) * BN;
+    s.Nvalid = g.N;
+    bb = b;
+    nn = n;
+    return true;
   };
-  if (i0 + BM <= n && j0 + BN <= g.N) {
-    float* yp[MT][16];
+  Src cur, nxt;
+  int b = 0, n = 0, nb = 0, nn = 0;
+  int L = slot;
+  while (L < local_tiles && !locate(L, cur, b, n)) L += slots;
+  if (L >= local_tiles) return;
+  Stage st;
+  issue_slab(cur, 0, g.K, g.Ksplit, st);
+  for (;;) {
+    int Ln = L + slots;
+    while (Ln < local_tiles && !locate(Ln, nxt, nb, nn)) Ln += slots;
+    const bool more = Ln < local_tiles;
+    Frag f;
+    tile_nt_run(cur, g.K, g.Ksplit, lds, f, st, nxt, more);
+    const int i0 = cur.i0, j0 = cur.j0;
+    float* Y = g.Y + (size_t)b * g.cap * g.ldy;
+    // epilogue: the bias of a lane's NT columns is loaded once; whole tiles take a guard-free path so
+    // that the residual loads / stores of all 16*MT rows are issued back to back instead of one
+    // load -> wait -> store round trip per element
+    float bj[NT];
+    int jj[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yp[mt][r] = Y + (size_t)(i0 + row_of(mt, r)) * g.ldy + j0 + col_of(0);
-    float old[MT][16][NT];
-    if (EPI == EPI_RESID) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int j = j0 + col_of(nt);
+      jj[nt] = j < g.N ? j : -1;
+      bj[nt] = j < g.N ? g.bias[j] : 0.0f;
+    }
+    auto finish = [&](float acc, float bias, float old) {
+      float v = acc + bias;
+      if (EPI == EPI_DIV) v = v / g.div;
+      if (EPI == EPI_RESID) v = old + v;
+      return v;
+    };
+    if (i0 + BM <= n && j0 + BN <= g.N) {
+      // uniform row pointer (scalar registers) + one 32-bit lane offset shared by every access
+      float* ytile = Y + (size_t)i0 * g.ldy + j0;
+      const unsigned lane_off = (unsigned)(row_base() * g.ldy + col_of(0));
+      // rows go in batches of 8: eight residual loads in flight, then eight stores
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+          float old[8][NT];
+          if (EPI == EPI_RESID) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) old[mt][r][nt] = yp[mt][r][nt * 32];
+            for (int r = 0; r < 8; ++r) {
+              const float* yrow = ytile + (size_t)row_step(mt, r0 + r) * g.ldy;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) old[r][nt] = yrow[lane_off + nt * 32];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            float* yrow = ytile + (size_t)row_step(mt, r0 + r) * g.ldy;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              yrow[lane_off + nt * 32] = finish(f.acc[mt][nt][r0 + r], bj[nt], EPI == EPI_RESID ? old[r][nt] : 0.0f);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + row_of(mt, r);
+          if (i >= n) continue;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (jj[nt] < 0) continue;
+            float* y = Y + (size_t)i * g.ldy + jj[nt];
+            *y = finish(f.acc[mt][nt][r], bj[nt], EPI == EPI_RESID ? *y : 0.0f);
+          }
+        }
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) yp[mt][r][nt * 32] = finish(f.acc[mt][nt][r], bj[nt], EPI == EPI_RESID ? old[mt][r][nt] : 0.0f);
-    return;
+    if (!more) break;
+    cur = nxt;
+    b = nb;
+    n = nn;
+    L = Ln;
   }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + row_of(mt, r);
-      if (i >= n) continue;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (jj[nt] < 0) continue;
-        float* y = Y + (size_t)i * g.ldy + jj[nt];
-        *y = finish(f.acc[mt][nt][r], bj[nt], EPI == EPI_RESID ? *y : 0.0f);
-      }
-    }
 }
 
 // qkv [B,cap,768] with feature (h*64+c)*3+t  ->  q,k (rotary applied), v as [B,cap,256]
@@ -448,6 +496,23 @@ char* carve_side(Side& s, char* p, int B, int cap) {
   return p;
 }
 
+// persistent launch size: resident workgroups of the tile kernels on this device (a multiple of
+// 8 so that every XCD gets the same number of slots), never more than the tiles there are
+unsigned gemm_grid(int tiles) {
+  static int resident = 0;
+  if (resident == 0) {
+    int dev = 0, cus = 256, per_cu = 2;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lg_gemm_kernel<EPI_BIAS>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    }
+    resident = (cus * per_cu) & ~7;
+    if (resident < 8) resident = 8;
+  }
+  const int want = (tiles + 7) & ~7;
+  return (unsigned)(want < resident ? want : resident);
+}
+
 int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx, const float* X2, int ldx2, int Ksplit, int K, const float* W,
          const float* bias, int N, float* Y, int ldy, float div = 1.0f) {
   GemmArgs g;
@@ -465,7 +530,8 @@ int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx,
   g.N = N;
   g.ldy = ldy;
   g.div = div;
-  const dim3 grid((unsigned)einx_cdiv(N, BN), (unsigned)einx_cdiv(s.cap, BM), (unsigned)B);
+  g.B = B;
+  const dim3 grid(gemm_grid(einx_cdiv(N, BN) * einx_cdiv(s.cap, BM) * B));
   if (epi == EPI_BIAS) hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, st, g);
   else if (epi == EPI_DIV) hipLaunchKernelGGL(lg_gemm_kernel<EPI_DIV>, grid, dim3(THREADS), 0, st, g);
   else hipLaunchKernelGGL(lg_gemm_kernel<EPI_RESID>, grid, dim3(THREADS), 0, st, g);
@@ -517,7 +583,8 @@ EINX_EXPORT int einx_linear(const float* x, int M, int K, const float* w, const 
   g.N = N;
   g.ldy = N;
   g.div = 1.0f;
-  const dim3 grid((unsigned)einx_cdiv(N, BN), (unsigned)einx_cdiv(M, BM), 1);
+  g.B = 1;
+  const dim3 grid(gemm_grid(einx_cdiv(N, BN) * einx_cdiv(M, BM)));
   if (accumulate) hipLaunchKernelGGL(lg_gemm_kernel<EPI_RESID>, grid, dim3(THREADS), 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, (hipStream_t)stream, g);
   EINX_CHECK_LAUNCH();

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--skip-linear", action="store_true")
+    ap.add_argument("--only-linear", action="store_true")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "relu"], help="operand values of the linear shapes (power / clock sensitivity)")
     a = ap.parse_args()
     dev = "cuda:0"
     B, n = a.batch, 1024
@@ -43,10 +45,17 @@ def main():
             M = B * n
             x = torch.randn(M, K, device=dev)
             w = torch.randn(Nn, K, device=dev)
+            if a.data == "zeros":
+                x.zero_()
+                w.zero_()
+            elif a.data == "relu":
+                x.relu_()
             b = torch.randn(Nn, device=dev)
             y = torch.empty(M, Nn, device=dev)
             ms = timed(lambda: N.linear(x, w, b, out=y), a.reps)
             print(f"linear M={M} K={K} N={Nn}: {ms * 1e3:8.1f} us  {2.0 * M * K * Nn / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    if a.only_linear:
+        return
     from importlib import import_module
     bt = import_module("ei-nexus_official_amd.core.modules.matchers._batched")
     lg = pkg.LightGlue({"input_dim": 256}).to(dev).eval()

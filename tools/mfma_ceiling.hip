@@ -7,14 +7,27 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE, int NWAVES, int PF>
-__global__ __launch_bounds__(NWAVES * 64) void k(float* out, int iters) {
+__global__ __launch_bounds__(NWAVES * 64) void k(float* out, int iters, int data) {
   __shared__ float lds[8192];
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < 8192; i += NWAVES * 64) lds[i] = (float)(i % 7) * 0.125f;
+  // data: 0 = small regular values, 1 = zeros, 2 = random mantissas in [-1,1) (operand toggling drives power -> clocks)
+  for (int i = tid; i < 8192; i += NWAVES * 64) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    lds[i] = data == 0 ? (float)(i % 7) * 0.125f : data == 1 ? 0.0f : (float)(int)h * (1.0f / 2147483648.0f);
+  }
   __syncthreads();
   f32x16 acc[2];
   for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
   float a = 1.0f + lane * 1e-3f, b0 = 0.5f, b1 = 0.25f;
+  if (data == 1) a = b0 = b1 = 0.0f;
+  if (data == 2) {
+    a = lds[lane];
+    b0 = lds[lane + 64];
+    b1 = lds[lane + 128];
+  }
   const int base = lane + (tid >> 6) * 64;
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
@@ -51,17 +64,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k(float* out, int iters) {
 }
 
 template <int MODE, int NWAVES, int PF>
-void run(const char* name, int blocks_per_cu) {
-  const int blocks = 256 * blocks_per_cu, iters = 200;
+void run(const char* name, int blocks_per_cu, int data = 0) {
+  const int blocks = 256 * blocks_per_cu, iters = 2000;
   float* out;
   hipMalloc(&out, (size_t)blocks * NWAVES * 64 * 4);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, NWAVES, PF>), dim3(blocks), dim3(NWAVES * 64), 0, 0, out, 10);
+  hipLaunchKernelGGL((k<MODE, NWAVES, PF>), dim3(blocks), dim3(NWAVES * 64), 0, 0, out, 10, data);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((k<MODE, NWAVES, PF>), dim3(blocks), dim3(NWAVES * 64), 0, 0, out, iters);
+  hipLaunchKernelGGL((k<MODE, NWAVES, PF>), dim3(blocks), dim3(NWAVES * 64), 0, 0, out, iters, data);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -81,5 +94,10 @@ int main() {
   run<1, 8, 2>("LDS fed, 8 waves/WG, PF=2", 2);
   run<1, 8, 3>("LDS fed, 8 waves/WG, PF=3", 2);
   run<1, 8, 2>("LDS fed, 8 waves/WG, PF=2", 1);
+  run<0, 8, 1>("registers, 8 waves/WG, zeros", 2, 1);
+  run<0, 8, 1>("registers, 8 waves/WG, random", 2, 2);
+  run<1, 8, 2>("LDS fed, 8 waves/WG, PF=2, zeros", 2, 1);
+  run<1, 8, 2>("LDS fed, 8 waves/WG, PF=2, random", 2, 2);
+  run<1, 8, 2>("LDS fed, 8 waves/WG, PF=2, small values", 2, 0);
   return 0;
 }
