@@ -12,6 +12,19 @@ import torch
 from . import _native as N
 
 
+_SIZE_CACHE = {}
+
+
+def _size_tensor(H, W, dev):
+    """int64 [2] = (H, W) on the device (the reference's feats["image_size"] entries), cached: building
+    it costs a host-to-device copy per call otherwise."""
+    key = (H, W, str(dev))
+    t = _SIZE_CACHE.get(key)
+    if t is None:
+        t = _SIZE_CACHE[key] = torch.tensor([H, W], device=dev)
+    return t
+
+
 class FeatsDict(dict):
     """The reference's feature dict plus a handle on the device-side batch (`_batched`) so that the
     matcher can consume it without re-packing the per-image lists."""
@@ -34,6 +47,7 @@ class BatchedFeats:
         self.scale = 1.0
         self.ordering = "yx"
         self.dense = False
+        self._prepared = None
 
     # ------------------------------------------------------------------ device handles
     @property
@@ -44,13 +58,17 @@ class BatchedFeats:
     def positions(self):
         return self.det.positions
 
-    def materialize(self, counts_host):
-        """counts_host: python ints per image (already clamped by the caller's sync)."""
+    def prepare(self):
+        """Everything of the output dict that does not depend on the keypoint counts.  Called BEFORE
+        the host waits for the counts, so the crop/clone kernels and the Python work run while the
+        device is still busy with the detection tail instead of leaving it idle afterwards."""
+        if self._prepared is not None:
+            return self._prepared
         H, W = self.image_size
         w0, w1, h0, h1 = self.pads
         Hp, Wp = self.padded
         dev = self.score.device
-        size_t = torch.tensor([H, W], device=dev)
+        size_t = _size_tensor(H, W, dev)
         out = FeatsDict()
         out["image_size"] = [size_t] * self.B
         out["backbone_feats"] = self.feats
@@ -58,7 +76,7 @@ class BatchedFeats:
         out["raw_descriptors"] = self.raw
         out["probability"] = self.prob
         out["score"] = self.score[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
-        out["nms"] = self.det.nms
+        out["nms"] = None  # filled by materialize (a re-detection replaces it)
         if self.cell == 8:
             out["coarse_descriptors"] = self.coarse
         if self.dense:
@@ -72,6 +90,14 @@ class BatchedFeats:
             first, second = (gy, gx) if self.ordering == "yx" else (gx, gy)
             sc = out["score"]
             out["dense_positions"] = [torch.stack([first, second, sc[b, 0]], -1).reshape(-1, 3) for b in range(self.B)]
+        self._prepared = out
+        return out
+
+    def materialize(self, counts_host):
+        """counts_host: python ints per image (already clamped by the caller's sync)."""
+        out = self.prepare()
+        self._prepared = None
+        out["nms"] = self.det.nms
         cap = self.det.cap
         ns = [min(int(c), cap) for c in counts_host]
         if all(v == cap for v in ns):

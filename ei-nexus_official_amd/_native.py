@@ -205,7 +205,10 @@ def upsample_normalize(raw, padded_size, pads, scale):
 
 # ------------------------------------------------------------------------------ matching
 class MatchResult:
-    __slots__ = ("matches0", "matches1", "scores0", "scores1", "la", "mk0", "mk1", "nmatch", "ref0", "ref1")
+    __slots__ = ("matches0", "matches1", "scores0", "scores1", "la", "mk0", "mk1", "nmatch", "ref0", "ref1", "mk0_flat", "mk1_flat")
+
+    def __init__(self):
+        self.mk0_flat = self.mk1_flat = None
 
 
 def mnn(desc0, n, desc1, m, want_la=True):
@@ -237,6 +240,16 @@ def gather_matches(r, kpts0, kpts1, n, cols):
     r.nmatch = torch.empty((B,), dtype=torch.int32, device=dev)
     check(lib().einx_gather_matches(_ptr(kpts0), _ptr(kpts1), _ptr(r.matches0), _ptr(n), cap0, cap1, B, cols, _ptr(r.mk0), _ptr(r.mk1),
                                     _ptr(r.nmatch), _stream(kpts0)), "einx_gather_matches")
+    return r
+
+
+def compact_matches(r):
+    """r.mk0/r.mk1 [B,cap0,cols] + r.nmatch -> r.mk0_flat/r.mk1_flat [B*cap0,cols] packed pair after pair."""
+    B, cap0, cols = r.mk0.shape
+    r.mk0_flat = torch.empty((B * cap0, cols), dtype=F32, device=r.mk0.device)
+    r.mk1_flat = torch.empty((B * cap0, cols), dtype=F32, device=r.mk0.device)
+    check(lib().einx_compact_rows(_ptr(r.mk0), _ptr(r.mk1), _ptr(r.nmatch), B, cap0, cols, _ptr(r.mk0_flat), _ptr(r.mk1_flat),
+                                  _stream(r.mk0)), "einx_compact_rows")
     return r
 
 

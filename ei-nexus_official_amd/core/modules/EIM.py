@@ -69,6 +69,8 @@ class EIM(nn.Module):
 
     def forward(self, events, image, events_mask=None, image_mask=None):
         ev, im, mr = self.forward_batched(events, image, events_mask, image_mask)
+        ev.prepare()  # count-independent outputs are built while the device still works on the tail
+        im.prepare()
         while True:
             rows = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
             if mr is not None:

@@ -53,8 +53,9 @@ class Matcher(nn.Module):
         return 3 if self.matcher_type == "MNN" else 2
 
     def match_batched(self, bf0, bf1):
-        """BatchedFeats x2 -> MatchResult on the device (no sync)."""
-        return self.matcher.match_batched(from_batched(bf0), from_batched(bf1))
+        """BatchedFeats x2 -> MatchResult on the device (no sync).  The matched keypoints are also
+        packed pair after pair so that materialize() cuts the per-pair lists with one split call."""
+        return N.compact_matches(self.matcher.match_batched(from_batched(bf0), from_batched(bf1)))
 
     def materialize(self, r, n_host, m_host, nmatch_host):
         return materialize_matches(r, n_host, m_host, nmatch_host, self._cols)

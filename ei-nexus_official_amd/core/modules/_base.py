@@ -30,19 +30,20 @@ class NativeExtractor(nn.Module):
                                                               requires_grad=learnable_descriptor_scale_factor)
         self.dense_outputs = True  # reference-complete dict; set False to skip the 92 MB/image dense maps
         self._engine = None
+        self._scale_host = None
 
     # -- cache invalidation: anything that moves or replaces parameters drops the native images
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self._engine = self._scale_host = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._engine = None
+        self._engine = self._scale_host = None
         return super().load_state_dict(*a, **k)
 
     def refresh(self):
-        """Call after editing parameters in place."""
-        self._engine = None
+        """Call after editing parameters in place (weights or descriptor_scale_factor)."""
+        self._engine = self._scale_host = None
 
     def _layer(self, block, pool=False):
         conv, bn, relu, pool = block_spec(block, pool)
@@ -72,8 +73,11 @@ class NativeExtractor(nn.Module):
             raise RuntimeError("the native path implements eval-mode BatchNorm (running statistics) only; call .eval() first")
         if not prepared:
             x = self._prepare_input(x)
-        scale = float(self.descriptor_scale_factor.detach())
-        return self.engine().run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask,
+        eng = self.engine()
+        if self._scale_host is None:  # one device read per engine build, not one host sync per forward
+            self._scale_host = float(self.descriptor_scale_factor.detach())
+        scale = self._scale_host
+        return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask,
                                  dense=self.dense_outputs if dense is None else dense, nms_iters=nms_iters)
 
     def forward(self, x, score_mask=None, **kwargs):

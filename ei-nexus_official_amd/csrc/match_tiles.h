@@ -318,6 +318,29 @@ __global__ __launch_bounds__(1024) void gather_matches_kernel(const float* k0, c
   if (tid == 0) nmatch[b] = base;
 }
 
+// rows [b, 0:counts[b]] of two padded [B,cap,width] arrays -> consecutive rows of two flat arrays
+// (pair b starts at sum(counts[:b])): lets the host cut per-pair views with one split call
+__global__ __launch_bounds__(256) void compact_rows_kernel(const float* s0, const float* s1, const int32_t* counts, int B, int cap, int width,
+                                                           float* d0, float* d1) {
+  __shared__ int part[256];
+  const int b = blockIdx.x;
+  int acc = 0;
+  for (int i = threadIdx.x; i < b; i += 256) acc += min(counts[i], cap);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  const size_t base = (size_t)part[0] * width;
+  const int n = min(counts[b], cap) * width;
+  const size_t src = (size_t)b * cap * width;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    d0[base + i] = s0[src + i];
+    d1[base + i] = s1[src + i];
+  }
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 

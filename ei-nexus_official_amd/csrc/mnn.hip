@@ -109,3 +109,12 @@ EINX_EXPORT int einx_gather_matches(const float* kpts0, const float* kpts1, cons
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }
+
+EINX_EXPORT int einx_compact_rows(const float* src0, const float* src1, const int32_t* counts, int B, int cap, int width, float* dst0,
+                                  float* dst1, void* stream) {
+  EINX_CHECK_ARG(src0 && src1 && counts && dst0 && dst1, "null pointer");
+  EINX_CHECK_ARG(B > 0 && cap > 0 && width > 0, "bad shape");
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, src0, src1, counts, B, cap, width, dst0, dst1);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}

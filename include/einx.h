@@ -166,6 +166,13 @@ int einx_similarity(const float* desc0, const int32_t* n, int cap0, const float*
 int einx_gather_matches(const float* kpts0, const float* kpts1, const int64_t* matches0, const int32_t* n, int cap0, int cap1,
                         int B, int cols, float* out0, float* out1, int32_t* nmatch, void* stream);
 
+/* Packs the first counts[b] rows of two padded [B,cap,width] arrays (the matched keypoints of
+ * einx_gather_matches) into two flat [sum(counts),width] arrays, pair after pair, so that the
+ * per-pair lists the reference returns (Matchers.py:177-201) are views cut by one split call.
+ * dst0/dst1 need room for B*cap rows. */
+int einx_compact_rows(const float* src0, const float* src1, const int32_t* counts, int B, int cap, int width, float* dst0, float* dst1,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LightGlue  (K8, K9)   core/modules/matchers/lightglue.py:522-716
  * ---------------------------------------------------------------------------------------- */
