@@ -42,6 +42,7 @@ class BatchedFeats:
         self.feats = self.logits = self.raw = self.prob = self.score = None
         self.det = None
         self.sparse_desc = None
+        self.raw_cl = None
         self.coarse = None
         self.normalized = None
         self.scale = 1.0
@@ -137,7 +138,8 @@ class ExtractorEngine:
             det.indices = det.indices[:, :cmax].contiguous()
             det.cap = cmax
         bf.det = det
-        bf.sparse_desc = N.desc_sample(bf.raw, det.indices, det.counts, bf.padded, bilinear=(self.cell == 8), scale=bf.scale)
+        bf.sparse_desc = N.desc_sample(bf.raw, det.indices, det.counts, bf.padded, bilinear=(self.cell == 8), scale=bf.scale,
+                                       raw_cl=bf.raw_cl)
         return bf
 
     def grow_nms_iters(self):
@@ -179,7 +181,7 @@ class ExtractorEngine:
         # dense by-products first: they depend only on `raw`, so they run under the other stream's
         # convolutions instead of lengthening the latency-bound detection tail at the end of the step
         if self.cell == 8:
-            bf.coarse = N.normalize_map(raw, scale)
+            bf.coarse, bf.raw_cl = N.normalize_map(raw, scale, want_cl=True)  # + channels-last raw copy for the sparse sampler
         prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
         bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
         self.redetect(bf, nms_iters)

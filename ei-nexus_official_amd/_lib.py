@@ -59,9 +59,9 @@ SIGNATURES = {
     "einx_detect_ws_bytes": (c_size_t, [ctypes.POINTER(DetectParams)]),
     "einx_detect": (c_int, [c_void_p, ctypes.POINTER(DetectParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
-    "einx_desc_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
+    "einx_desc_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
                                  c_void_p, c_void_p]),
-    "einx_normalize_map": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "einx_normalize_map": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "einx_upsample_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_void_p, c_void_p]),
     "einx_mnn_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -172,23 +172,29 @@ def detect(score, *, top_k, radius, det_thr, pads=(0, 0, 0, 0), ordering="yx", c
 
 
 # ------------------------------------------------------------------------------ descriptors
-def desc_sample(raw, indices, counts, padded_size, bilinear, scale):
-    _dev_check(raw, indices, counts)
+def desc_sample(raw, indices, counts, padded_size, bilinear, scale, raw_cl=None):
+    """raw [B,D,hc,wc].  raw_cl: the channels-last copy [B,hc*wc,D] from normalize_map(want_cl=True);
+    when given (bilinear only) the taps are read from it -- same values, coalesced rows."""
+    _dev_check(raw, indices, counts, raw_cl)
     B, D, hc, wc = raw.shape
     cap = indices.shape[1]
     out = torch.empty((B, cap, D), dtype=F32, device=raw.device)
-    check(lib().einx_desc_sample(_ptr(raw), B, D, hc, wc, int(padded_size[0]), int(padded_size[1]), int(bilinear), _ptr(indices),
-                                 _ptr(counts), cap, float(scale), _ptr(out), _stream(raw)), "einx_desc_sample")
+    use_cl = raw_cl is not None and bilinear
+    src = raw_cl if use_cl else raw
+    check(lib().einx_desc_sample(_ptr(src), B, D, hc, wc, int(padded_size[0]), int(padded_size[1]), int(bilinear), int(use_cl),
+                                 _ptr(indices), _ptr(counts), cap, float(scale), _ptr(out), _stream(raw)), "einx_desc_sample")
     return out
 
 
-def normalize_map(raw, scale):
+def normalize_map(raw, scale, want_cl=False):
+    """-> normalised map like `raw`; with want_cl also the channels-last copy [B,P,D] of the raw values."""
     _dev_check(raw)
     B, D = raw.shape[:2]
     P = int(raw.numel() // (B * D))
     out = torch.empty_like(raw)
-    check(lib().einx_normalize_map(_ptr(raw), B, D, P, float(scale), _ptr(out), _stream(raw)), "einx_normalize_map")
-    return out
+    cl = torch.empty((B, P, D), dtype=F32, device=raw.device) if (want_cl and D <= 512) else None
+    check(lib().einx_normalize_map(_ptr(raw), B, D, P, float(scale), _ptr(out), _ptr(cl), _stream(raw)), "einx_normalize_map")
+    return (out, cl) if want_cl else out
 
 
 def upsample_normalize(raw, padded_size, pads, scale):

@@ -17,7 +17,10 @@ __device__ __forceinline__ float wave_butterfly_sum(float v) {
 }
 
 // one wave per keypoint; lane l owns channels l, l+64, ...
-template <bool BILINEAR>
+// CL: `raw` is the channels-last copy [B, hc*wc, D] written by normalize_map_tile_kernel: the four
+// taps of a keypoint are four contiguous D-float rows (coalesced), instead of 4*D words that each
+// sit in a different channel plane (one cache line per lane and tap).
+template <bool BILINEAR, bool CL = false>
 __global__ __launch_bounds__(256) void desc_sample_kernel(const float* raw, int D, int hc, int wc, int Hp, int Wp,
                                                           const int32_t* indices, const int32_t* counts, int cap, float scale,
                                                           float* out) {
@@ -49,11 +52,19 @@ __global__ __launch_bounds__(256) void desc_sample_kernel(const float* raw, int 
       const int c = lane + 64 * i;
       float t = 0.0f;
       if (c < D) {
-        const float* p = rb + (size_t)c * plane;
-        const float a = (vy0 && vx0) ? p[y0 * wc + x0] : 0.0f;
-        const float bb = (vy0 && vx1) ? p[y0 * wc + x1] : 0.0f;
-        const float cc = (vy1 && vx0) ? p[y1 * wc + x0] : 0.0f;
-        const float dd = (vy1 && vx1) ? p[y1 * wc + x1] : 0.0f;
+        float a, bb, cc, dd;
+        if (CL) {
+          a = (vy0 && vx0) ? rb[(size_t)(y0 * wc + x0) * D + c] : 0.0f;
+          bb = (vy0 && vx1) ? rb[(size_t)(y0 * wc + x1) * D + c] : 0.0f;
+          cc = (vy1 && vx0) ? rb[(size_t)(y1 * wc + x0) * D + c] : 0.0f;
+          dd = (vy1 && vx1) ? rb[(size_t)(y1 * wc + x1) * D + c] : 0.0f;
+        } else {
+          const float* p = rb + (size_t)c * plane;
+          a = (vy0 && vx0) ? p[y0 * wc + x0] : 0.0f;
+          bb = (vy0 && vx1) ? p[y0 * wc + x1] : 0.0f;
+          cc = (vy1 && vx0) ? p[y1 * wc + x0] : 0.0f;
+          dd = (vy1 && vx1) ? p[y1 * wc + x1] : 0.0f;
+        }
         t = a * nw;
         t = t + bb * ne;
         t = t + cc * sw;
@@ -104,6 +115,47 @@ __global__ void random_positions_kernel(const float* u, int R, float s0, float s
   out[t * 3 + 0] = u[t * 2 + 0] * s0;
   out[t * 3 + 1] = u[t * 2 + 1] * s1;
   out[t * 3 + 2] = 0.0f;
+}
+
+// normalize_descriptors through LDS: a workgroup stages PT pixels x D channels with fully coalesced,
+// deeply pipelined loads (the thread-per-pixel form below issues D dependent strided loads from far
+// too few threads), one lane per pixel then walks the channels as the same sequential fmaf chain
+// c = 0..D-1, and all threads write the normalised map -- plus, optionally, the channels-last copy
+// of the raw map that desc_sample_kernel<.., CL> gathers from.  Element (c, pixel) lives at
+// lds[c*PT + ((pixel + c) & (PT-1))]: conflict-free along pixels and along channels.
+template <int PT>
+__global__ __launch_bounds__(256) void normalize_map_tile_kernel(const float* raw, int D, int P, float scale, float* out, float* raw_cl) {
+  extern __shared__ float tile[];
+  __shared__ float s_den[PT];
+  const int b = blockIdx.y, p0 = blockIdx.x * PT;
+  const int tid = threadIdx.x;
+  const float* rb = raw + (size_t)b * D * P;
+  const int px = tid % PT, cgrp = tid / PT;
+  constexpr int CG = 256 / PT;  // channels handled per sweep
+  const bool pv = p0 + px < P;
+  for (int c = cgrp; c < D; c += CG) tile[c * PT + ((px + c) & (PT - 1))] = pv ? rb[(size_t)c * P + p0 + px] : 0.0f;
+  __syncthreads();
+  if (tid < PT) {
+    float s = 0.0f;
+    for (int c = 0; c < D; ++c) {
+      const float v = tile[c * PT + ((tid + c) & (PT - 1))];
+      s = fmaf(v, v, s);
+    }
+    s_den[tid] = fmaxf(sqrtf(s), 1e-12f);
+  }
+  __syncthreads();
+  if (pv) {
+    const float den = s_den[px];
+    float* ob = out + (size_t)b * D * P + p0 + px;
+    for (int c = cgrp; c < D; c += CG) ob[(size_t)c * P] = scale * (tile[c * PT + ((px + c) & (PT - 1))] / den);
+  }
+  if (raw_cl) {
+    float* cb = raw_cl + ((size_t)b * P + p0) * D;
+    for (int e = tid; e < PT * D; e += 256) {
+      const int pixel = e / D, c = e % D;
+      if (p0 + pixel < P) cb[(size_t)pixel * D + c] = tile[c * PT + ((pixel + c) & (PT - 1))];
+    }
+  }
 }
 
 // thread per pixel, channels walked sequentially (fmaf chain c = 0..D-1)
@@ -159,27 +211,39 @@ __global__ void upsample_normalize_kernel(const float* raw, int B, int D, int hc
 
 }  // namespace
 
-EINX_EXPORT int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, const int32_t* indices,
-                                 const int32_t* counts, int cap, float scale, float* out, void* stream) {
+EINX_EXPORT int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last,
+                                 const int32_t* indices, const int32_t* counts, int cap, float scale, float* out, void* stream) {
   EINX_CHECK_ARG(raw && indices && counts && out, "null pointer");
   EINX_CHECK_ARG(B > 0 && D > 0 && D <= 512 && hc > 0 && wc > 0 && cap > 0, "bad shape (D must be <= 512)");
   EINX_CHECK_ARG(bilinear || (Hp == hc && Wp == wc), "gather mode needs a full-resolution map");
+  EINX_CHECK_ARG(!channels_last || bilinear, "the channels-last layout is implemented for bilinear sampling");
   dim3 grid((unsigned)einx_cdiv(cap, 4), (unsigned)B);
-  if (bilinear)
-    hipLaunchKernelGGL(desc_sample_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, raw, D, hc, wc, Hp, Wp, indices, counts, cap,
-                       scale, out);
+  hipStream_t s = (hipStream_t)stream;
+  if (bilinear && channels_last)
+    hipLaunchKernelGGL((desc_sample_kernel<true, true>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
+  else if (bilinear)
+    hipLaunchKernelGGL((desc_sample_kernel<true, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
   else
-    hipLaunchKernelGGL(desc_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, raw, D, hc, wc, Hp, Wp, indices, counts, cap,
-                       scale, out);
+    hipLaunchKernelGGL((desc_sample_kernel<false, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }
 
-EINX_EXPORT int einx_normalize_map(const float* raw, int B, int D, int P, float scale, float* out, void* stream) {
+EINX_EXPORT int einx_normalize_map(const float* raw, int B, int D, int P, float scale, float* out, float* raw_cl, void* stream) {
   EINX_CHECK_ARG(raw && out, "null pointer");
   EINX_CHECK_ARG(B > 0 && D > 0 && P > 0, "bad shape");
-  const size_t n = (size_t)B * P;
-  hipLaunchKernelGGL(normalize_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, B, D, P, scale, out);
+  hipStream_t s = (hipStream_t)stream;
+  if (D <= 256) {
+    hipLaunchKernelGGL(normalize_map_tile_kernel<64>, dim3((unsigned)einx_cdiv(P, 64), (unsigned)B), dim3(256), (size_t)D * 64 * sizeof(float), s,
+                       raw, D, P, scale, out, raw_cl);
+  } else if (D <= 512) {
+    hipLaunchKernelGGL(normalize_map_tile_kernel<32>, dim3((unsigned)einx_cdiv(P, 32), (unsigned)B), dim3(256), (size_t)D * 32 * sizeof(float), s,
+                       raw, D, P, scale, out, raw_cl);
+  } else {
+    EINX_CHECK_ARG(raw_cl == nullptr, "channels-last copy needs D <= 512");
+    const size_t n = (size_t)B * P;
+    hipLaunchKernelGGL(normalize_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, B, D, P, scale, out);
+  }
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

@@ -124,12 +124,14 @@ int einx_detect(const float* score, const einx_detect_params* p, void* ws, float
 
 /* sparsify_low_resolution_descriptors (bilinear=1; descriptor_util.py:74-128) or
  * sparsify_full_resolution_descriptors (bilinear=0; descriptor_util.py:50-71), then
- * F.normalize * scale.  raw [B,D,hc,wc]; indices/counts from einx_detect; out [B,cap,D]. */
-int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, const int32_t* indices,
-                     const int32_t* counts, int cap, float scale, float* out, void* stream);
+ * F.normalize * scale.  raw [B,D,hc,wc], or with channels_last=1 (bilinear only) the [B,hc*wc,D]
+ * copy written by einx_normalize_map; indices/counts from einx_detect; out [B,cap,D]. */
+int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last,
+                     const int32_t* indices, const int32_t* counts, int cap, float scale, float* out, void* stream);
 
-/* normalize_descriptors over channels of a dense map (descriptor_util.py:21-28). [B,D,P] */
-int einx_normalize_map(const float* raw, int B, int D, int P, float scale, float* out, void* stream);
+/* normalize_descriptors over channels of a dense map (descriptor_util.py:21-28). raw/out [B,D,P].
+ * raw_cl: optional [B,P,D] channels-last copy of `raw` (un-normalised) for einx_desc_sample, or NULL. */
+int einx_normalize_map(const float* raw, int B, int D, int P, float scale, float* out, float* raw_cl, void* stream);
 
 /* F.normalize(x, dim=1) * scale on a row-major [R,C] matrix: the random padding descriptors of the
  * trainable matcher branch (core/modules/Matchers.py:114-131) */

@@ -176,6 +176,40 @@ def test_desc_helpers_vs_golden_and_oracle(oracle):
     assert np.array_equal(_np(up), oracle.upsample_normalize(raw, (c["hc"] * 8, c["wc"] * 8), 1.0))
 
 
+@pytest.mark.parametrize("shape", [(3, 256, 33, 44), (2, 128, 9, 70), (1, 320, 5, 7), (2, 7, 3, 41), (1, 600, 4, 9)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_normalize_map_tiles_and_channels_last_sampler(oracle, shape):
+    """the LDS-tiled normalise (64 / 32 pixel tiles, ragged pixel and channel counts, D > 512 fall-back),
+    its channels-last raw copy, and the sampler reading that copy: all bit-equal to the oracle."""
+    N = pkg.native
+    B, D, hc, wc = shape
+    raw = synth.normalish(700 + D, shape)
+    raw[0, :, 0, 0] = 0  # an all-zero pixel -> eps clamp
+    t = _t(raw)
+    if D <= 512:
+        co, cl = N.normalize_map(t, 1.3, want_cl=True)
+        assert np.array_equal(_np(cl), raw.reshape(B, D, hc * wc).transpose(0, 2, 1))
+    else:
+        co, cl = N.normalize_map(t, 1.3), None
+    assert np.array_equal(_np(co), oracle.normalize_map(raw, 1.3))
+    if D > 512:
+        return
+    Hp, Wp = hc * 8, wc * 8
+    n = 50
+    idx = [np.sort(np.argsort(synth.uniform01(800 + b, (Hp * Wp,)))[:n]).astype(np.int32) for b in range(B)]
+    idx[-1] = idx[-1][:17]  # ragged count
+    cap = n
+    ind = np.zeros((B, cap), np.int32)
+    for b in range(B):
+        ind[b, :len(idx[b])] = idx[b]
+    cnt = torch.tensor([len(i) for i in idx], dtype=torch.int32, device=DEV)
+    exp = oracle.desc_sample_bilinear(raw, idx, (Hp, Wp), 1.0)
+    for use_cl in (False, True):
+        got = _np(N.desc_sample(t, _t(ind), cnt, (Hp, Wp), True, 1.0, raw_cl=cl if use_cl else None))
+        for b in range(B):
+            assert np.array_equal(got[b, :len(idx[b])], exp[b]), (use_cl, b)
+
+
 # ------------------------------------------------------------------ MNN
 MNN = Golden("mnn")
 
