@@ -30,31 +30,60 @@ __device__ __forceinline__ bool mask_on(const uint8_t* mask, int b, int H, int W
   return false;
 }
 
-__global__ void score65_kernel(const float* logits, int B, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0,
-                               int dilate, int border, float* prob, float* score) {
+// 8 lanes per cell: lane (cell j, row i) of a wave is lane j + 8*i and owns channels 8i..8i+7, i.e.
+// row i of the cell's 8x8 pixel block (pixel_shuffle: score[8h+i][8w+k] = prob[8i+k][h][w]).  The 64
+// exponentials of a cell are computed once and in parallel; the softmax denominator is then summed
+// by every lane in the oracle's order c = 0..64 (values fetched with lane shuffles), so the result
+// is bit-identical to the one-thread-per-cell form.  A lane writes its 8 score pixels as two 16-byte
+// stores; 8 neighbouring cells give 256 contiguous bytes per row.
+__global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B, int hc, int wc, const uint8_t* mask, int H, int W,
+                                                      int h0, int w0, int dilate, int border, float* prob, float* score) {
   const int cells = hc * wc;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= B * cells) return;
-  const int b = gid / cells, cell = gid % cells;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 7, i = lane >> 3;
+  const int gid = (blockIdx.x * 4 + wave) * 8 + j;
+  const bool valid = gid < B * cells;
+  const int g = valid ? gid : B * cells - 1;
+  const int b = g / cells, cell = g % cells;
   const int h = cell / wc, w = cell % wc;
   const float* l = logits + (size_t)b * 65 * cells + cell;
-  float mx = l[0];
-  for (int c = 1; c < 65; ++c) mx = fmaxf(mx, l[(size_t)c * cells]);
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = l[(size_t)(8 * i + k) * cells];
+  const float v64 = l[(size_t)64 * cells];
+  float mx = v64;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mx = fmaxf(mx, v[k]);
+  mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = einx_expf(v[k] - mx);
+  const float e64 = einx_expf(v64 - mx);
   float s = 0.0f;
-  for (int c = 0; c < 65; ++c) s = s + einx_expf(l[(size_t)c * cells] - mx);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) s = s + __shfl(e[c & 7], j + 8 * (c >> 3), 64);
+  s = s + e64;
+  if (!valid) return;
   const int Hp = hc * 8, Wp = wc * 8;
   float* pr = prob + (size_t)b * 65 * cells + cell;
-  for (int c = 0; c < 65; ++c) {
-    const float p = einx_expf(l[(size_t)c * cells] - mx) / s;
-    pr[(size_t)c * cells] = p;
-    if (c < 64) {
-      const int y = h * 8 + (c >> 3), x = w * 8 + (c & 7);
-      float v = p;
-      if (mask && !mask_on(mask, b, H, W, h0, w0, Hp, Wp, y, x, dilate)) v = 0.0f;
-      if (border > 0 && (y < border || y >= Hp - border || x < border || x >= Wp - border)) v = 0.0f;
-      score[((size_t)b * Hp + y) * Wp + x] = v;
-    }
+  const int y = h * 8 + i;
+  float out[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float p = e[k] / s;
+    pr[(size_t)(8 * i + k) * cells] = p;
+    const int x = w * 8 + k;
+    float t = p;
+    if (mask && !mask_on(mask, b, H, W, h0, w0, Hp, Wp, y, x, dilate)) t = 0.0f;
+    if (border > 0 && (y < border || y >= Hp - border || x < border || x >= Wp - border)) t = 0.0f;
+    out[k] = t;
   }
+  if (i == 0) pr[(size_t)64 * cells] = e64 / s;
+  f32x4* dst = reinterpret_cast<f32x4*>(score + ((size_t)b * Hp + y) * Wp + w * 8);  // 32-byte aligned: Wp % 8 == 0
+  dst[0] = f32x4{out[0], out[1], out[2], out[3]};
+  dst[1] = f32x4{out[4], out[5], out[6], out[7]};
 }
 
 __global__ void score1_kernel(const float* logits, int B, int Hp, int Wp, const uint8_t* mask, int H, int W, int h0, int w0,
@@ -555,7 +584,7 @@ EINX_EXPORT int einx_score_map(const float* logits, int B, int C, int hc, int wc
   hipStream_t s = (hipStream_t)stream;
   if (C == 65) {
     const int n = B * hc * wc;
-    hipLaunchKernelGGL(score65_kernel, dim3(einx_cdiv(n, 128)), dim3(128), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
+    hipLaunchKernelGGL(score65_kernel, dim3(einx_cdiv(n, 32)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
                        prob, score);
   } else {
     const int n = B * hc * wc;
