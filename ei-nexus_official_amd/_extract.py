@@ -49,6 +49,7 @@ class BatchedFeats:
         self.ordering = "yx"
         self.dense = False
         self._prepared = None
+        self._full_lists = None
 
     # ------------------------------------------------------------------ device handles
     @property
@@ -91,6 +92,9 @@ class BatchedFeats:
             first, second = (gy, gx) if self.ordering == "yx" else (gx, gy)
             sc = out["score"]
             out["dense_positions"] = [torch.stack([first, second, sc[b, 0]], -1).reshape(-1, 3) for b in range(self.B)]
+        # speculative per-image lists for the common case that every image fills its top-k quota
+        # (checked against the real counts in materialize)
+        self._full_lists = (self.det, list(self.sparse_desc.unbind(0)), list(self.det.positions.unbind(0)))
         self._prepared = out
         return out
 
@@ -102,9 +106,14 @@ class BatchedFeats:
         cap = self.det.cap
         ns = [min(int(c), cap) for c in counts_host]
         if all(v == cap for v in ns):
-            # common case (every image filled its top-k quota): one unbind instead of B slicing calls
-            out["sparse_descriptors"] = list(self.sparse_desc.unbind(0))
-            out["sparse_positions"] = list(self.det.positions.unbind(0))
+            # common case (every image filled its top-k quota): one unbind instead of B slicing calls,
+            # normally already done by prepare() while the device was busy
+            spec = self._full_lists
+            if spec is not None and spec[0] is self.det:
+                out["sparse_descriptors"], out["sparse_positions"] = spec[1], spec[2]
+            else:
+                out["sparse_descriptors"] = list(self.sparse_desc.unbind(0))
+                out["sparse_positions"] = list(self.det.positions.unbind(0))
         else:
             out["sparse_descriptors"] = [self.sparse_desc[b, :ns[b]] for b in range(self.B)]
             out["sparse_positions"] = [self.det.positions[b, :ns[b]] for b in range(self.B)]

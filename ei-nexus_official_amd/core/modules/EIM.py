@@ -11,6 +11,7 @@ from torch import nn
 
 from .Extractors import EventKeypointsExtractor, ImageKeypointsExtractor
 from .Matchers import Matcher
+from .matchers._batched import full_batch_lists
 
 
 class EIM(nn.Module):
@@ -71,6 +72,7 @@ class EIM(nn.Module):
         ev, im, mr = self.forward_batched(events, image, events_mask, image_mask)
         ev.prepare()  # count-independent outputs are built while the device still works on the tail
         im.prepare()
+        pre = full_batch_lists(mr) if mr is not None else None
         while True:
             rows = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
             if mr is not None:
@@ -87,6 +89,7 @@ class EIM(nn.Module):
                     eng.redetect(bf, eng.grow_nms_iters())
             if mr is not None:
                 mr = self.matcher.match_batched(ev, im)
+                pre = None
         self._last_match = mr  # device-side MatchResult of this call (consumed by core.metrics batch_metrics)
         n, m = host[0].tolist(), host[1].tolist()
         events_feats = ev.materialize(n)
@@ -95,7 +98,7 @@ class EIM(nn.Module):
         if mr is not None:
             n = [min(v, ev.det.cap) for v in n]
             m = [min(v, im.det.cap) for v in m]
-            matches = self.matcher.materialize(mr, n, m, host[4].tolist())
+            matches = self.matcher.materialize(mr, n, m, host[4].tolist(), prebuilt=pre)
         elif self.matcher.matcher is not None:
             # un-frozen matcher (EIM.py:92-95 -> Matchers.py:204-222): random padding to max_points_num and
             # one stacked call; like the reference it rewrites sparse_positions / sparse_descriptors of

@@ -12,7 +12,7 @@ from ... import _native as N
 
 from .matchers.MNN import NearestNeighborMatcher
 from .matchers.lightglue import LightGlue
-from .matchers._batched import from_batched, from_feats, materialize_matches
+from .matchers._batched import from_batched, from_feats, full_batch_lists, materialize_matches
 
 
 class Matcher(nn.Module):
@@ -57,8 +57,8 @@ class Matcher(nn.Module):
         packed pair after pair so that materialize() cuts the per-pair lists with one split call."""
         return N.compact_matches(self.matcher.match_batched(from_batched(bf0), from_batched(bf1)))
 
-    def materialize(self, r, n_host, m_host, nmatch_host):
-        return materialize_matches(r, n_host, m_host, nmatch_host, self._cols)
+    def materialize(self, r, n_host, m_host, nmatch_host, prebuilt=None):
+        return materialize_matches(r, n_host, m_host, nmatch_host, self._cols, prebuilt=prebuilt)
 
     # ---- un-frozen branch: pad to max_points_num (Matchers.py:67-149) ---------------------------
     def pad_sparse_positions_to_length(self, sparse_positions, length, image_size=None):

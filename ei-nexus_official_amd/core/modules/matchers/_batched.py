@@ -61,7 +61,18 @@ def from_feats(feats):
     return pb
 
 
-def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None):
+def full_batch_lists(r):
+    """count-independent part of the per-pair lists when every image filled its quota (one unbind per
+    output); can be built before the host knows the counts."""
+    B = r.matches0.shape[0]
+    return {
+        "matches0": list(r.matches0[:, None, :].unbind(0)), "matches1": list(r.matches1[:, None, :].unbind(0)),
+        "matching_scores0": list(r.scores0[:, None, :].unbind(0)), "matching_scores1": list(r.scores1[:, None, :].unbind(0)),
+        "log_assignment": [None] * B if r.la is None else list(r.la[:, None].unbind(0)),
+    }
+
+
+def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None, prebuilt=None):
     """MatchResult (device, padded) -> the reference's per-pair lists (Matchers.py:168-203).
     Reproduces the empty-input dict (MNN.py:63-86 / lightglue.py:569-591) and the zero-match
     `torch.stack([])` failure (MNN.py:126-127) of the reference."""
@@ -75,10 +86,8 @@ def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None):
     if all(v == cap0 for v in n_host) and all(v == cap1 for v in m_host) and all(v > 0 for v in nmatch_host) and cap0 > 0 and cap1 > 0:
         # common case: every image filled its keypoint quota -> whole-batch views, per-pair work only
         # where the length really differs (matched keypoints)
-        out["matches0"] = list(r.matches0[:, None, :].unbind(0))
-        out["matches1"] = list(r.matches1[:, None, :].unbind(0))
-        out["matching_scores0"] = list(r.scores0[:, None, :].unbind(0))
-        out["matching_scores1"] = list(r.scores1[:, None, :].unbind(0))
+        pre = prebuilt if prebuilt is not None else full_batch_lists(r)
+        out.update(pre)
         if r.mk0_flat is not None:  # packed on the device: one split instead of 2 B slicing calls
             total = sum(nmatch_host)
             out["matched_kpts0"] = list(r.mk0_flat[:total].split(nmatch_host))
@@ -86,7 +95,6 @@ def materialize_matches(r, n_host, m_host, nmatch_host, cols, extra=None):
         else:
             out["matched_kpts0"] = [r.mk0[b, :nmatch_host[b], :cols] for b in range(B)]
             out["matched_kpts1"] = [r.mk1[b, :nmatch_host[b], :cols] for b in range(B)]
-        out["log_assignment"] = [None] * B if r.la is None else list(r.la[:, None].unbind(0))
         return out
     for b in range(B):
         n, m = n_host[b], m_host[b]

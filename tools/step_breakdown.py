@@ -41,6 +41,7 @@ def main():
         t1 = time.perf_counter()
         e.prepare()
         i.prepare()
+        pre = model.matcher.__class__.__module__ and __import__("importlib").import_module(pkg.__name__ + ".core.modules.matchers._batched").full_batch_lists(mr)
         t2 = time.perf_counter()
         host = torch.stack([e.det.counts, i.det.counts, e.det.not_converged, i.det.not_converged, mr.nmatch]).cpu()
         t3 = time.perf_counter()
@@ -48,7 +49,7 @@ def main():
         ef = e.materialize(n)
         imf = i.materialize(m)
         t4 = time.perf_counter()
-        mt = model.matcher.materialize(mr, n, m, host[4].tolist())
+        mt = model.matcher.materialize(mr, n, m, host[4].tolist(), prebuilt=pre)
         t5 = time.perf_counter()
         rows.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0])
     r = np.array(rows[5:]) * 1e3
