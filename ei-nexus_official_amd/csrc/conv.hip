@@ -42,7 +42,10 @@ struct ConvArgs {
 // WM (output-channel groups) x WN (pixel groups); each wave owns MT x NT MFMA tiles of 32x32, with
 // WM*MT == 2 (64 output channels per workgroup).  CK: input channels staged per LDS round.
 // POOL: fuse MaxPool2d(2,2).
-template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
+// EXACT: Cin is a whole multiple of CK (every layer but the thin first ones): chunks reload through
+// constant per-thread element offsets from a uniform base pointer that advances with the chunk, with
+// no per-element multiplies, clamps or 64-bit address arithmetic in the steady state.
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool EXACT>
 __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs a) {
   constexpr int kMT = MT, kNT = NT;
   constexpr int NW = WM * WN;
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
   const size_t src_plane = (size_t)a.Hs * a.Ws;
   const float* in_b = a.in + (size_t)b * a.Cin * src_plane;
   int g_off[IN_PER_THR];  // offset inside a source channel plane, -1 = structural zero
-  int g_ci[IN_PER_THR];
+  int g_ci[IN_PER_THR];   // (generic path) channel inside the chunk
+  unsigned goff[IN_PER_THR];  // (EXACT path) element offset from the chunk's first channel plane
+  unsigned okmask = 0;        // (EXACT path) bit i: element i is a real pixel (not padding / tail)
 #pragma unroll
   for (int i = 0; i < IN_PER_THR; ++i) {
     const int e = tid + i * NTHR;
@@ -148,8 +153,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
         }
       }
     }
-    g_off[i] = off;
-    g_ci[i] = cil;
+    if (EXACT) {
+      goff[i] = (unsigned)cil * (unsigned)src_plane + (unsigned)(off >= 0 ? off : 0);
+      okmask |= (off >= 0 ? 1u : 0u) << i;
+    } else {
+      g_off[i] = off;
+      g_ci[i] = cil;
+    }
   }
 
   f32x16 acc[kMT][kNT];
@@ -166,15 +176,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
   float r_in[IN_PER_THR];
   f32x4 r_w[W_PER_THR];
 
+  unsigned woff[W_PER_THR];  // (EXACT path) element offset of this thread's weight float4 inside a chunk's rows
+  if (EXACT) {
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i) {
+      const int f = tid + i * NTHR;
+      const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
+      woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4);
+    }
+  }
+  unsigned pend = 0;  // (generic path) validity bits of the chunk in flight
   auto issue_loads = [&](int c) {
+    if (EXACT) {
+      const float* ib = in_b + (size_t)c * CK * src_plane;
+#pragma unroll
+      for (int i = 0; i < IN_PER_THR; ++i) r_in[i] = ib[goff[i]];  // padding is masked at commit time
+      const float* wb = a.w + (size_t)c * W_ROWS * a.CoutPad;
+#pragma unroll
+      for (int i = 0; i < W_PER_THR; ++i) r_w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+      return;
+    }
     const int ci0 = c * CK;
 #pragma unroll
     for (int i = 0; i < IN_PER_THR; ++i) {
       // unconditional load from a clamped (always valid) address, then select: no branches
       const int ci = ci0 + g_ci[i];
       const bool ok = g_off[i] >= 0 && ci < a.Cin;
-      const float v = in_b[(size_t)(ci < a.Cin ? ci : a.Cin - 1) * src_plane + (g_off[i] >= 0 ? g_off[i] : 0)];
-      r_in[i] = ok ? v : 0.0f;
+      r_in[i] = in_b[(size_t)(ci < a.Cin ? ci : a.Cin - 1) * src_plane + (g_off[i] >= 0 ? g_off[i] : 0)];
+      pend = (pend & ~(1u << i)) | ((ok ? 1u : 0u) << i);
     }
     const int krow0 = c * W_ROWS;
 #pragma unroll
@@ -187,11 +216,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs
       r_w[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + rr) * a.CoutPad + co0 + c4 * 4);
     }
   };
+  // The zero for padding / channel-tail elements is selected here, when the value is consumed: a select
+  // right after the load would make the wave wait for the load before it starts the MFMAs the load is
+  // meant to fly under.
   auto commit_loads = [&]() {
+    const unsigned m = EXACT ? okmask : pend;
 #pragma unroll
     for (int i = 0; i < IN_PER_THR; ++i) {
       const int e = tid + i * NTHR;
-      if (e < IN_ELEMS) in_tile[e] = r_in[i];
+      if (e < IN_ELEMS) in_tile[e] = ((m >> i) & 1u) ? r_in[i] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < W_PER_THR; ++i) {
@@ -336,8 +369,12 @@ struct TileCfg {
 
 template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
 void launch(const ConvArgs& a, int B, hipStream_t s) {
+  // the offset-table reload (EXACT) is used where it measured faster (bench.py --layer-table, B=32): every
+  // 3x3 tile except 11x22, whose 768-workgroup launches on the 256-channel heads ran 20 % slower with it
+  const bool exact = (a.Cin % CK) == 0 && KS == 3 && !(TH == 11 && TW == 22);
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
-  hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL>), grid, dim3(WM * WN * 64), 0, s, a);
+  if (exact) hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, true>), grid, dim3(WM * WN * 64), 0, s, a);
+  else hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, false>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
 // waste = slots launched / pixels useful, for picking a tile shape per layer
