@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--log-assignment", action="store_true", help="also materialise log_assignment (reference-complete matcher dict)")
     ap.add_argument("--dense", action="store_true", help="also materialise the dense descriptor maps (reference-complete dict)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--cpu-pairs", type=int, default=None, help="pairs of the CPU baseline sample (default: ~10-20 s of host work)")
     ap.add_argument("--with-metrics", action="store_true", help="also compute MR/MMA/VDD on the device each step (metrics.hip) and all-reduce their sums")
     ap.add_argument("--layer-table", action="store_true", help="tuning aid: time every conv layer of both extractors standalone and exit")
     ap.add_argument("--kernel-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
@@ -182,7 +182,7 @@ def main():
     value = stats["pairs"] / elapsed
 
     # ---- roofline of the dominant kernel: the second backbone conv (64->64 at full resolution) ----------
-    # SP-shaped nets: conv_block_kernel<3,8,32,2,4,1,2,8,true> (conv1b, fused pool); SiLK: same tile, no pool.
+    # SP-shaped nets: conv_block_kernel<3,8,32,2,4,1,2,8,true,true> (conv1b, fused pool, offset-table reloads); SiLK: same tile, no pool.
     roofline = None
     if rank == 0:
         ext = model.image_extractor.extractor
@@ -208,7 +208,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv1b.json")
         if args.config == "sp_mnn" and B == 32 and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]  # FETCH_SIZE+WRITE_SIZE, separate --pmc passes
-        kname = f"conv_block_kernel<3,8,32,2,4,1,2,8,{'true' if l1.pool else 'false'}> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
+        kname = f"conv_block_kernel<3,8,32,2,4,1,2,8,{'true' if l1.pool else 'false'},true> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
         roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "launch_ms": round(dur * 1e3, 4),
                     "flop_per_launch": flops,
@@ -218,7 +218,8 @@ def main():
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        nb = args.cpu_pairs
+        nb = args.cpu_pairs if args.cpu_pairs else {"sp_mnn": 32, "sp_lg": 4, "silk_mnn": 4}.get(args.config, 4)
+        nb = max(1, min(nb, B))
         sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
         et, it = cfg.event_extractor.type, cfg.image_extractor.type
         escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
