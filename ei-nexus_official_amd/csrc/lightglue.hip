@@ -56,7 +56,7 @@ __global__ void lg_posenc_kernel(const float* kpts, const int32_t* cnt, int cap,
 // ------------------------------------------------------------------------------------------
 // batched Linear: Y[b,i,:] = cat(X[b,i,:], X2[b,i,:]) @ W^T + bias  (+ epilogue)
 // ------------------------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_DIV = 1, EPI_RESID = 2 };
+enum { EPI_BIAS = 0, EPI_DIV = 1, EPI_RESID = 2, EPI_ROPE = 3 };
 
 struct GemmArgs {
   const float* X;
@@ -67,6 +67,11 @@ struct GemmArgs {
   const int32_t* cnt;  // per-batch row counts, or null: every batch has `cap` rows
   int cap, ldx, ldx2, Ksplit, K, N, ldy, B;
   float div;
+  // EPI_ROPE (the Wqkv projection of SelfBlock, lightglue.py:252-272): W rows are laid out (head, dim, 3);
+  // the tile list walks them as three 256-column blocks q | k | v (row stride 3 in W), applies the cached
+  // rotary encoding to q and k in the epilogue and writes the three [B,cap,256] buffers directly
+  const float* enc;  // [B,cap,128]: cos(64) | sin(64)
+  float *Yq, *Yk, *Yv;
 };
 
 // Persistent workgroups: the launch holds as many workgroups as the chip runs at once (a multiple
@@ -91,14 +96,22 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
     if (ti * BM >= n) return false;
     s.A = g.X + (size_t)b * g.cap * g.ldx;
     s.A2 = g.X2 ? g.X2 + (size_t)b * g.cap * g.ldx2 : nullptr;
-    s.B = g.W;
     s.lda = g.ldx;
     s.lda2 = g.ldx2;
-    s.ldb = g.K;
     s.i0 = ti * BM;
     s.Mvalid = n;
-    s.j0 = (L % tilesN) * BN;
-    s.Nvalid = g.N;
+    if (EPI == EPI_ROPE) {  // tile tj: block t = tj / 2 of (q, k, v), columns hc0.. of that block = W rows (hc0 + r) * 3 + t
+      const int tj = L % tilesN;
+      s.B = g.W + (size_t)(tj >> 1) * g.K;
+      s.ldb = 3 * g.K;
+      s.j0 = (tj & 1) * BN;
+      s.Nvalid = 256;
+    } else {
+      s.B = g.W;
+      s.ldb = g.K;
+      s.j0 = (L % tilesN) * BN;
+      s.Nvalid = g.N;
+    }
     bb = b;
     nn = n;
     return true;
@@ -117,6 +130,56 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
     Frag f;
     tile_nt_run(cur, g.K, g.Ksplit, lds, f, st, nxt, more);
     const int i0 = cur.i0, j0 = cur.j0;
+    if (EPI == EPI_ROPE) {
+      const int t = (int)((cur.B - g.W) / g.K);  // 0: q, 1: k, 2: v
+      float* Yt = (t == 0 ? g.Yq : t == 1 ? g.Yk : g.Yv) + (size_t)b * g.cap * 256;
+      const float* encb = g.enc + (size_t)b * g.cap * 128;
+      const bool odd = threadIdx.x & 1;  // column parity == lane parity (col_of(nt) = 64*wn + 32*nt + lane%32)
+      float bq[NT];
+      int hc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        hc[nt] = j0 + col_of(nt);
+        bq[nt] = g.bias[hc[nt] * 3 + t];
+      }
+      // rows go in batches of 4: the 16 cos/sin loads of a batch are issued together, ahead of its stores
+      // (the compiler cannot move a load above an earlier store through plain float pointers)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+          float cs[4][NT], sn[4][NT];
+          if (t < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = i0 + row_of(mt, r0 + r);
+              const float* e = encb + (size_t)(i < n ? i : n - 1) * 128;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                cs[r][nt] = e[hc[nt] & 63];
+                sn[r][nt] = e[64 + (hc[nt] & 63)];
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + row_of(mt, r0 + r);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              float v = f.acc[mt][nt][r0 + r] + bq[nt];
+              const float partner = __shfl_xor(v, 1, 64);  // the other element of the rotary pair (adjacent column)
+              if (t < 2) v = (v * cs[r][nt]) + ((odd ? partner : -partner) * sn[r][nt]);  // rotate_half: (x0,x1) -> (-x1,x0), lightglue.py:151-158
+              if (i < n) Yt[(size_t)i * 256 + hc[nt]] = v;
+            }
+          }
+        }
+      if (!more) break;
+      cur = nxt;
+      b = nb;
+      n = nn;
+      L = Ln;
+      continue;
+    }
     float* Y = g.Y + (size_t)b * g.cap * g.ldy;
     // epilogue: the bias of a lane's NT columns is loaded once; whole tiles take a guard-free path so
     // that the residual loads / stores of all 16*MT rows are issued back to back instead of one
@@ -182,28 +245,6 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
     n = nn;
     L = Ln;
   }
-}
-
-// qkv [B,cap,768] with feature (h*64+c)*3+t  ->  q,k (rotary applied), v as [B,cap,256]
-__global__ void lg_rope_split_kernel(const float* qkv, const float* enc, const int32_t* cnt, int cap, float* q, float* k, float* v) {
-  const int b = blockIdx.y;
-  const int n = min(cnt[b], cap);
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // token * 128 + pair index
-  const int i = t >> 7, pidx = t & 127;
-  if (i >= n) return;
-  const int hc = pidx * 2;  // even channel in 0..255 (h*64 + c)
-  const int c = hc & 63;
-  const float* src = qkv + ((size_t)b * cap + i) * 768 + (size_t)hc * 3;
-  const float* e = enc + ((size_t)b * cap + i) * 128;
-  const float c0 = e[c], c1 = e[c + 1], s0 = e[64 + c], s1 = e[64 + c + 1];
-  const size_t o = ((size_t)b * cap + i) * D + hc;
-  const float q0 = src[0], q1 = src[3], k0 = src[1], k1 = src[4];
-  q[o] = (q0 * c0) + ((-q1) * s0);
-  q[o + 1] = (q1 * c1) + (q0 * s1);
-  k[o] = (k0 * c0) + ((-k1) * s0);
-  k[o + 1] = (k1 * c1) + (k0 * s1);
-  v[o] = src[2];
-  v[o + 1] = src[5];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -471,12 +512,12 @@ struct Side {
   const float* desc;
   const int32_t* cnt;
   int cap;
-  float *x, *enc, *qkv, *q, *k, *v, *ctx, *msg, *h, *cert, *dust;
+  float *x, *enc, *q, *k, *v, *ctx, *msg, *h, *cert, *dust;
 };
 
 size_t side_bytes(int B, int cap) {
   const size_t tok = (size_t)B * cap;
-  return al(tok * D * 4) + al(tok * 128 * 4) + al(tok * 768 * 4) + 3 * al(tok * D * 4) + 2 * al(tok * D * 4) + al(tok * 512 * 4) + 2 * al(tok * 4);
+  return al(tok * D * 4) + al(tok * 128 * 4) + 3 * al(tok * D * 4) + 2 * al(tok * D * 4) + al(tok * 512 * 4) + 2 * al(tok * 4);
 }
 
 char* carve_side(Side& s, char* p, int B, int cap) {
@@ -484,7 +525,6 @@ char* carve_side(Side& s, char* p, int B, int cap) {
   auto take = [&](size_t bytes) { float* r = (float*)p; p += al(bytes); return r; };
   s.x = take(tok * D * 4);
   s.enc = take(tok * 128 * 4);
-  s.qkv = take(tok * 768 * 4);
   s.q = take(tok * D * 4);
   s.k = take(tok * D * 4);
   s.v = take(tok * D * 4);
@@ -535,6 +575,33 @@ int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx,
   if (epi == EPI_BIAS) hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, st, g);
   else if (epi == EPI_DIV) hipLaunchKernelGGL(lg_gemm_kernel<EPI_DIV>, grid, dim3(THREADS), 0, st, g);
   else hipLaunchKernelGGL(lg_gemm_kernel<EPI_RESID>, grid, dim3(THREADS), 0, st, g);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// fused Wqkv projection + rotary split: X [B,cap,256] -> q, k (rotary applied), v, each [B,cap,256]
+int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const float* X, const float* Wqkv, const float* bqkv, float* q, float* k, float* v) {
+  GemmArgs g{};
+  g.X = X;
+  g.X2 = nullptr;
+  g.W = Wqkv;
+  g.bias = bqkv;
+  g.Y = nullptr;
+  g.cnt = s.cnt;
+  g.cap = s.cap;
+  g.ldx = D;
+  g.ldx2 = 0;
+  g.Ksplit = 0x7fffffff;
+  g.K = D;
+  g.N = 3 * D;
+  g.ldy = D;
+  g.div = 1.0f;
+  g.B = B;
+  g.enc = s.enc;
+  g.Yq = q;
+  g.Yk = k;
+  g.Yv = v;
+  const dim3 grid(gemm_grid(einx_cdiv(3 * D, BN) * einx_cdiv(s.cap, BM) * B));
+  hipLaunchKernelGGL(lg_gemm_kernel<EPI_ROPE>, grid, dim3(THREADS), 0, st, g);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -661,10 +728,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
     const einx_lg_layer& L = w->layers[li];
     for (int sd = 0; sd < 2; ++sd) {
       Side& s = *sides[sd];
-      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqkv, L.bqkv, 3 * D, s.qkv, 3 * D));
-      hipLaunchKernelGGL(lg_rope_split_kernel, dim3((unsigned)einx_cdiv(s.cap * 128, 256), (unsigned)B), dim3(256), 0, st, s.qkv, s.enc, s.cnt,
-                         s.cap, s.q, s.k, s.v);
-      LG_CHECK(0);
+      LG_CHECK(gemm_qkv_rope(st, s, B, s.x, L.Wqkv, L.bqkv, s.q, s.k, s.v));
       LG_CHECK(attn(st, B, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
       if (L.Wo) {
         LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
