@@ -216,7 +216,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port, not the reference files) on the host cores, bounded sample ----
     cpu_baseline = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         from oracle import oracle as orc
         nb = args.cpu_pairs if args.cpu_pairs else {"sp_mnn": 32, "sp_lg": 4, "silk_mnn": 4}.get(args.config, 4)
         nb = max(1, min(nb, B))

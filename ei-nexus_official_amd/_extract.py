@@ -86,12 +86,7 @@ class BatchedFeats:
             out["normalized_descriptors"] = nd
             C = nd.shape[1]
             out["dense_descriptors"] = [nd[b].permute(1, 2, 0).reshape(-1, C) for b in range(self.B)]
-            ys = torch.arange(H, device=dev, dtype=torch.float32) + 0.5
-            xs = torch.arange(W, device=dev, dtype=torch.float32) + 0.5
-            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
-            first, second = (gy, gx) if self.ordering == "yx" else (gx, gy)
-            sc = out["score"]
-            out["dense_positions"] = [torch.stack([first, second, sc[b, 0]], -1).reshape(-1, 3) for b in range(self.B)]
+            out["dense_positions"] = list(N.dense_positions(out["score"], self.ordering).unbind(0))
         # speculative per-image lists for the common case that every image fills its top-k quota
         # (checked against the real counts in materialize)
         self._full_lists = (self.det, list(self.sparse_desc.unbind(0)), list(self.det.positions.unbind(0)))

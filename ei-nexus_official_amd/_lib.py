@@ -83,6 +83,7 @@ SIGNATURES = {
     "einx_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "einx_similarity": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "einx_normalize_keypoints": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "einx_dense_positions": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "einx_compact_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "einx_random_positions": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
 }

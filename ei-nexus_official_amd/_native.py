@@ -130,6 +130,15 @@ def score_map(logits, mask=None, pads=(0, 0, 0, 0), dilate=False, border=0):
     return prob, score
 
 
+def dense_positions(score, ordering="yx"):
+    """score [B,1,H,W] (unpadded) -> [B,H*W,3] dense keypoint list (get_dense_positions)."""
+    _dev_check(score)
+    B, _, H, W = score.shape
+    out = torch.empty((B, H * W, 3), dtype=F32, device=score.device)
+    check(lib().einx_dense_positions(_ptr(score), B, H, W, int(ordering == "xy"), _ptr(out), _stream(score)), "einx_dense_positions")
+    return out
+
+
 def remove_border(score, border):
     _dev_check(score)
     B = score.shape[0]

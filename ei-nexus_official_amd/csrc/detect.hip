@@ -100,6 +100,20 @@ __global__ void score1_kernel(const float* logits, int B, int Hp, int Wp, const 
   score[gid] = v;
 }
 
+// get_dense_positions (detector_util.py:504-519) on an unpadded map: row p of image b = (y+0.5, x+0.5, score)
+// in "yx" ordering, (x+0.5, y+0.5, score) in "xy"
+__global__ void dense_positions_kernel(const float* score, int B, int H, int W, int xy, float* out) {
+  const size_t n = (size_t)B * H * W;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const int p = (int)(gid % ((size_t)H * W));
+  const float fy = (float)(p / W) + 0.5f, fx = (float)(p % W) + 0.5f;
+  float* o = out + gid * 3;
+  o[0] = xy ? fx : fy;
+  o[1] = xy ? fy : fx;
+  o[2] = score[gid];
+}
+
 __global__ void border_kernel(float* score, int B, int Hp, int Wp, int border) {
   const int n = Hp * Wp;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,6 +614,15 @@ EINX_EXPORT int einx_remove_border(float* score, int B, int Hp, int Wp, int bord
   if (border <= 0) return EINX_OK;
   const int n = B * Hp * Wp;
   hipLaunchKernelGGL(border_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, score, B, Hp, Wp, border);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_dense_positions(const float* score, int B, int H, int W, int ordering_xy, float* out, void* stream) {
+  EINX_CHECK_ARG(score && out, "null pointer");
+  EINX_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad shape");
+  const size_t n = (size_t)B * H * W;
+  hipLaunchKernelGGL(dense_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, score, B, H, W, ordering_xy, out);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

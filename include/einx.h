@@ -90,6 +90,10 @@ int einx_score_map(const float* logits, int B, int C, int hc, int wc, const uint
 /* remove_border_points alone, in place on [B,Hp,Wp] (detector_util.py:138-164) */
 int einx_remove_border(float* score, int B, int Hp, int Wp, int border, void* stream);
 
+/* get_dense_positions (core/modules/utils/detector_util.py:504-519) for an unpadded score map
+ * [B,1,H,W]: out [B,H*W,3] = (y+0.5, x+0.5, score) ("yx") or (x+0.5, y+0.5, score) ("xy") */
+int einx_dense_positions(const float* score, int B, int H, int W, int ordering_xy, float* out, void* stream);
+
 typedef struct einx_detect_params {
   int32_t B, Hp, Wp;     /* padded map */
   int32_t H, W, h0, w0;  /* unpadded size and top/left padding (Padder) */

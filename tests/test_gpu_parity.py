@@ -210,6 +210,24 @@ def test_normalize_map_tiles_and_channels_last_sampler(oracle, shape):
             assert np.array_equal(got[b, :len(idx[b])], exp[b]), (use_cl, b)
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 5, 7, 40, 56, (2, 3, 35, 50)),      # scale 1/8 with a crop window
+    (1, 256, 33, 44, 264, 352, (2, 3, 260, 346)),  # the shipped geometry
+    (2, 7, 5, 7, 33, 47, (0, 0, 33, 47)),       # non-integer scale, no crop
+    (1, 9, 5, 7, 10, 14, (1, 2, 8, 11)),        # x2
+    (1, 5, 6, 70, 120, 140, (3, 1, 110, 139)),  # 1/20 vertically: bands taller than one sweep; several column blocks
+    (1, 4, 8, 9, 8, 9, (0, 0, 8, 9)),           # identity size
+], ids=lambda c: "x".join(map(str, c[:6])))
+def test_upsample_normalize_bands(oracle, case):
+    """upsample_descriptors + normalize + crop (dense outputs): band-wise kernel == per-pixel oracle, bit for bit."""
+    B, D, hc, wc, Hp, Wp, (h0, w0, H, W) = case
+    raw = synth.normalish(900 + D + hc, (B, D, hc, wc))
+    got = _np(pkg.native.upsample_normalize(_t(raw), (Hp, Wp), (w0, Wp - w0 - W, h0, Hp - h0 - H), 1.25))
+    exp = oracle.upsample_normalize(raw, (Hp, Wp), 1.25)[:, :, h0:h0 + H, w0:w0 + W]
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+
+
 # ------------------------------------------------------------------ MNN
 MNN = Golden("mnn")
 
