@@ -136,10 +136,13 @@ __global__ void border_kernel(float* score, int B, int Hp, int Wp, int border) {
 // raises flags[b][it] if it zeroes any non-zero pixel.  When a pass changes nothing src == dst, so
 // skipped passes leave both ping-pong buffers holding the fix-point.
 // ------------------------------------------------------------------------------------------
-constexpr int NMS_TH = 32, NMS_TW = 64, NMS_MAXR = 4;
+#ifndef EINX_NMS_THREADS
+#define EINX_NMS_THREADS 512
+#endif
+constexpr int NMS_TH = 32, NMS_TW = 64, NMS_MAXR = 4, NMS_THREADS = EINX_NMS_THREADS;
 
 template <int R>
-__global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
+__global__ __launch_bounds__(NMS_THREADS) void nms_pass_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
                                                        int32_t* flags, int it, int nIt) {
   constexpr int VH = NMS_TH + 4 * R, VW = NMS_TW + 4 * R;  // values: tile + halo 2R
   constexpr int MH = NMS_TH + 2 * R, MW = NMS_TW + 2 * R;  // is-max: tile + halo R
@@ -161,13 +164,13 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* 
   const int y0 = tyi * NMS_TH, x0 = txi * NMS_TW;
   const int tid = threadIdx.x;
   if (tid == 0) changed = 0;
-  for (int i = tid; i < VH * VW; i += 256) {
+  for (int i = tid; i < VH * VW; i += NMS_THREADS) {
     const int y = y0 - 2 * R + i / VW, x = x0 - 2 * R + i % VW;
     vals[i] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? s[(size_t)y * Wp + x] : 0.0f;
   }
   __syncthreads();
   // A: row-wise window maximum for every staged row, columns of the is-max grid
-  for (int i = tid; i < VH * MW; i += 256) {
+  for (int i = tid; i < VH * MW; i += NMS_THREADS) {
     const int vy = i / MW, mx = i % MW;
     const float* row = vals + vy * VW + mx;  // window = row[0 .. 2R], centre row[R]
     float m = row[0];
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* 
   }
   __syncthreads();
   // B: is-max on tile + halo R
-  for (int i = tid; i < MH * MW; i += 256) {
+  for (int i = tid; i < MH * MW; i += NMS_THREADS) {
     const int my = i / MW, mx = i % MW;
     const int vy = my + R;
     const float* row = vals + vy * VW + mx;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* 
   }
   __syncthreads();
   // C: row-wise OR of is-max for the tile's columns
-  for (int i = tid; i < MH * NMS_TW; i += 256) {
+  for (int i = tid; i < MH * NMS_TW; i += NMS_THREADS) {
     const int my = i / NMS_TW, tx = i % NMS_TW;
     const uint8_t* row = ismax + my * MW + tx;  // window row[0 .. 2R]
     unsigned o = 0;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* src, float* 
   __syncthreads();
   // D: suppress
   int my_changed = 0;
-  for (int i = tid; i < NMS_TH * NMS_TW; i += 256) {
+  for (int i = tid; i < NMS_TH * NMS_TW; i += NMS_THREADS) {
     const int ty = i / NMS_TW, tx = i % NMS_TW;
     const int y = y0 + ty, x = x0 + tx;
     if (y >= Hp || x >= Wp) continue;
@@ -487,20 +490,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
     return;
   }
   // ---- threshold from the order statistics ------------------------------------------------------
+  // sorted[lo] by a 4-pass radix select on the candidates (the 256-bin histogram is scanned by 256 threads,
+  // not by one); sorted[hi], hi <= lo + 1, is then either the same value (duplicates / zeros reach rank
+  // hi) or the smallest candidate above it: one counting pass instead of a second radix select.
   float thr = a.det_thr;
   if (a.top_k > 0) {
     float tk = 0.0f;
     if (a.top_k < N) {
       const int zeros = N - nz;  // all candidates are > 0, so zeros occupy ranks [0, zeros)
-      float vq[2] = {0.0f, 0.0f};
-      for (int w = 0; w < 2; ++w) {
-        const int rank_all = w == 0 ? a.lo : a.hi;
-        if (w == 1 && a.hi == a.lo) {
-          vq[1] = vq[0];
-          break;
-        }
-        if (rank_all < zeros) continue;  // value 0
-        unsigned prefix = 0, rank = (unsigned)(rank_all - zeros);
+      float v0 = 0.0f;
+      if (a.lo >= zeros) {
+        unsigned prefix = 0, rank = (unsigned)(a.lo - zeros);
         for (int pass = 0; pass < 4; ++pass) {
           const int shift = 24 - 8 * pass;
           for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
@@ -511,28 +511,62 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
             if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
           }
           __syncthreads();
-          if (tid == 0) {
-            unsigned run = 0;
-            int dsel = 255;
-            for (int dgt = 0; dgt < 256; ++dgt) {
-              const unsigned c = hist[dgt];
-              if (rank < run + c) {
-                dsel = dgt;
-                break;
-              }
-              run += c;
+          // parallel bin scan: thread d < 256 owns bin d
+          const unsigned c = tid < 256 ? hist[tid] : 0u;
+          unsigned incl = c;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+          }
+          if (lane == 63 && wave < 4) scratch[wave] = (int)incl;
+          __syncthreads();
+          if (tid < 256) {
+            unsigned basew = 0;
+            for (int w = 0; w < wave; ++w) basew += (unsigned)scratch[w];
+            const unsigned excl = basew + incl - c;
+            if ((rank >= excl && rank < excl + c) || (tid == 255 && rank >= excl + c)) {  // the last bin also catches an out-of-range rank
+              sh_pre = prefix | ((unsigned)tid << shift);
+              sh_rk = rank - excl;
             }
-            sh_pre = prefix | ((unsigned)dsel << shift);
-            sh_rk = rank - run;
           }
           __syncthreads();
           prefix = sh_pre;
           rank = sh_rk;
           __syncthreads();
         }
-        vq[w] = einx_ordered_unkey(prefix);
+        v0 = einx_ordered_unkey(prefix);
       }
-      tk = vq[1] - (vq[1] - vq[0]) * 0.5f;
+      float v1 = v0;
+      if (a.hi != a.lo) {
+        int le = 0;
+        float mn = einx_u2f(0x7f800000u);
+        for (int i = tid; i < nz; i += SEL_THREADS) {
+          const float v = cval[i];
+          le += v <= v0 ? 1 : 0;
+          if (v > v0) mn = fminf(mn, v);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          le += __shfl_xor(le, off, 64);
+          mn = fminf(mn, __shfl_xor(mn, off, 64));
+        }
+        __syncthreads();
+        if (lane == 0) {
+          scratch[wave] = le;
+          hist[wave] = einx_f2u(mn);
+        }
+        __syncthreads();
+        int le_all = zeros;
+        float mn_all = einx_u2f(0x7f800000u);
+        for (int w = 0; w < NWAVES; ++w) {
+          le_all += scratch[w];
+          mn_all = fminf(mn_all, einx_u2f(hist[w]));
+        }
+        __syncthreads();
+        if (a.hi >= le_all) v1 = mn_all;  // rank hi lies beyond every value <= v0
+      }
+      tk = v1 - (v1 - v0) * 0.5f;
     }
     thr = fminf(tk, a.det_thr);
   }
@@ -568,16 +602,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
     base += total;
   }
   if (tid == 0) a.counts[b] = base;
-  // ---- thresholded map, cropped to the unpadded window ------------------------------------------------
-  if (a.nms_out) {
-    const int HW = a.H * a.W;
-    float* o = a.nms_out + (size_t)b * HW;
-    for (int i = tid; i < HW; i += SEL_THREADS) {
-      const int uy = i / a.W, ux = i % a.W;
-      const float v = m[(size_t)(uy + a.h0) * a.Wp + ux + a.w0];
-      o[i] = v > thr ? v : 0.0f;
-    }
-  }
+}
+
+// thresholded NMS map, cropped to the unpadded window (the `nms` output): nms_out[b,y,x] = v > thr[b] ? v : 0
+__global__ void nms_crop_kernel(const float* map, const float* thr, int B, int Hp, int Wp, int h0, int w0, int H, int W, float* out) {
+  const size_t n = (size_t)B * H * W;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const int b = (int)(gid / ((size_t)H * W));
+  const int r = (int)(gid % ((size_t)H * W));
+  const float v = map[((size_t)b * Hp + (r / W + h0)) * Wp + r % W + w0];
+  out[gid] = v > thr[b] ? v : 0.0f;
 }
 
 void topk_ranks(int N, int k, int* lo, int* hi) {
@@ -659,10 +694,10 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
     for (int it = 0; it < nIt; ++it) {
       float* dst = (it & 1) ? buf1 : buf0;
       switch (p->radius) {
-        case 1: hipLaunchKernelGGL(nms_pass_kernel<1>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
-        case 2: hipLaunchKernelGGL(nms_pass_kernel<2>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
-        case 3: hipLaunchKernelGGL(nms_pass_kernel<3>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
-        default: hipLaunchKernelGGL(nms_pass_kernel<4>, grid, dim3(256), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        case 1: hipLaunchKernelGGL(nms_pass_kernel<1>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        case 2: hipLaunchKernelGGL(nms_pass_kernel<2>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        case 3: hipLaunchKernelGGL(nms_pass_kernel<3>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        default: hipLaunchKernelGGL(nms_pass_kernel<4>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
       }
       EINX_CHECK_LAUNCH();
       cur = dst;
@@ -691,6 +726,12 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
   a.lo = a.hi = 0;
   if (p->top_k > 0 && p->top_k < N) topk_ranks(N, p->top_k, &a.lo, &a.hi);
   hipLaunchKernelGGL(select_compact_kernel, dim3(p->B), dim3(SEL_THREADS), 0, s, a);
+  if (nms_out) {
+    EINX_CHECK_LAUNCH();
+    const size_t n = (size_t)p->B * p->H * p->W;
+    hipLaunchKernelGGL(nms_crop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.map, thr, p->B, p->Hp, p->Wp, p->h0, p->w0, p->H, p->W,
+                       nms_out);
+  }
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }
