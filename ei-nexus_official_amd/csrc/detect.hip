@@ -164,9 +164,22 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass_kernel(const float* src,
   const int y0 = tyi * NMS_TH, x0 = txi * NMS_TW;
   const int tid = threadIdx.x;
   if (tid == 0) changed = 0;
-  for (int i = tid; i < VH * VW; i += NMS_THREADS) {
-    const int y = y0 - 2 * R + i / VW, x = x0 - 2 * R + i % VW;
-    vals[i] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? s[(size_t)y * Wp + x] : 0.0f;
+  // all of a thread's tile loads are issued before the first is consumed (clamped addresses, then select)
+  constexpr int NLOAD = (VH * VW + NMS_THREADS - 1) / NMS_THREADS;
+  float staged[NLOAD];
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int i = tid + k * NMS_THREADS;
+    const int ii = i < VH * VW ? i : 0;
+    const int y = y0 - 2 * R + ii / VW, x = x0 - 2 * R + ii % VW;
+    const bool in = y >= 0 && y < Hp && x >= 0 && x < Wp;
+    const float v = s[(size_t)(in ? y : 0) * Wp + (in ? x : 0)];
+    staged[k] = in ? v : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int i = tid + k * NMS_THREADS;
+    if (i < VH * VW) vals[i] = staged[k];
   }
   __syncthreads();
   // A: row-wise window maximum for every staged row, columns of the is-max grid
