@@ -261,7 +261,10 @@ struct AttnArgs {
   float scale;
 };
 
-constexpr int AKB = 64;   // keys staged per round
+#ifndef EINX_AKB
+#define EINX_AKB 32
+#endif
+constexpr int AKB = EINX_AKB;   // keys staged per round (32: 124 VGPRs -> three workgroups per CU; 64: 151 -> two)
 constexpr int KPITCH = 68;  // K rows padded to 68 floats: 16-byte aligned for ds_read_b128, and the 32 rows a
                             // half-wave reads start on 16 distinct 4-bank groups (conflict-free)
 
@@ -299,10 +302,11 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   float m_run = NEG, l_run = 0.0f;
 
   // K/V block staging through registers: block kb0+64 is in flight while block kb0 is consumed
-  f32x4 rk[4], rv[4];
+  constexpr int ASTG = AKB * 16 / 256;  // float4 per thread per operand per round
+  f32x4 rk[ASTG], rv[ASTG];
   auto issue = [&](int kb0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ASTG; ++i) {
       const int fidx = tid + i * 256;
       const int row = fidx >> 4, c4 = fidx & 15;
       const int key = min(kb0 + row, nk - 1);  // clamped: rows past nk are masked after the QK product
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ASTG; ++i) {
       const int fidx = tid + i * 256;
       const int row = fidx >> 4, c4 = fidx & 15;
       *reinterpret_cast<f32x4*>(Ks + row * KPITCH + c4 * 4) = rk[i];
