@@ -136,8 +136,18 @@ __global__ __launch_bounds__(256) void normalize_map_tile_kernel(const float* ra
   for (int c = cgrp; c < D; c += CG) tile[c * PT + ((px + c) & (PT - 1))] = pv ? rb[(size_t)c * P + p0 + px] : 0.0f;
   __syncthreads();
   if (tid < PT) {
+    // one lane per pixel walks the channels in order; the LDS reads of 16 channels are in flight at a time so
+    // the chain runs at fmaf latency, not at one LDS round trip per channel
     float s = 0.0f;
-    for (int c = 0; c < D; ++c) {
+    int c = 0;
+    for (; c + 16 <= D; c += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = tile[(c + u) * PT + ((tid + c + u) & (PT - 1))];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s = fmaf(v[u], v[u], s);
+    }
+    for (; c < D; ++c) {
       const float v = tile[c * PT + ((tid + c) & (PT - 1))];
       s = fmaf(v, v, s);
     }
