@@ -104,6 +104,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is the product and has no fallback. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C ei-nexus_official_amd/csrc`.")
+    # torch ships its own libamdhip64; whichever copy is loaded first serves the whole process, and device memory
+    # and streams come from torch, so its runtime has to be the one (loading ours first leaves torch's kernels and
+    # ours on different runtimes: "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
