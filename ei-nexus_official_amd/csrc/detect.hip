@@ -250,6 +250,174 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass_kernel(const float* src,
 }
 
 // ------------------------------------------------------------------------------------------
+// The same pass for R = 4 (every shipped configuration) with register tiling: a work item is eight
+// neighbouring columns of one row, read with 16-byte LDS loads, and the boolean planes are bit-packed
+// (one byte per eight columns), so a pass issues ~4x fewer LDS instructions -- the LDS pipe, shared by
+// the four resident workgroups of a CU, is what bounds the generic kernel above.  Same predicates:
+//   ismax = v > 0 && inside && max(left 4) < v && max(right 4) <= v && max(4 rows above of R9) < v
+//           && max(4 rows below of R9) <= v;   suppressed = (some ismax in the 9x9 window) && !ismax
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
+                                                                int32_t* flags, int it, int nIt) {
+  constexpr int R = 4;
+  constexpr int VH = NMS_TH + 4 * R, VW = NMS_TW + 4 * R;  // 48 x 80 values: tile + halo 2R
+  constexpr int MH = NMS_TH + 2 * R, MW = NMS_TW + 2 * R;  // 40 x 72 is-max grid: tile + halo R
+  constexpr int G = MW / 8, TG = NMS_TW / 8;               // 9 column groups of the is-max grid, 8 of the tile
+  __shared__ __attribute__((aligned(16))) float vals[VH * VW];
+  __shared__ __attribute__((aligned(16))) float r9[VH * MW];
+  __shared__ uint8_t rowok8[VH * G];   // bit k of [vy][g]: centre > 0 and row-wise conditions hold at column g*8+k
+  __shared__ uint8_t ismax8[MH * (G + 1)];
+  __shared__ uint8_t rowor8[MH * TG];
+  __shared__ int changed;
+  int bid = blockIdx.x;
+  const int txi = bid % tilesX;
+  bid /= tilesX;
+  const int tyi = bid % tilesY;
+  const int b = bid / tilesY;
+  if (it >= 2 && flags[b * nIt + it - 1] == 0) return;
+  const float* s = src + (size_t)b * Hp * Wp;
+  float* d = dst + (size_t)b * Hp * Wp;
+  const int y0 = tyi * NMS_TH, x0 = txi * NMS_TW;
+  const int tid = threadIdx.x;
+  if (tid == 0) changed = 0;
+  constexpr int NLOAD = (VH * VW + NMS_THREADS - 1) / NMS_THREADS;
+  float staged[NLOAD];
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int i = tid + k * NMS_THREADS;
+    const int ii = i < VH * VW ? i : 0;
+    const int y = y0 - 2 * R + ii / VW, x = x0 - 2 * R + ii % VW;
+    const bool in = y >= 0 && y < Hp && x >= 0 && x < Wp;
+    const float v = s[(size_t)(in ? y : 0) * Wp + (in ? x : 0)];
+    staged[k] = in ? v : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const int i = tid + k * NMS_THREADS;
+    if (i < VH * VW) vals[i] = staged[k];
+  }
+  __syncthreads();
+  // A: per row and column group: R9 (9-wide row maximum) and the row-wise part of the is-max test
+  if (tid < VH * G) {
+    const int vy = tid / G, g = tid % G;
+    float v[16];
+    const float* row = vals + vy * VW + g * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q);
+      v[4 * q] = t[0];
+      v[4 * q + 1] = t[1];
+      v[4 * q + 2] = t[2];
+      v[4 * q + 3] = t[3];
+    }
+    float m9[8];
+    unsigned ok = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float left = v[k], right = v[k + 5];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) {
+        left = fmaxf(left, v[k + t]);
+        right = fmaxf(right, v[k + 5 + t]);
+      }
+      const float c = v[k + 4];
+      m9[k] = fmaxf(fmaxf(left, right), c);
+      ok |= (c > 0.0f && left < c && right <= c) ? (1u << k) : 0u;
+    }
+    float* o = r9 + vy * MW + g * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{m9[0], m9[1], m9[2], m9[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{m9[4], m9[5], m9[6], m9[7]};
+    rowok8[tid] = (uint8_t)ok;
+  }
+  __syncthreads();
+  // B: column-wise part on the is-max grid (rows my = 0..39 <-> vy = my + 4)
+  if (tid < MH * G) {
+    const int my = tid / G, g = tid % G;
+    const int vy = my + R;
+    float above[8], below[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) above[k] = below[k] = 0.0f;
+#pragma unroll
+    for (int dy = 1; dy <= R; ++dy) {
+      const float* ra = r9 + (vy - dy) * MW + g * 8;
+      const float* rb = r9 + (vy + dy) * MW + g * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ra), a1 = *reinterpret_cast<const f32x4*>(ra + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(rb), b1 = *reinterpret_cast<const f32x4*>(rb + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        above[k] = dy == 1 ? a0[k] : fmaxf(above[k], a0[k]);
+        above[k + 4] = dy == 1 ? a1[k] : fmaxf(above[k + 4], a1[k]);
+        below[k] = dy == 1 ? b0[k] : fmaxf(below[k], b0[k]);
+        below[k + 4] = dy == 1 ? b1[k] : fmaxf(below[k + 4], b1[k]);
+      }
+    }
+    const float* crow = vals + vy * VW + g * 8 + R;
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow), c1 = *reinterpret_cast<const f32x4*>(crow + 4);
+    const unsigned rok = rowok8[vy * G + g];
+    const int y = y0 - R + my;
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float c = k < 4 ? c0[k] : c1[k - 4];
+      const int x = x0 - R + g * 8 + k;
+      const bool okk = ((rok >> k) & 1u) && y >= 0 && y < Hp && x >= 0 && x < Wp && above[k] < c && below[k] <= c;
+      bits |= okk ? (1u << k) : 0u;
+    }
+    ismax8[my * (G + 1) + g] = (uint8_t)bits;
+    if (g == 0) ismax8[my * (G + 1) + G] = 0;  // pad byte read by the last tile group
+  }
+  __syncthreads();
+  // C: row-wise OR over the 9-wide window, for the tile's 64 columns (bit k of group t8: is-max columns t8*8+k .. +8)
+  if (tid < MH * TG) {
+    const int my = tid / TG, t8 = tid % TG;
+    const unsigned w = (unsigned)ismax8[my * (G + 1) + t8] | ((unsigned)ismax8[my * (G + 1) + t8 + 1] << 8) |
+                       ((unsigned)ismax8[my * (G + 1) + t8 + 2] << 16);
+    unsigned r = 0;
+#pragma unroll
+    for (int dx = 0; dx <= 2 * R; ++dx) r |= w >> dx;
+    rowor8[tid] = (uint8_t)(r & 0xFFu);
+  }
+  __syncthreads();
+  // D: column-wise OR and suppression for 8 pixels of one tile row
+  int my_changed = 0;
+  if (tid < NMS_TH * TG) {
+    const int ty = tid / TG, t8 = tid % TG;
+    unsigned o8 = 0;
+#pragma unroll
+    for (int dy = 0; dy <= 2 * R; ++dy) o8 |= rowor8[(ty + dy) * TG + t8];
+    // is-max bits of the pixels themselves: grid row ty+R, columns t8*8 + k + R
+    const unsigned iw = (unsigned)ismax8[(ty + R) * (G + 1) + t8] | ((unsigned)ismax8[(ty + R) * (G + 1) + t8 + 1] << 8);
+    const unsigned is8 = (iw >> R) & 0xFFu;
+    const unsigned sup = o8 & ~is8;
+    const float* crow = vals + (ty + 2 * R) * VW + t8 * 8 + 2 * R;
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow), c1 = *reinterpret_cast<const f32x4*>(crow + 4);
+    const int y = y0 + ty;
+    if (y < Hp) {
+      float out[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float c = k < 4 ? c0[k] : c1[k - 4];
+        const bool kill = c != 0.0f && ((sup >> k) & 1u);
+        out[k] = kill ? 0.0f : c;
+        if (kill && x0 + t8 * 8 + k < Wp) my_changed = 1;
+      }
+      float* o = d + (size_t)y * Wp + x0 + t8 * 8;
+      if (x0 + t8 * 8 + 7 < Wp && (Wp & 3) == 0) {
+        *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (x0 + t8 * 8 + k < Wp) o[k] = out[k];
+      }
+    }
+  }
+  if (my_changed) changed = 1;
+  __syncthreads();
+  if (tid == 0 && changed) atomicOr(&flags[b * nIt + it], 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // K5: per image one 1024-thread workgroup: radix select of the order statistics
 // sorted[lo], sorted[hi] (ascending), thr = min(b - (b-a)*0.5, det_thr), then raster-order
 // stream compaction of (v > thr) with wave ballots.
@@ -710,7 +878,7 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
         case 1: hipLaunchKernelGGL(nms_pass_kernel<1>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
         case 2: hipLaunchKernelGGL(nms_pass_kernel<2>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
         case 3: hipLaunchKernelGGL(nms_pass_kernel<3>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
-        default: hipLaunchKernelGGL(nms_pass_kernel<4>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
+        default: hipLaunchKernelGGL(nms_pass4_kernel, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
       }
       EINX_CHECK_LAUNCH();
       cur = dst;
