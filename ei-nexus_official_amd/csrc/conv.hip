@@ -46,7 +46,10 @@ struct ConvArgs {
 // constant per-thread element offsets from a uniform base pointer that advances with the chunk, with
 // no per-element multiplies, clamps or 64-bit address arithmetic in the steady state.
 template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool EXACT>
-__global__ __launch_bounds__(WM * WN * 64) void conv_block_kernel(const ConvArgs a) {
+#ifndef EINX_THIN_WAVES
+#define EINX_THIN_WAVES 6  // thin first layers: cap registers so three 8-wave workgroups share a CU (their load -> MFMA -> store phases only overlap across workgroups)
+#endif
+__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void conv_block_kernel(const ConvArgs a) {
   constexpr int kMT = MT, kNT = NT;
   constexpr int NW = WM * WN;
   constexpr int TAPS = KS * KS;
