@@ -449,9 +449,20 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   a.W = W;
   a.relu = d->relu;
   if (d->ks == 1) {
-    a.tilesX = einx_cdiv(H * W, 256);
+    // small maps (the 33x44 heads): 128-pixel runs double the workgroup count so that the 256 CUs hold
+    // enough waves to hide the staging latency (768 -> 1536 workgroups for 256 output channels at B=32)
+    const long blocks256 = (long)einx_cdiv(H * W, 256) * B * (a.CoutPad / kCoutTile);
+#ifndef EINX_1X1_SMALL_LIMIT
+#define EINX_1X1_SMALL_LIMIT 1024
+#endif
     a.tilesY = 1;
-    launch<1, 1, 256, 1, 4, 2, 2, 32, false>(a, B, s);
+    if (blocks256 < EINX_1X1_SMALL_LIMIT) {
+      a.tilesX = einx_cdiv(H * W, 128);
+      launch<1, 1, 128, 1, 4, 2, 1, 32, false>(a, B, s);
+    } else {
+      a.tilesX = einx_cdiv(H * W, 256);
+      launch<1, 1, 256, 1, 4, 2, 2, 32, false>(a, B, s);
+    }
     EINX_CHECK_LAUNCH();
     return EINX_OK;
   }
