@@ -140,8 +140,8 @@ def write_readme(pmc, busy):
           f"{ko[0]} launches, average {ko[1]:.3f} ms = {flop / ko[1] / 1e9:.1f} TFLOP/s.")
     A(f"* `{R}_sp_mnn_b32_kernel_stats_single_stream.csv` (`EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 "
       f"--no-cpu-baseline`): {single['Calls']} launches, average {float(single['AverageNs']) / 1e6:.3f} ms = {flop / float(single['AverageNs']) * 1e9 / 1e12:.1f} TFLOP/s. "
-      "The average mixes the 12 roofline-loop launches and the image-side layer with the event-side layer of the same shape, which carries a BatchNorm "
-      "epilogue and dense (non-ReLU-sparse) inputs and runs ~8-12 % slower at lower clocks (see DESIGN.md, data-dependent clocks).")
+      "The average mixes the roofline-loop launches and the image-side layer with the event-side layer of the same shape (dense, not ReLU-sparse, "
+      "inputs: ~2 % slower, see DESIGN.md, data-dependent clocks) and the first launches of the process, which run before the device reaches its working clocks.")
     A(f"* `{R}_sp_mnn_b32_kernel_stats.csv` (same command, default two-stream schedule): average {float(over['AverageNs']) / 1e6:.3f} ms -- "
       "the event and image extractors run concurrently, so per-kernel durations there include time-sharing of the CUs; use the single-stream file for kernel rates.")
     A(f"* `{R}_pmc_conv1b.json`: separate `--pmc` passes over `bench.py --kernel-only`: FETCH_SIZE {pmc['FETCH_SIZE_KB'] / 1024:.0f} MiB + WRITE_SIZE "
