@@ -486,6 +486,9 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     const long blocks = (long)einx_cdiv(H, cfgs[best].th) * einx_cdiv(W, cfgs[best].tw) * B * (a.CoutPad / kCoutTile);
     if (blocks < 640 && tile_waste(H, W, cfgs[4]) <= bw * 1.05 + 1e-9) best = 4;
   }
+  // an 8-wave 11x22 tile beats the 4-wave 192-slot tiles even at ~6 % more pixel slots (132x176: 3072 workgroups
+  // = six full rounds of two per CU; measured +3 % on that layer)
+  if (!d->pool && (best == 1 || best == 2) && tile_waste(H, W, cfgs[3]) <= bw * 1.06 + 1e-9) best = 3;
   a.tilesX = einx_cdiv(W, cfgs[best].tw);
   a.tilesY = einx_cdiv(H, cfgs[best].th);
   // Wave layouts (measured per layer, bench.py --layer-table): 8 waves (2 channel groups x 4 pixel
