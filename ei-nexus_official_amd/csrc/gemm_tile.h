@@ -138,23 +138,28 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
       issue_slab(next, 0, K, Ksplit, st);
     }
     // software-pipelined fragment reads: step kk+1's operands are requested before step kk's MFMAs
-    float av[2][MT], bv[2][NT];
+#ifndef EINX_GEMM_PF
+#define EINX_GEMM_PF 1
+#endif
+    constexpr int PF = EINX_GEMM_PF;  // fragment prefetch distance in K-steps
+    float av[PF + 1][MT], bv[PF + 1][NT];
     auto load_frag = [&](int kk, int buf) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
     };
-    load_frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < PF; ++kk) load_frag(kk, kk % (PF + 1));
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      if (kk + 1 < BK / 2) load_frag(kk + 1, (kk + 1) & 1);
+      if (kk + PF < BK / 2) load_frag(kk + PF, (kk + PF) % (PF + 1));
       __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][mt], bv[kk & 1][nt], f.acc[mt][nt], 0, 0, 0);
+          f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % (PF + 1)][mt], bv[kk % (PF + 1)][nt], f.acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
