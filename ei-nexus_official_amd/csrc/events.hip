@@ -6,85 +6,153 @@
 // datasets/visualize.py:23-50 (draw_events_accumulation_image) with the `> 0` mask of
 // test_events-image_same-time.py:137.
 //
-// HBM/atomic-bound integer/float scatter: one thread per event, 8 fp32 atomics (the reference's
-// put_(accumulate=True)); the count image uses integer atomics and is therefore bit-exact, the
-// voxel grid is exact up to fp32 summation order (atomics commute only approximately).
+// Scatter-add (the reference's put_(accumulate=True)): the voxel grid accumulates in LDS tiles (fp32 LDS atomics,
+// exact up to summation order), the count image uses integer global atomics and is bit-exact.
 #include "einx_common.h"
 
 namespace {
 
+// All samples of a batch go through ONE launch per stage: blockIdx.y is the sample, the device copy of the
+// offsets array (one small host-to-device copy per call) delimits its events.
 struct VoxArgs {
   const float* x;
   const float* y;
   const double* t;
   const float* p;
-  long long n;
+  const int64_t* offs;  // device [B+1]
   int bins, H, W;
-  float* grid;  // [bins,H,W] of this sample
+  float* grid;  // [B,bins,H,W]
 };
 
-__global__ void voxel_scatter_kernel(const VoxArgs a) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  // time_normalization in float64 (numpy), then float32 (torch) exactly as the reference
-  const double t0d = a.t[0], tld = a.t[a.n - 1];
-  const double den = (tld - t0d) + 1e-8;
-  const float tf = (float)((a.t[i] - t0d) / den);
-  const float tf0 = (float)(0.0 / den);
-  const float tfl = (float)((tld - t0d) / den);
-  const float tn = ((float)(a.bins - 1) * (tf - tf0)) / (tfl - tf0);
-  const float xf = a.x[i], yf = a.y[i];
-  float value = a.p[i];
-  if (value < 1.0f) value = -1.0f;
-  const int x0 = (int)xf, y0 = (int)yf, t0 = (int)tn;  // .int() truncates toward zero
+// Scatter through LDS tiles instead of global float atomics: scattered `global_atomic_add_f32` (64 lanes in 64
+// different rows) runs at ~0.08 TB/s on this chip, which made the scatter 80 % of the call.  A workgroup owns
+// `rows` image rows of one sample for all time bins (bins*rows*W floats in LDS), sweeps that sample's events
+// (reading y first and skipping events that cannot touch its rows), accumulates with LDS atomics, then writes
+// its slab with plain coalesced stores -- no memset of the grid, and the per-sample statistics of the non-zero
+// voxels come from the slab while it is still in LDS.
+__global__ __launch_bounds__(1024) void voxel_tile_kernel(const VoxArgs a, int rows, double* stats_all) {
+  extern __shared__ float tile[];  // [bins][rows][W]
+  __shared__ double sh[3][16];
+  __shared__ int wqueue[16 * 128];  // per-wave queue of event indices that touch this slab
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows;
+  const int nr = min(rows, a.H - r0);
+  const int tid = threadIdx.x;
+  const int slab = a.bins * rows * a.W;
+  for (int i = tid; i < slab; i += 1024) tile[i] = 0.0f;
+  __syncthreads();
+  const long long o0 = a.offs[b], n = a.offs[b + 1] - o0;
+  if (n > 0) {
+    const double* t = a.t + o0;
+    const double t0d = t[0], tld = t[n - 1];
+    const double den = (tld - t0d) + 1e-8;
+    const float tf0 = (float)(0.0 / den);
+    const float tfl = (float)((tld - t0d) / den);
+    // Every lane tests its events on y alone (8 loads in flight); the few that can touch this slab (rows/H of
+    // them) are appended to a per-wave LDS queue and processed 64 at a time with all lanes busy -- without
+    // the queue nearly every wave would run the whole body for every event with one or two active lanes.
+    // No workgroup barrier inside the sweep: the 16 waves run independently.
+    const int lane = tid & 63, wave = tid >> 6;
+    int* queue = wqueue + wave * 128;
+    int qn = 0;  // wave-uniform
+    auto process = [&](long long i) {
+      const float yf = a.y[o0 + i];
+      const int y0 = (int)yf;  // .int() truncates toward zero
+      // time_normalization in float64 (numpy), then float32 (torch) exactly as the reference
+      const float tf = (float)((t[i] - t0d) / den);
+      const float tn = ((float)(a.bins - 1) * (tf - tf0)) / (tfl - tf0);
+      const float xf = a.x[o0 + i];
+      float value = a.p[o0 + i];
+      if (value < 1.0f) value = -1.0f;
+      const int x0 = (int)xf, t0 = (int)tn;
 #pragma unroll
-  for (int dx = 0; dx < 2; ++dx)
+      for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int xl = x0 + dx, yl = y0 + dy, tl = t0 + dt;
-        if (xl < a.W && xl >= 0 && yl < a.H && yl >= 0 && tl >= 0 && tl < a.bins) {
-          const float w = value * (1.0f - fabsf((float)xl - xf)) * (1.0f - fabsf((float)yl - yf)) * (1.0f - fabsf((float)tl - tn));
-          atomicAdd(&a.grid[((size_t)tl * a.H + yl) * a.W + xl], w);
+          for (int dt = 0; dt < 2; ++dt) {
+            const int xl = x0 + dx, yl = y0 + dy, tl = t0 + dt;
+            if (xl < a.W && xl >= 0 && yl < r0 + nr && yl >= r0 && yl >= 0 && tl >= 0 && tl < a.bins) {
+              const float w = value * (1.0f - fabsf((float)xl - xf)) * (1.0f - fabsf((float)yl - yf)) * (1.0f - fabsf((float)tl - tn));
+              atomicAdd(&tile[(tl * rows + (yl - r0)) * a.W + xl], w);
+            }
+          }
+    };
+    for (long long ib = tid; ib - lane < n; ib += 8 * 1024) {  // the wave's lanes walk 8 x 64 consecutive events per trip
+      float yv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) yv[u] = ib + u * 1024 < n ? a.y[o0 + ib + u * 1024] : -4.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long i = ib + u * 1024;
+        const int y0 = (int)yv[u];
+        const bool hit = i < n && y0 + 1 >= r0 && y0 < r0 + nr;
+        const unsigned long long m = __ballot(hit);
+        if (m == 0) continue;
+        if (hit) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+        qn += __popcll(m);
+        if (qn >= 64) {  // wave-uniform
+          process((long long)queue[lane]);
+          qn -= 64;
+          if (lane < qn) {
+            const int v = queue[64 + lane];
+            queue[lane] = v;
+          }
         }
       }
-}
-
-// per-sample statistics over the non-zero voxels: count, sum, sum of squares (fp64)
-__global__ __launch_bounds__(256) void voxel_stats_kernel(const float* grid, long long n, double* stats /*[3]*/) {
-  __shared__ double sh[3][4];
-  double c = 0.0, s = 0.0, q = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float v = grid[i];
-    if (v != 0.0f) {
-      c += 1.0;
-      s += (double)v;
-      q += (double)v * (double)v;
     }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    c += __shfl_xor(c, off, 64);
-    s += __shfl_xor(s, off, 64);
-    q += __shfl_xor(q, off, 64);
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-    sh[0][wave] = c;
-    sh[1][wave] = s;
-    sh[2][wave] = q;
+    if (lane < qn) process((long long)queue[lane]);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&stats[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomicAdd(&stats[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-    atomicAdd(&stats[2], sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
+  float* grid = a.grid + (size_t)b * a.bins * a.H * a.W;
+  double c = 0.0, sm = 0.0, q = 0.0;
+  const int rowlen = nr * a.W;
+  for (int tb = 0; tb < a.bins; ++tb) {
+    const float* src = tile + tb * rows * a.W;
+    float* dst = grid + ((size_t)tb * a.H + r0) * a.W;
+    for (int i = tid; i < rowlen; i += 1024) {
+      const float v = src[i];
+      dst[i] = v;
+      if (v != 0.0f) {
+        c += 1.0;
+        sm += (double)v;
+        q += (double)v * (double)v;
+      }
+    }
+  }
+  if (stats_all) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      c += __shfl_xor(c, off, 64);
+      sm += __shfl_xor(sm, off, 64);
+      q += __shfl_xor(q, off, 64);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) {
+      sh[0][wave] = c;
+      sh[1][wave] = sm;
+      sh[2][wave] = q;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double c2 = 0.0, s2 = 0.0, q2 = 0.0;
+      for (int w = 0; w < 16; ++w) {
+        c2 += sh[0][w];
+        s2 += sh[1][w];
+        q2 += sh[2][w];
+      }
+      double* stats = stats_all + 4 * b;
+      atomicAdd(&stats[0], c2);
+      atomicAdd(&stats[1], s2);
+      atomicAdd(&stats[2], q2);
+    }
   }
 }
 
-// (v - mean) / std (unbiased) on the non-zero voxels; std == 0 -> only centre
-__global__ void voxel_normalize_kernel(float* grid, long long n, const double* stats) {
+// (v - mean) / std (unbiased) on the non-zero voxels; std == 0 -> only centre; grid (blocks, B)
+__global__ void voxel_normalize_kernel(float* grid_all, long long n, const double* stats_all) {
+  float* grid = grid_all + (size_t)blockIdx.y * n;
+  const double* stats = stats_all + 4 * blockIdx.y;
   const double cnt = stats[0];
   if (cnt <= 0.0) return;
   const double mean = stats[1] / cnt;
@@ -99,16 +167,21 @@ __global__ void voxel_normalize_kernel(float* grid, long long n, const double* s
   }
 }
 
-__global__ void events_count_kernel(const float* x, const float* y, long long n, int H, int W, int32_t* cnt) {
+__global__ void events_count_kernel(const float* x, const float* y, const int64_t* offs, int H, int W, int32_t* cnt_all) {
+  const int b = blockIdx.y;
+  const long long o0 = offs[b], n = offs[b + 1] - o0;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int xi = (int)x[i], yi = (int)y[i];
-  if (xi >= 0 && xi < W && yi >= 0 && yi < H) atomicAdd(&cnt[yi * W + xi], 1);
+  const int xi = (int)x[o0 + i], yi = (int)y[o0 + i];
+  if (xi >= 0 && xi < W && yi >= 0 && yi < H) atomicAdd(&cnt_all[(size_t)b * H * W + yi * W + xi], 1);
 }
 
-__global__ __launch_bounds__(256) void minmax_kernel(const int32_t* cnt, int n, int32_t* mm /*[2]: min, max*/) {
+// one 1024-thread workgroup per sample: min and max of the count image
+__global__ __launch_bounds__(1024) void minmax_kernel(const int32_t* cnt_all, int n, int32_t* mm_all /*[B][2]: min, max*/) {
+  __shared__ int slo[16], shi[16];
+  const int32_t* cnt = cnt_all + (size_t)blockIdx.x * n;
   int lo = 0x7fffffff, hi = -0x7fffffff - 1;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     lo = min(lo, cnt[i]);
     hi = max(hi, cnt[i]);
   }
@@ -118,27 +191,55 @@ __global__ __launch_bounds__(256) void minmax_kernel(const int32_t* cnt, int n, 
     hi = max(hi, __shfl_xor(hi, off, 64));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&mm[0], lo);
-    atomicMax(&mm[1], hi);
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = min(lo, slo[w]);
+      hi = max(hi, shi[w]);
+    }
+    mm_all[2 * blockIdx.x] = lo;
+    mm_all[2 * blockIdx.x + 1] = hi;
   }
 }
 
-// uint8((cnt - min) / (max - min) * 255) > 0, in float64 like numpy
-__global__ void events_mask_kernel(const int32_t* cnt, int n, const int32_t* mm, uint8_t* mask) {
+// uint8((cnt - min) / (max - min) * 255) > 0, in float64 like numpy; grid (blocks, B)
+__global__ void events_mask_kernel(const int32_t* cnt_all, int n, const int32_t* mm_all, uint8_t* mask_all) {
+  const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double lo = (double)mm[0], hi = (double)mm[1];
-  double v = ((double)cnt[i] - lo) / (hi - lo) * 255.0;  // hi == lo gives NaN like numpy -> uint8 0 ... -> mask false
+  const double lo = (double)mm_all[2 * b], hi = (double)mm_all[2 * b + 1];
+  double v = ((double)cnt_all[(size_t)b * n + i] - lo) / (hi - lo) * 255.0;  // hi == lo gives NaN like numpy -> uint8 0 ... -> mask false
   if (v > 255.0) v = 255.0;
-  mask[i] = (v == v && (int)v > 0) ? 1 : 0;
+  mask_all[(size_t)b * n + i] = (v == v && (int)v > 0) ? 1 : 0;
 }
 
 }  // namespace
 
+// workspace: [B][4] fp64 statistics | count image int32 [B,H,W] | min/max int32 [B][2] | device offsets int64 [B+1]
 EINX_EXPORT size_t einx_events_ws_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)B * 32 + (size_t)B * H * W * sizeof(int32_t) + (size_t)B * 8 + 256;
+  return (size_t)B * 32 + (size_t)B * H * W * sizeof(int32_t) + (size_t)B * 8 + ((size_t)B + 1) * 8 + 256;
 }
+
+namespace {
+// copies the host offsets to the workspace and returns the largest per-sample event count (-1 on bad input)
+long long stage_offsets(const int64_t* offsets_host, int B, int H, int W, void* ws, hipStream_t s, int64_t** dev) {
+  long long mx = 0;
+  for (int b = 0; b < B; ++b) {
+    const long long n = offsets_host[b + 1] - offsets_host[b];
+    if (n < 0) return -1;
+    mx = n > mx ? n : mx;
+  }
+  char* p = (char*)ws + (size_t)B * 32 + (size_t)B * H * W * sizeof(int32_t) + (size_t)B * 8;
+  p = (char*)(((size_t)p + 7) & ~(size_t)7);
+  *dev = (int64_t*)p;
+  if (hipMemcpyAsync(p, offsets_host, ((size_t)B + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+  return mx;
+}
+}  // namespace
 
 EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t, const float* p, const int64_t* offsets_host, int B,
                                 int bins, int H, int W, int normalize, float* grid, void* ws, void* stream) {
@@ -146,33 +247,42 @@ EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t,
   EINX_CHECK_ARG(B > 0 && bins > 0 && H > 0 && W > 0, "bad shape");
   hipStream_t s = (hipStream_t)stream;
   const size_t per = (size_t)bins * H * W;
-  double* stats = (double*)ws;  // [B][3] (+1 pad)
-  if (hipMemsetAsync(grid, 0, per * B * sizeof(float), s) != hipSuccess || hipMemsetAsync(stats, 0, (size_t)B * 32, s) != hipSuccess) {
-    einx_set_error("einx_voxel_grid: memset failed");
+  double* stats = (double*)ws;  // [B][4]
+  int64_t* offs = nullptr;
+  const long long mx = stage_offsets(offsets_host, B, H, W, ws, s, &offs);
+  EINX_CHECK_ARG(mx != -1, "offsets must be non-decreasing");
+  if (mx == -2 || hipMemsetAsync(stats, 0, (size_t)B * 32, s) != hipSuccess) {
+    einx_set_error("einx_voxel_grid: memset / copy failed");
     return EINX_ERR_LAUNCH;
   }
-  for (int b = 0; b < B; ++b) {
-    const long long n = offsets_host[b + 1] - offsets_host[b];
-    EINX_CHECK_ARG(n >= 0, "offsets must be non-decreasing");
-    if (n == 0) continue;
-    VoxArgs a;
-    a.x = x + offsets_host[b];
-    a.y = y + offsets_host[b];
-    a.t = t + offsets_host[b];
-    a.p = p + offsets_host[b];
-    a.n = n;
-    a.bins = bins;
-    a.H = H;
-    a.W = W;
-    a.grid = grid + per * b;
-    hipLaunchKernelGGL(voxel_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    EINX_CHECK_LAUNCH();
-    if (normalize) {
-      hipLaunchKernelGGL(voxel_stats_kernel, dim3(256), dim3(256), 0, s, a.grid, (long long)per, stats + 4 * b);
-      EINX_CHECK_LAUNCH();
-      hipLaunchKernelGGL(voxel_normalize_kernel, dim3(512), dim3(256), 0, s, a.grid, (long long)per, stats + 4 * b);
-      EINX_CHECK_LAUNCH();
+  VoxArgs a;
+  a.x = x;
+  a.y = y;
+  a.t = t;
+  a.p = p;
+  a.offs = offs;
+  a.bins = bins;
+  a.H = H;
+  a.W = W;
+  a.grid = grid;
+  // rows per workgroup: the slab bins*rows*W floats stays under ~68 KB (+8 KB of per-wave queues) so that two workgroups share a CU
+  int rows = (int)(17000 / ((long long)bins * W));
+  rows = rows < 1 ? 1 : (rows > H ? H : rows);
+  const size_t lds = (size_t)bins * rows * W * sizeof(float);
+  EINX_CHECK_ARG(lds <= 150 * 1024, "bins * W too large for the LDS tile scatter");
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&voxel_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      einx_set_error("einx_voxel_grid: cannot reserve %zu bytes of LDS", lds);
+      return EINX_ERR_LAUNCH;
     }
+    lds_attr = lds;
+  }
+  hipLaunchKernelGGL(voxel_tile_kernel, dim3((unsigned)einx_cdiv(H, rows), (unsigned)B), dim3(1024), lds, s, a, rows, normalize ? stats : nullptr);
+  EINX_CHECK_LAUNCH();
+  if (normalize) {
+    hipLaunchKernelGGL(voxel_normalize_kernel, dim3(128, (unsigned)B), dim3(256), 0, s, grid, (long long)per, stats);
+    EINX_CHECK_LAUNCH();
   }
   return EINX_OK;
 }
@@ -185,26 +295,20 @@ EINX_EXPORT int einx_events_mask(const float* x, const float* y, const int64_t* 
   const int n = H * W;
   int32_t* cnt = (int32_t*)((char*)ws + (size_t)B * 32);
   int32_t* mm = (int32_t*)((char*)ws + (size_t)B * 32 + (size_t)B * n * sizeof(int32_t));
-  if (hipMemsetAsync(cnt, 0, (size_t)B * n * sizeof(int32_t), s) != hipSuccess) {
-    einx_set_error("einx_events_mask: memset failed");
+  int64_t* offs = nullptr;
+  const long long mx = stage_offsets(offsets_host, B, H, W, ws, s, &offs);
+  EINX_CHECK_ARG(mx != -1, "offsets must be non-decreasing");
+  if (mx == -2 || hipMemsetAsync(cnt, 0, (size_t)B * n * sizeof(int32_t), s) != hipSuccess) {
+    einx_set_error("einx_events_mask: memset / copy failed");
     return EINX_ERR_LAUNCH;
   }
-  for (int b = 0; b < B; ++b) {
-    const int32_t init[2] = {0x7fffffff, -0x7fffffff - 1};
-    if (hipMemcpyAsync(mm + 2 * b, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) {
-      einx_set_error("einx_events_mask: memcpy failed");
-      return EINX_ERR_LAUNCH;
-    }
-    const long long ne = offsets_host[b + 1] - offsets_host[b];
-    if (ne > 0) {
-      hipLaunchKernelGGL(events_count_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, x + offsets_host[b], y + offsets_host[b], ne, H, W,
-                         cnt + (size_t)b * n);
-      EINX_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(minmax_kernel, dim3(64), dim3(256), 0, s, cnt + (size_t)b * n, n, mm + 2 * b);
-    EINX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(events_mask_kernel, dim3((unsigned)einx_cdiv(n, 256)), dim3(256), 0, s, cnt + (size_t)b * n, n, mm + 2 * b, mask + (size_t)b * n);
+  if (mx > 0) {
+    hipLaunchKernelGGL(events_count_kernel, dim3((unsigned)((mx + 255) / 256), (unsigned)B), dim3(256), 0, s, x, y, offs, H, W, cnt);
     EINX_CHECK_LAUNCH();
   }
+  hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)B), dim3(1024), 0, s, cnt, n, mm);
+  EINX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(events_mask_kernel, dim3((unsigned)einx_cdiv(n, 256), (unsigned)B), dim3(256), 0, s, cnt, n, mm, mask);
+  EINX_CHECK_LAUNCH();
   return EINX_OK;
 }
