@@ -452,11 +452,8 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     // small maps (the 33x44 heads): 128-pixel runs double the workgroup count so that the 256 CUs hold
     // enough waves to hide the staging latency (768 -> 1536 workgroups for 256 output channels at B=32)
     const long blocks256 = (long)einx_cdiv(H * W, 256) * B * (a.CoutPad / kCoutTile);
-#ifndef EINX_1X1_SMALL_LIMIT
-#define EINX_1X1_SMALL_LIMIT 1024
-#endif
     a.tilesY = 1;
-    if (blocks256 < EINX_1X1_SMALL_LIMIT) {
+    if (blocks256 < 1024) {
       a.tilesX = einx_cdiv(H * W, 128);
       launch<1, 1, 128, 1, 4, 2, 1, 32, false>(a, B, s);
     } else {
@@ -466,9 +463,9 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     EINX_CHECK_LAUNCH();
     return EINX_OK;
   }
-  // candidate tile shapes (all 4 waves): A (8,32) 1x4 waves of 2x2 tiles; B (12,16) and C (22,8)
-  // 2x2 waves of 1x3 tiles (192 pixel slots); D (11,22) like A.  Pooled layers need even tile dims
-  // so that every 2x2 window lives inside one tile.
+  // candidate tile shapes: (8,32) and (11,22) with 256 pixel slots (8 waves), (12,16) and (22,8) with 192
+  // (4 waves), (11,11) with 128 for small maps.  Pooled layers need even tile dims so that every 2x2 window
+  // lives inside one tile.  First choice: the least pixel-slot waste; then the two corrections below.
   static const TileCfg cfgs[5] = {{8, 32, 256}, {12, 16, 192}, {22, 8, 192}, {11, 22, 256}, {11, 11, 128}};
   int best = 0;
   double bw = 1e30;
