@@ -49,6 +49,11 @@ CONV_SHAPES = [
     (256, 256, 5, 6, 1, False, True, False, None),
     (128, 1, 37, 45, 1, False, True, False, None),
     (6, 7, 9, 10, 3, False, True, False, None),        # ragged everything
+    (64, 256, 132, 176, 3, True, True, False, None),   # 11x22 tile preferred over 12x16 (768 workgroups), generic reload path
+    (64, 64, 132, 176, 3, True, False, True, None),    # 12x16 pooled, offset-table reload
+    (8, 64, 16, 16, 3, True, True, False, None),       # one chunk, offset-table reload
+    (256, 64, 33, 44, 1, False, True, False, None),    # 1x1 with 128-pixel runs
+    (256, 130, 120, 90, 1, True, False, False, None),  # 1x1, ragged cout (the 256-pixel-run variant is exercised by the SiLK e2e cases)
 ]
 
 
