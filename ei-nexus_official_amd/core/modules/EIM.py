@@ -43,7 +43,7 @@ class EIM(nn.Module):
             self._einx_side_stream = st
         return st
 
-    def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False):
+    def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False, before_match=None):
         """Enqueue the whole pipeline; returns device-side results without synchronising.
         The event and image extractors share nothing, so the event side is enqueued on a second HIP
         stream: its small late layers and its latency-bound NMS/selection kernels overlap the other
@@ -63,42 +63,71 @@ class EIM(nn.Module):
         else:
             ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
             im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
+        if before_match is not None:
+            before_match(ev, im)  # hook of forward(): early read-back of the detection counts
         mr = None
         if self.matcher.matcher is not None and self.matcher.freeze:
             mr = self.matcher.match_batched(ev, im)
         return ev, im, mr
 
+    def _pinned(self, name, shape):
+        buf = self._host_bufs.get(name) if hasattr(self, "_host_bufs") else None
+        if buf is None or tuple(buf.shape) != tuple(shape):
+            if not hasattr(self, "_host_bufs"):
+                self._host_bufs = {}
+            buf = self._host_bufs[name] = torch.empty(shape, dtype=torch.int32, pin_memory=True)
+        return buf
+
     def forward(self, events, image, events_mask=None, image_mask=None):
-        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask)
+        """The host reads the counts back in two steps: the per-image keypoint counts are copied (pinned buffer,
+        non-blocking) as soon as both extractors are done, so the feature lists are built while the matcher still
+        runs; the per-pair match counts follow.  Both copies complete before this function returns: from the
+        caller's point of view it is one synchronous forward like the reference's."""
+        B = events.shape[0]
+        early = {}
+
+        def read_detection(ev, im):
+            rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged])
+            early["host"] = self._pinned("det", (4, B)).copy_(rows, non_blocking=True)
+            early["event"] = torch.cuda.Event()
+            early["event"].record()
+
+        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=read_detection)
+        nm_event = None
+        if mr is not None:
+            nm_host = self._pinned("nmatch", (B,)).copy_(mr.nmatch, non_blocking=True)
+            nm_event = torch.cuda.Event()
+            nm_event.record()
         ev.prepare()  # count-independent outputs are built while the device still works on the tail
         im.prepare()
         pre = full_batch_lists(mr) if mr is not None else None
-        while True:
-            rows = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
-            if mr is not None:
-                rows.append(mr.nmatch)
-            host = torch.stack(rows).cpu()  # the one host synchronisation of the forward pass
-            redo = [bool(host[2].any()), bool(host[3].any())]
-            if not any(redo):
-                break
+        early["event"].synchronize()
+        host = early["host"]
+        while bool(host[2].any()) or bool(host[3].any()):
             # the NMS fix-point of some image needed more passes than were enqueued: redo only the
-            # detection tail (and the matcher) with a larger, remembered, pass budget
-            for flag, bf, wrapper in ((redo[0], ev, self.event_extractor), (redo[1], im, self.image_extractor)):
+            # detection tail (and the matcher) with a larger, remembered, pass budget (rare: blocking read-back)
+            for flag, bf, wrapper in ((bool(host[2].any()), ev, self.event_extractor), (bool(host[3].any()), im, self.image_extractor)):
                 if flag:
                     eng = wrapper.extractor.engine()
                     eng.redetect(bf, eng.grow_nms_iters())
             if mr is not None:
                 mr = self.matcher.match_batched(ev, im)
                 pre = None
-        self._last_match = mr  # device-side MatchResult of this call (consumed by core.metrics batch_metrics)
+            host = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]).cpu()
+            if mr is not None:
+                nm_host = mr.nmatch.cpu()
+                nm_event = None
         n, m = host[0].tolist(), host[1].tolist()
         events_feats = ev.materialize(n)
         image_feats = im.materialize(m)
+        if nm_event is not None:
+            nm_event.synchronize()
+        self._last_match = mr  # device-side MatchResult of this call (consumed by core.metrics batch_metrics)
         matches = None
         if mr is not None:
             n = [min(v, ev.det.cap) for v in n]
             m = [min(v, im.det.cap) for v in m]
-            matches = self.matcher.materialize(mr, n, m, host[4].tolist(), prebuilt=pre)
+            matches = self.matcher.materialize(mr, n, m, nm_host.tolist(), prebuilt=pre)
         elif self.matcher.matcher is not None:
             # un-frozen matcher (EIM.py:92-95 -> Matchers.py:204-222): random padding to max_points_num and
             # one stacked call; like the reference it rewrites sparse_positions / sparse_descriptors of
