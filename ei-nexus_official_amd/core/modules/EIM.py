@@ -1,9 +1,9 @@
 """EIM: event extractor + image extractor + matcher (reference core/modules/EIM.py:13-100).
 
 Same constructor, checkpoint-prefix loading and `forward` contract.  The difference is the
-schedule: both extractors and the matcher are enqueued for the whole batch on the current HIP
-stream, and the host synchronises exactly once (to read the keypoint / match counts that shape
-the returned Python lists)."""
+schedule: both extractors (on two HIP streams) and the matcher are enqueued for the whole batch,
+and the host only waits for two small read-backs: the keypoint counts and the match counts that
+shape the returned Python lists."""
 import os
 
 import torch
