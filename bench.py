@@ -237,18 +237,21 @@ def main():
         sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
         et, it = cfg.event_extractor.type, cfg.image_extractor.type
         escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
+        passes = 2 if (args.config == "sp_mnn" and not args.cpu_pairs) else 1  # the headline sample: ~10-20 s of host work
         tc = time.perf_counter()
-        oe = orc.extractor_forward(et, sub("event_extractor.extractor."), ev_np[:nb].copy(), mask_np[:nb], top_k=1024, scale=escale)
-        oi = orc.extractor_forward(it, sub("image_extractor.extractor."), img_np[:nb].copy(), None, top_k=1024, scale=iscale)
         nmatch = 0
-        for b in range(nb):
-            if cfg.matcher.type == "MNN":
-                r = orc.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=args.log_assignment)
-            else:
-                r = orc.lightglue(sub("matcher.matcher."), oe["sparse_positions"][b], oe["sparse_descriptors"][b],
-                                  oi["sparse_positions"][b], oi["sparse_descriptors"][b])
-            nmatch += int((r["matches0"] > -1).sum())
+        for _ in range(passes):
+            oe = orc.extractor_forward(et, sub("event_extractor.extractor."), ev_np[:nb].copy(), mask_np[:nb], top_k=1024, scale=escale)
+            oi = orc.extractor_forward(it, sub("image_extractor.extractor."), img_np[:nb].copy(), None, top_k=1024, scale=iscale)
+            for b in range(nb):
+                if cfg.matcher.type == "MNN":
+                    r = orc.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=args.log_assignment)
+                else:
+                    r = orc.lightglue(sub("matcher.matcher."), oe["sparse_positions"][b], oe["sparse_descriptors"][b],
+                                      oi["sparse_positions"][b], oi["sparse_descriptors"][b])
+                nmatch += int((r["matches0"] > -1).sum())
         cpu_s = time.perf_counter() - tc
+        nb *= passes
         cores = os.cpu_count() or 1
         try:
             cores = len(os.sched_getaffinity(0))
