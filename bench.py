@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--log-assignment", action="store_true", help="also materialise log_assignment (reference-complete matcher dict)")
     ap.add_argument("--dense", action="store_true", help="also materialise the dense descriptor maps (reference-complete dict)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-torch", action="store_true", help="also time oracle/torch_cpu.py (plain PyTorch on the host cores; SP+MNN only)")
     ap.add_argument("--cpu-pairs", type=int, default=None, help="pairs of the CPU baseline sample (default: ~10-20 s of host work)")
     ap.add_argument("--with-metrics", action="store_true", help="also compute MR/MMA/VDD on the device each step (metrics.hip) and all-reduce their sums")
     ap.add_argument("--layer-table", action="store_true", help="tuning aid: time every conv layer of both extractors standalone and exit")
@@ -260,6 +261,18 @@ def main():
         cpu_baseline = {"value": round(nb / cpu_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
                         "sample": f"{nb} pairs of the same workload through oracle/ (C, OpenMP on all host cores), {cpu_s:.1f} s"}
 
+    cpu_torch = None
+    if rank == 0 and world == 1 and args.cpu_torch and args.config == "sp_mnn":
+        from oracle import torch_cpu
+        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
+        nb = min(16, B)
+        torch_cpu.sp_mnn_pairs(sub("event_extractor.extractor."), sub("image_extractor.extractor."), ev_np[:2], mask_np[:2], img_np[:2].copy())
+        tc = time.perf_counter()
+        torch_cpu.sp_mnn_pairs(sub("event_extractor.extractor."), sub("image_extractor.extractor."), ev_np[:nb], mask_np[:nb], img_np[:nb].copy())
+        cpu_s = time.perf_counter() - tc
+        cpu_torch = {"value": round(nb / cpu_s, 3), "unit": "pairs/s", "threads": torch.get_num_threads(), "kind": "plain PyTorch CPU expression (oracle/torch_cpu.py)",
+                     "sample": f"{nb} pairs, one batched call, {cpu_s:.1f} s"}
+
     if rank == 0:
         out = {
             "metric": "event-image pairs/s (extract+match, 346x260, 1024 kpts)",
@@ -274,6 +287,8 @@ def main():
                        "harness_metrics_mean": ([round(v, 5) for v in (metric_sums / pairs_total).tolist()] if args.with_metrics else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if cpu_torch is not None:
+            out["cpu_baseline_torch"] = cpu_torch
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -372,3 +372,27 @@ def test_pair_metrics(oracle, name):
     np.testing.assert_allclose(got[[0, 1, 2, 3, 6]], exp[[0, 1, 2, 3, 6]], atol=1e-7, rtol=1e-6)
     np.testing.assert_allclose(got[[4, 7]], exp[[4, 7]], atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(got[[5, 8]], exp[[5, 8]], atol=2e-3, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ plain-PyTorch CPU expression (second CPU baseline)
+def test_torch_cpu_pipeline_agrees_with_the_oracle(oracle):
+    """oracle/torch_cpu.py (torch's own CPU operators, used only as bench.py's second CPU timing) and the C oracle
+    are independent restatements of the same pipeline: same keypoint sets, descriptors to 1e-5."""
+    from oracle import torch_cpu
+    c = E2E.cases["sp_mnn"]
+    sd = state_dict_for(c, E2E)
+    B, H, W = 2, 96, 136
+    ev, mask = synth.synth_events(77, B, c["ce"], H, W)
+    img = synth.synth_image(77, B, H, W)
+    nm, fe, fi = torch_cpu.sp_mnn_pairs(sub_dict(sd, "event_extractor.extractor."), sub_dict(sd, "image_extractor.extractor."), ev, mask, img.copy(),
+                                        top_k=200)
+    oe = oracle.extractor_forward("vgg", sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=200)
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=200)
+    for b in range(B):
+        for got, exp in ((fe[b], (oe["sparse_positions"][b], oe["sparse_descriptors"][b])), (fi[b], (oi["sparse_positions"][b], oi["sparse_descriptors"][b]))):
+            pos, desc = got[0].numpy(), got[1].numpy()
+            assert pos.shape == exp[0].shape and np.array_equal(pos[:, :2], exp[0][:, :2])
+            np.testing.assert_allclose(pos[:, 2], exp[0][:, 2], atol=1e-5)
+            np.testing.assert_allclose(desc, exp[1], atol=1e-5)
+        r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
+        assert nm[b] == int((r["matches0"] > -1).sum())
