@@ -6,35 +6,47 @@
 A step = one pass of the hot path (EIM.forward: event extractor + image extractor + matcher) over
 one batch of synthetic pairs already resident in HBM.  Default workload = BASELINE.json configs[1]:
 batch 32, 5-bin event voxel + gray image, SuperPoint-shaped extractors + MNN matcher.
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); pairs are independent, so ranks
-shard them with NO data-path collective; the only RCCL traffic is the all-reduce of the metric
-accumulators (weak scaling: the per-GPU batch is fixed).
-Prints ONE JSON line (rank 0) with the driver contract plus `roofline` and `cpu_baseline`.
+
+One process per GPU.  Under a launcher (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*) this
+process is a rank; started plainly with `--gpus N` (N > 1) it is the LAUNCHER: it never touches
+the GPU, spawns N fresh rank processes with that environment (the reference's pattern:
+init_process_group(env://) under a launcher, train_extractor.py:82-91) and exits with their status.
+Pairs are independent, so ranks shard them with NO data-path collective; the only RCCL traffic is
+the all-reduce of the metric accumulators (weak scaling: the per-GPU batch is fixed).
+
+Rank 0 prints ONE JSON line with the driver contract plus
+  roofline         dominant kernel (conv1b), mean of >= 20 launches timed with HIP events
+  roofline_stages  conv stage, descriptor-correlation GEMM, LightGlue GEMM / attention kernels
+  cpu_baseline     the oracle (a port) on the host cores, bounded sample; `verified_pairs` = pairs of
+                   that sample whose GPU outputs (keypoints, descriptors, matches) equal the oracle's
+  extra_configs    short legs for BASELINE configs[2], configs[3], B=1 latency and the round-1 weights
+  rccl             world size seen by the process group + latency of the metric all-reduce (N > 1 or --spawn)
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_HBM_BYTES = 8.0e12
+SP_PAIR_BYTES = 188.8e6  # algorithmic HBM bytes of the conv stage per pair (SURVEY 8d)
+LG_PAIR_FLOP = 80.5e9    # LightGlue forward per pair at 1024 x 1024 keypoints (SURVEY 8d)
 
 WORKLOADS = {
-    "sp_mnn": ("SP_MNN", "B32 346x260 5-bin event voxel + gray image, VGG(event)+SuperPoint(image) extractors, MNN matcher, k=1024"),
-    "silk_mnn": ("SiLK_MNN", "B32 346x260, VGG_NP(event)+SiLK(image) extractors, MNN matcher, k=1024"),
-    "sp_lg": ("SP_LG", "B64 346x260, VGG(event)+SuperPoint(image) extractors, LightGlue matcher, k=1024"),
+    "sp_mnn": ("SP_MNN", 32, "346x260 5-bin event voxel + gray image, VGG(event)+SuperPoint(image) extractors, MNN matcher, k=1024"),
+    "silk_mnn": ("SiLK_MNN", 32, "346x260, VGG_NP(event)+SiLK(image) extractors, MNN matcher, k=1024"),
+    "sp_lg": ("SP_LG", 64, "346x260, VGG(event)+SuperPoint(image) extractors, LightGlue matcher, k=1024"),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -43,15 +55,101 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (default 32; 64 for sp_lg)")
     ap.add_argument("--log-assignment", action="store_true", help="also materialise log_assignment (reference-complete matcher dict)")
     ap.add_argument("--dense", action="store_true", help="also materialise the dense descriptor maps (reference-complete dict)")
+    ap.add_argument("--raw-weights", action="store_true",
+                    help="headline on the un-calibrated synthetic weights (round-1 workload: near-constant descriptors, ~2 matches per pair)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra_configs and roofline_stages (they run at N=1 only)")
+    ap.add_argument("--extras", action="store_true", help="run extra_configs / roofline_stages on rank 0 even when N > 1")
     ap.add_argument("--cpu-torch", action="store_true", help="also time oracle/torch_cpu.py (plain PyTorch on the host cores; SP+MNN only)")
     ap.add_argument("--cpu-pairs", type=int, default=None, help="pairs of the CPU baseline sample (default: ~10-20 s of host work)")
     ap.add_argument("--with-metrics", action="store_true", help="also compute MR/MMA/VDD on the device each step (metrics.hip) and all-reduce their sums")
     ap.add_argument("--layer-table", action="store_true", help="tuning aid: time every conv layer of both extractors standalone and exit")
     ap.add_argument("--kernel-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
-    return ap.parse_args()
+    ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (one-rank RCCL group)")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="launcher / collective rehearsal on CPU: ranks form a gloo group, all-reduce the metric accumulators, run no kernels")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Parent of `--gpus N`: spawn N fresh rank processes (env:// rendezvous on 127.0.0.1) and wait.
+    This process makes no GPU call.  A rank that dies takes the others down (exact PIDs), so a
+    failure is loud and never a hang in the rendezvous."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench launcher] rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.05)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------ CPU rehearsal
+def dry_run_gloo(args):
+    """The N>1 control flow without kernels: same env:// rendezvous, same accumulator all-reduce,
+    same barrier + max-over-ranks timing, on the gloo backend (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", init_method="env://")
+    pkg_shard = _import_shard_only()
+    B = args.batch or WORKLOADS[args.config][1]
+    acc = pkg_shard.MetricAccumulator("cpu")
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc.add(B, B * 1000 + rank, B * 1001, 10 * (rank + 1), 0.0)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    acc.all_reduce()
+    stats = acc.as_dict()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "steps": args.steps,
+                          "pairs": stats["pairs"], "keypoints0": stats["keypoints0"], "matches": stats["matches"],
+                          "config": {"workload": WORKLOADS[args.config][2], "pairs_per_gpu_per_step": B, "global_batch": B * world}}))
+    dist.destroy_process_group()
+
+
+def _import_shard_only():
+    """shard.py without importing the package (which loads the HIP library and is GPU-only)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("einx_shard", os.path.join(ROOT, "ei-nexus_official_amd", "shard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ------------------------------------------------------------------------------------ workload
 def conv_layer_flops(cin, cout, ks, H, W):
     return 2.0 * cin * cout * ks * ks * H * W
 
@@ -68,95 +166,347 @@ def sp_pair_flops(ce):
     return net(ce) + net(1)
 
 
-def main():
-    args = parse()
+class Workload:
+    """One model + one resident batch of synthetic pairs + the step function."""
+
+    def __init__(self, pkg, dev, config, B, rank=0, calibrate=True, dense=False, log_assignment=False, ce=5, seed=11):
+        import torch
+        self.torch, self.pkg, self.dev, self.config, self.B, self.ce = torch, pkg, dev, config, B, ce
+        synth = pkg.synth
+        cfg_name = WORKLOADS[config][0]
+        self.cfg = cfg = pkg.default_config(cfg_name, event_channels=ce)
+        self.model = model = pkg.EIM(cfg, device=dev).eval()
+        self.sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=seed)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()}, strict=False)
+        for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+            ext.dense_outputs = bool(dense)
+        model.matcher.matcher.want_log_assignment = bool(log_assignment)
+        # synthetic pairs: each rank gets its own shard of the global pair index space
+        self.ev_np, self.mask_np = synth.synth_events(10_000 + rank * B, B, ce)
+        self.img_np = synth.synth_image(10_000 + rank * B, B)
+        self.ev = torch.from_numpy(self.ev_np).to(dev)
+        self.mask = torch.from_numpy(self.mask_np).to(dev)
+        self.img_src = torch.from_numpy(self.img_np).to(dev)
+        self.img = torch.empty_like(self.img_src)
+        self.calibrated = False
+        if calibrate:
+            self.calibrate()
+
+    def calibrate(self):
+        """Random-weight ReLU stacks emit descriptors dominated by a per-channel constant (every keypoint
+        looks alike: ~2 mutual matches in 1024).  As the golden fixtures do (tests/golden/gen_golden.py
+        `calibrate`), move the per-channel spatial mean of each raw descriptor map into the last bias of its
+        descriptor head, so the matcher sees descriptors that differ between keypoints.  Outside any timed
+        region; the adjusted biases become part of `self.sd`, which the CPU baseline / verification use too."""
+        torch, model = self.torch, self.model
+        self.img.copy_(self.img_src)
+        ef, imf, _ = model(self.ev, self.img, self.mask)
+        msd = model.state_dict()
+        over = {}
+        for prefix, feats in (("event_extractor.extractor.", ef), ("image_extractor.extractor.", imf)):
+            mean = feats["raw_descriptors"].mean(dim=(0, 2, 3))
+            cands = [k for k in msd if k.startswith(prefix) and (k.endswith("convDb.bias") or k.endswith("_desH2.1.bias"))]
+            assert len(cands) == 1, cands  # the last additive term of the descriptor head (conv bias / BatchNorm beta)
+            key = cands[0]
+            over[key] = (msd[key] - mean).detach().cpu()
+        model.load_state_dict(over, strict=False)  # parent-level load: the extractors' native weight images are rebuilt
+        for k, v in over.items():
+            self.sd[k] = v.numpy()
+        self.calibrated = True
+
+    def step(self):
+        self.img.copy_(self.img_src)  # SuperPoint scales its input in place (reference quirk), so refresh it
+        return self.model(self.ev, self.img, self.mask)
+
+    def sub(self, prefix):
+        return {k[len(prefix):]: v for k, v in self.sd.items() if k.startswith(prefix)}
+
+    def timed(self, steps, init=2, warmup=1):
+        torch = self.torch
+        for _ in range(init + warmup):
+            self.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nm = 0
+        for _ in range(steps):
+            _, _, m = self.step()
+            nm += sum(int(t.shape[0]) for t in m["matched_kpts0"])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return el / steps, nm / (steps * self.B)
+
+
+def hip_time(torch, fn, reps, warm=2):
+    """mean seconds per call, HIP events on the stream the kernels are launched on (torch's current stream)"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def library_profile(pkg, fn):
+    """{kernel class: (calls, total_ms)} of one call of fn, from the library's own HIP-event scopes."""
+    import ctypes
+    L = pkg.native.lib()
+    L.einx_profile_enable(1)
+    try:
+        fn()
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.einx_profile_report(buf, len(buf))
+    finally:
+        L.einx_profile_enable(0)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.rsplit(" ", 2)
+        out[name] = (int(calls), float(ms))
+    return out
+
+
+def layer_table(wl):
+    torch, pkg, model, B = wl.torch, wl.pkg, wl.model, wl.B
+    rows = []
+    for _ in range(3):  # bring the device to its working clocks before the first timed row
+        wl.step()
+    torch.cuda.synchronize()
+    for side, ext, x0 in (("event", model.event_extractor.extractor, wl.ev), ("image", model.image_extractor.extractor, wl.img_src)):
+        eng = ext.engine()
+        pads = pkg.native.padder_pads(260, 346, ext.cell_size)
+        Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
+        chains = [("bb", eng.backbone), ("det", eng.det_head), ("desc", eng.desc_head)]
+        feats = None
+        for cname, layers in chains:
+            t_in = x0 if cname == "bb" else feats
+            for li, layer in enumerate(layers):
+                fold = (pads[2], pads[0], Hp, Wp) if (cname == "bb" and li == 0) else None
+                out = layer(t_in, fold=fold)
+                dur = hip_time(torch, lambda: layer(t_in, fold=fold), 5, warm=1)
+                H_, W_ = (Hp, Wp) if fold else t_in.shape[-2:]
+                fl = conv_layer_flops(layer.cin, layer.cout, layer.ks, H_, W_) * B
+                rows.append((f"{side}.{cname}{li}", layer.cin, layer.cout, layer.ks, int(H_), int(W_), bool(layer.pool), round(dur * 1e6, 1),
+                             round(fl / dur / 1e12, 1)))
+                t_in = out
+            if cname == "bb":
+                feats = t_in
+    for r in rows:
+        print("%-14s cin=%3d cout=%3d ks=%d %3dx%3d pool=%d  %8.1f us  %6.1f TFLOP/s" % r)
+    print("total conv us", round(sum(r[7] for r in rows), 1))
+
+
+def dominant_kernel_roofline(wl, value_per_gpu, kernel_only=False):
+    """conv1b (64->64 3x3 at full resolution, fused ReLU + 2x2 max-pool) of the image extractor."""
+    torch, pkg, model, B = wl.torch, wl.pkg, wl.model, wl.B
+    ext = model.image_extractor.extractor
+    eng = ext.engine()
+    l0, l1 = eng.backbone[0], eng.backbone[1]
+    pads = pkg.native.padder_pads(260, 346, ext.cell_size)
+    Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
+    fold = (pads[2], pads[0], Hp, Wp)
+    x1 = l0(wl.img_src, fold=fold)
+    if kernel_only:
+        # no pipeline steps ran before: bring the device to its working clocks with the *first* layer's kernel, so that
+        # every launch of the measured kernel in a `rocprofv3 --stats` summary of this mode is a steady-state launch
+        for _ in range(300):
+            l0(wl.img_src, fold=fold)
+    reps = 24
+    dur = hip_time(torch, lambda: l1(x1), reps, warm=2)
+    flops = conv_layer_flops(l1.cin, l1.cout, l1.ks, Hp, Wp) * B
+    ach = flops / dur / 1e12
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv1b.json")
+    if wl.config == "sp_mnn" and B == 32 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+        traffic_src = "replayed from profiles/r01_pmc_conv1b.json (FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over this kernel; not re-measured by this run)"
+    tile = "8,32,2,4,1,2,8"
+    kname = f"conv_block_kernel<3,{tile},{'true' if l1.pool else 'false'},true> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
+    return {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "launch_ms": round(dur * 1e3, 4), "launches_timed": reps, "flop_per_launch": flops,
+            "hbm_frac_at_measured_rate": round(SP_PAIR_BYTES * value_per_gpu / PEAK_HBM_BYTES, 4) if wl.config == "sp_mnn" else None}
+
+
+def stage_rooflines(wl, lg_wl=None):
+    """Per-stage fractions asked for by the north_star: conv encoders (both roofs), the descriptor-correlation
+    GEMM, and LightGlue's GEMM / attention kernels.  Kernel times come from the library's HIP-event scopes
+    (einx_profile_*) around every launch of ONE forward with both extractors on one stream."""
+    torch, pkg, model, B = wl.torch, wl.pkg, wl.model, wl.B
+    out = []
+
+    def single_stream_forward(w):
+        keep = w.model.overlap_extractors
+        w.model.overlap_extractors = False
+        try:
+            w.step()
+            torch.cuda.synchronize()
+        finally:
+            w.model.overlap_extractors = keep
+
+    single_stream_forward(wl)
+    prof = library_profile(pkg, lambda: single_stream_forward(wl))
+    if wl.config != "silk_mnn":
+        conv_ms = sum(ms for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel"))
+        conv_calls = sum(c for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel"))
+        fl = sp_pair_flops(wl.ce) * B
+        if conv_ms > 0:
+            out.append({"stage": "conv encoders + heads (both extractors, %d launches)" % conv_calls, "ms": round(conv_ms, 3),
+                        "bound": "mfma", "achieved": round(fl / conv_ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "hbm": {"algorithmic_bytes": SP_PAIR_BYTES * B, "achieved_GBps": round(SP_PAIR_BYTES * B / conv_ms / 1e6, 1),
+                                "frac": round(SP_PAIR_BYTES * B / (conv_ms * 1e-3) / PEAK_HBM_BYTES, 4)},
+                        "note": "169 FLOP/B: compute-bound, the HBM fraction is reported because the north_star names it"})
+    if "mnn_tile_kernel<0>" in prof:
+        c, ms = prof["mnn_tile_kernel<0>"]
+        D = 128 if wl.config == "silk_mnn" else 256
+        fl = 2.0 * 1024 * 1024 * D * B * c
+        out.append({"stage": "descriptor-correlation GEMM + fused arg-max (mnn_tile_kernel<0>)", "ms": round(ms / c, 4), "bound": "mfma",
+                    "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
+    tail = {k: round(ms, 4) for k, (c, ms) in prof.items() if not k.startswith("conv_block_kernel") and not k.startswith("mnn_tile")}
+    if tail:
+        out.append({"stage": "latency-bound tail (ms per forward, both sides)", "kernels_ms": tail})
+    if lg_wl is not None:
+        single_stream_forward(lg_wl)
+        p2 = library_profile(pkg, lambda: single_stream_forward(lg_wl))
+        Bl = lg_wl.B
+        n = 1024
+        # per pair and layer: self 2 x (Wqkv 3d^2 + ffn0 (2d)(2d)... ) see SURVEY 8d; here: measured kernel time vs the FLOPs each class executes
+        d = 256
+        gemm_flop_layer = 2 * (2.0 * n * d * 3 * d + 2.0 * n * 2 * d * 2 * d + 2.0 * n * 2 * d * d)  # self: qkv, ffn0 (out_proj folded), ffn3; both sides
+        gemm_flop_layer += 2 * (2.0 * n * d * d * 2 + 2.0 * n * 2 * d * 2 * d + 2.0 * n * 2 * d * d)  # cross: to_qk, to_v, ffn0 (to_out folded), ffn3
+        attn_flop_layer = 4 * (2.0 * n * n * d * 2)  # 2 self + 2 cross attentions: QK^T and PV
+        if "lg_gemm_kernel" in p2:
+            c, ms = p2["lg_gemm_kernel"]
+            fl = (gemm_flop_layer * 9 + 2 * 2.0 * n * d * d) * Bl  # + final_proj on both sides
+            out.append({"stage": f"LightGlue linears (lg_gemm_kernel, {c} launches, B={Bl})", "ms": round(ms, 3), "bound": "mfma",
+                        "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
+        for key in ("lg_attn_kernel", "lg_cross_attn_kernel"):
+            if key in p2:
+                c, ms = p2[key]
+                share = 1.0 if ("lg_cross_attn_kernel" not in p2) else 0.5
+                fl = attn_flop_layer * share * 9 * Bl
+                out.append({"stage": f"LightGlue attention ({key}, {c} launches, B={Bl})", "ms": round(ms, 3), "bound": "mfma",
+                            "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
+        rest = {k: round(ms, 3) for k, (c, ms) in p2.items() if k.startswith("lg_") and k not in ("lg_gemm_kernel", "lg_attn_kernel", "lg_cross_attn_kernel")}
+        lg_ms = sum(ms for k, (c, ms) in p2.items() if k.startswith("lg_"))
+        out.append({"stage": f"LightGlue forward (all lg_* kernels, B={Bl})", "ms": round(lg_ms, 3), "bound": "mfma",
+                    "achieved": round(LG_PAIR_FLOP * Bl / lg_ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(LG_PAIR_FLOP * Bl / lg_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4), "other_kernels_ms": rest})
+    return out
+
+
+def cpu_baseline_and_verify(wl, args, gpu_out):
+    """The oracle (C port, OpenMP) on the host cores over the first pairs of the resident batch.  Its outputs
+    double as the checker of the GPU outputs of the same pairs (`verified_pairs`): same weights, same inputs."""
+    import numpy as np
+    from oracle import oracle as orc
+    cfg, B = wl.cfg, wl.B
+    nb = args.cpu_pairs if args.cpu_pairs else {"sp_mnn": 32, "sp_lg": 4, "silk_mnn": 4}.get(wl.config, 4)
+    nb = max(1, min(nb, B))
+    et, it = cfg.event_extractor.type, cfg.image_extractor.type
+    escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
+    passes = 2 if (wl.config == "sp_mnn" and not args.cpu_pairs) else 1  # the headline sample: ~10-20 s of host work
+    tc = time.perf_counter()
+    for _ in range(passes):
+        oe = orc.extractor_forward(et, wl.sub("event_extractor.extractor."), wl.ev_np[:nb].copy(), wl.mask_np[:nb], top_k=1024, scale=escale)
+        oi = orc.extractor_forward(it, wl.sub("image_extractor.extractor."), wl.img_np[:nb].copy(), None, top_k=1024, scale=iscale)
+        res = []
+        for b in range(nb):
+            if cfg.matcher.type == "MNN":
+                r = orc.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=args.log_assignment)
+            else:
+                r = orc.lightglue(wl.sub("matcher.matcher."), oe["sparse_positions"][b], oe["sparse_descriptors"][b],
+                                  oi["sparse_positions"][b], oi["sparse_descriptors"][b])
+            res.append(r)
+    cpu_s = time.perf_counter() - tc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # ---- verification of the GPU outputs against the checker (outside every timed region)
+    ef, imf, m = gpu_out
+    verified, first_bad = 0, None
+    for b in range(nb):
+        ok = True
+        for got, exp in ((ef, oe), (imf, oi)):
+            ok &= np.array_equal(got["sparse_positions"][b].cpu().numpy(), exp["sparse_positions"][b])
+            ok &= np.array_equal(got["sparse_descriptors"][b].cpu().numpy(), exp["sparse_descriptors"][b])
+        g0 = m["matches0"][b].cpu().numpy().reshape(-1)
+        ok &= np.array_equal(g0, np.asarray(res[b]["matches0"]).reshape(-1))
+        verified += int(bool(ok))
+        if not ok and first_bad is None:
+            first_bad = b
+    base = {"value": round(nb * passes / cpu_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{nb * passes} pairs of the same workload through oracle/ (C, OpenMP on all host cores), {cpu_s:.1f} s",
+            "verified_pairs": verified, "verified_of": nb,
+            "verified_what": "keypoint positions+scores and descriptors bit-equal, match indices equal, GPU vs oracle on the same pairs"}
+    if first_bad is not None:
+        base["first_mismatch_pair"] = first_bad
+    return base
+
+
+def run_rank(args):
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+        raise SystemExit(f"bench.py rank {rank}: needs a HIP device -- the product path has no CPU fallback "
+                         "(use --dry-run-gloo to rehearse the launcher and the collective on CPU)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
-    if distributed:  # torchrun launch (also with one rank): RCCL process group, one process per GPU
+    rccl = None
+    if distributed:  # under a launcher (also with one rank): RCCL process group, one process per GPU
         dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        world = dist.get_world_size()
+        probe = torch.ones(8, dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)  # communicator set-up happens here, not in the timed region
+        torch.cuda.synchronize()
+        assert int(probe[0].item()) == world, "RCCL all-reduce did not see every rank"
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        rccl = {"backend": dist.get_backend(), "world": world, "allreduce_us": round((time.perf_counter() - t0) / 20 * 1e6, 1),
+                "allreduce_payload_bytes": 64}
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     pkg = importlib.import_module("ei-nexus_official_amd")
-    synth = pkg.synth
-    cfg_name, wl_desc = WORKLOADS[args.config]
-    B = args.batch or (64 if args.config == "sp_lg" else 32)
-    ce = 5
-    cfg = pkg.default_config(cfg_name, event_channels=ce)
-    model = pkg.EIM(cfg, device=dev).eval()
-    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=11)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
-        ext.dense_outputs = bool(args.dense)
-    model.matcher.matcher.want_log_assignment = bool(args.log_assignment)
-
-    # synthetic pairs: each rank gets its own shard of the global pair index space
-    ev_np, mask_np = synth.synth_events(10_000 + rank * B, B, ce)
-    img_np = synth.synth_image(10_000 + rank * B, B)
-    ev = torch.from_numpy(ev_np).to(dev)
-    mask = torch.from_numpy(mask_np).to(dev)
-    img_src = torch.from_numpy(img_np).to(dev)
-    img = torch.empty_like(img_src)
-
+    B = args.batch or WORKLOADS[args.config][1]
+    wl = Workload(pkg, dev, args.config, B, rank=rank, calibrate=not args.raw_weights, dense=args.dense, log_assignment=args.log_assignment)
+    model = wl.model
     acc = pkg.shard.MetricAccumulator(dev)  # pairs, keypoints(ev), keypoints(im), matches, ...
-
     metric_sums = torch.zeros(9, dtype=torch.float64, device=dev)
     metric_rows = []
     batch_metrics = importlib.import_module(pkg.__name__ + ".core.metrics._native_metrics").batch_metrics
 
     def step(accumulate=False):
-        img.copy_(img_src)  # SuperPoint scales its input in place (reference quirk), so refresh it
-        ef, imf, m = model(ev, img, mask)
-        res = None
+        ef, imf, m = wl.step()
         if args.with_metrics:  # harness metrics of the reference's test script, computed on the device
             res = batch_metrics(ef._batched, imf._batched, model._last_match)
+            if accumulate:
+                metric_rows.append(res)  # [B,9] per step; summed after the timed region
         if accumulate:
             acc.add_batch(ef, imf, m)
-            if res is not None:
-                metric_rows.append(res)  # [B,9] per step; summed after the timed region
         return ef, imf, m
 
     if args.layer_table:
-        rows = []
-        for _ in range(3):  # bring the device to its working clocks before the first timed row
-            step()
-        torch.cuda.synchronize()
-        for side, ext, x0 in (("event", model.event_extractor.extractor, ev), ("image", model.image_extractor.extractor, img_src)):
-            eng = ext.engine()
-            pads = pkg.native.padder_pads(260, 346, ext.cell_size)
-            Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
-            chains = [("bb", eng.backbone), ("det", eng.det_head), ("desc", eng.desc_head)]
-            feats = None
-            for cname, layers in chains:
-                t_in = x0 if cname == "bb" else feats
-                for li, layer in enumerate(layers):
-                    fold = (pads[2], pads[0], Hp, Wp) if (cname == "bb" and li == 0) else None
-                    out = layer(t_in, fold=fold)
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(5):
-                        layer(t_in, fold=fold)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    dur = e0.elapsed_time(e1) / 5 * 1e-3
-                    H_, W_ = (Hp, Wp) if fold else t_in.shape[-2:]
-                    fl = conv_layer_flops(layer.cin, layer.cout, layer.ks, H_, W_) * B
-                    rows.append((f"{side}.{cname}{li}", layer.cin, layer.cout, layer.ks, int(H_), int(W_), bool(layer.pool), round(dur * 1e6, 1),
-                                 round(fl / dur / 1e12, 1)))
-                    t_in = out
-                if cname == "bb":
-                    feats = t_in
-        for r in rows:
-            print("%-14s cin=%3d cout=%3d ks=%d %3dx%3d pool=%d  %8.1f us  %6.1f TFLOP/s" % r)
-        print("total conv us", round(sum(r[7] for r in rows), 1))
+        layer_table(wl)
         return
     if args.kernel_only:
-        args.steps, args.warmup, args.no_cpu_baseline = 0, 0, True
+        args.steps, args.warmup, args.no_cpu_baseline, args.no_extras = 0, 0, True, True
     else:
         # initialisation, not a measured or warm-up step: the first forward builds the kernel-native weight images
         # (repack, BN fold, LightGlue projection folding), loads the code objects, sizes the allocator pool and settles
@@ -173,8 +523,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step(accumulate=True)
+        last = step(accumulate=True)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -189,109 +540,102 @@ def main():
     elapsed = float(t.item())
     stats = acc.as_dict()
     pairs_total = max(stats["pairs"], 1.0)
-    value = stats["pairs"] / elapsed
+    value = stats["pairs"] / elapsed if elapsed > 0 else 0.0
 
-    # ---- roofline of the dominant kernel: the second backbone conv (64->64 at full resolution) ----------
-    # SP-shaped nets: conv_block_kernel<3,8,32,2,4,1,2,8,true,true> (conv1b, fused pool, offset-table reloads); SiLK: same tile, no pool.
-    roofline = None
+    roofline = stages = cpu_baseline = cpu_torch = None
+    extras = []
+    do_extras = rank == 0 and not args.no_extras and (world == 1 or args.extras)
     if rank == 0:
-        ext = model.image_extractor.extractor
-        eng = ext.engine()
-        l0, l1 = eng.backbone[0], eng.backbone[1]
-        pads = pkg.native.padder_pads(260, 346, ext.cell_size)
-        Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
-        x1 = l0(img_src, fold=(pads[2], pads[0], Hp, Wp))
-        reps = 10
-        if args.kernel_only:
-            # no pipeline steps ran before: bring the device to its working clocks with the *first* layer's kernel, so that
-            # every launch of the measured kernel in a `rocprofv3 --stats` summary of this mode is a steady-state launch
-            for _ in range(300):
-                l0(img_src, fold=(pads[2], pads[0], Hp, Wp))
-        for _ in range(2):
-            l1(x1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()  # HIP events on the stream the kernel is launched on (torch's current stream)
-        for _ in range(reps):
-            l1(x1)
-        e1.record()
-        torch.cuda.synchronize()
-        dur = e0.elapsed_time(e1) * 1e-3 / reps
-        flops = conv_layer_flops(l1.cin, l1.cout, l1.ks, Hp, Wp) * B
-        ach = flops / dur / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv1b.json")
-        if args.config == "sp_mnn" and B == 32 and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]  # FETCH_SIZE+WRITE_SIZE, separate --pmc passes
-        kname = f"conv_block_kernel<3,8,32,2,4,1,2,8,{'true' if l1.pool else 'false'},true> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "launch_ms": round(dur * 1e3, 4),
-                    "flop_per_launch": flops,
-                    "hbm_frac_at_measured_rate": round(188.8e6 * value / max(world, 1) / 8e12, 4) if args.config == "sp_mnn" else None}
+        roofline = dominant_kernel_roofline(wl, value / max(world, 1), kernel_only=args.kernel_only)
 
-    # ---- CPU baseline: the oracle (a port, not the reference files) on the host cores, bounded sample ----
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
-        from oracle import oracle as orc
-        nb = args.cpu_pairs if args.cpu_pairs else {"sp_mnn": 32, "sp_lg": 4, "silk_mnn": 4}.get(args.config, 4)
-        nb = max(1, min(nb, B))
-        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
-        et, it = cfg.event_extractor.type, cfg.image_extractor.type
-        escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
-        passes = 2 if (args.config == "sp_mnn" and not args.cpu_pairs) else 1  # the headline sample: ~10-20 s of host work
-        tc = time.perf_counter()
-        nmatch = 0
-        for _ in range(passes):
-            oe = orc.extractor_forward(et, sub("event_extractor.extractor."), ev_np[:nb].copy(), mask_np[:nb], top_k=1024, scale=escale)
-            oi = orc.extractor_forward(it, sub("image_extractor.extractor."), img_np[:nb].copy(), None, top_k=1024, scale=iscale)
-            for b in range(nb):
-                if cfg.matcher.type == "MNN":
-                    r = orc.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=args.log_assignment)
-                else:
-                    r = orc.lightglue(sub("matcher.matcher."), oe["sparse_positions"][b], oe["sparse_descriptors"][b],
-                                      oi["sparse_positions"][b], oi["sparse_descriptors"][b])
-                nmatch += int((r["matches0"] > -1).sum())
-        cpu_s = time.perf_counter() - tc
-        nb *= passes
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        cpu_baseline = {"value": round(nb / cpu_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-                        "sample": f"{nb} pairs of the same workload through oracle/ (C, OpenMP on all host cores), {cpu_s:.1f} s"}
-
-    cpu_torch = None
+    # ---- CPU baseline (the oracle: a port, not the reference files) + verification, N=1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if last is None:
+            last = step()
+        cpu_baseline = cpu_baseline_and_verify(wl, args, last)
     if rank == 0 and world == 1 and args.cpu_torch and args.config == "sp_mnn":
         from oracle import torch_cpu
-        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
         nb = min(16, B)
-        torch_cpu.sp_mnn_pairs(sub("event_extractor.extractor."), sub("image_extractor.extractor."), ev_np[:2], mask_np[:2], img_np[:2].copy())
+        a_ = (wl.sub("event_extractor.extractor."), wl.sub("image_extractor.extractor."))
+        torch_cpu.sp_mnn_pairs(*a_, wl.ev_np[:2], wl.mask_np[:2], wl.img_np[:2].copy())
         tc = time.perf_counter()
-        torch_cpu.sp_mnn_pairs(sub("event_extractor.extractor."), sub("image_extractor.extractor."), ev_np[:nb], mask_np[:nb], img_np[:nb].copy())
+        torch_cpu.sp_mnn_pairs(*a_, wl.ev_np[:nb], wl.mask_np[:nb], wl.img_np[:nb].copy())
         cpu_s = time.perf_counter() - tc
-        cpu_torch = {"value": round(nb / cpu_s, 3), "unit": "pairs/s", "threads": torch.get_num_threads(), "kind": "plain PyTorch CPU expression (oracle/torch_cpu.py)",
-                     "sample": f"{nb} pairs, one batched call, {cpu_s:.1f} s"}
+        cpu_torch = {"value": round(nb / cpu_s, 3), "unit": "pairs/s", "threads": torch.get_num_threads(),
+                     "kind": "plain PyTorch CPU expression (oracle/torch_cpu.py)", "sample": f"{nb} pairs, one batched call, {cpu_s:.1f} s"}
+
+    # ---- short extra legs: the other BASELINE configs, B=1 latency, the round-1 (un-calibrated) weights ----
+    if do_extras:
+        def leg(config, batch, calibrate=True, steps=3, note=None):
+            w = wl if (config == args.config and batch == B and calibrate == wl.calibrated) else Workload(pkg, dev, config, batch, calibrate=calibrate)
+            sec, mm = w.timed(steps)
+            e = {"config": config, "workload": f"B{batch} " + WORKLOADS[config][2], "pairs_per_step": batch, "calibrated_descriptors": bool(w.calibrated),
+                 "value": round(batch / sec, 2), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": steps, "mean_matches": round(mm, 1)}
+            if note:
+                e["note"] = note
+            extras.append(e)
+            return w
+
+        lg_wl = None
+        if args.config == "sp_mnn":
+            lg_wl = leg("sp_lg", 64, note="BASELINE configs[3]")
+            stages = stage_rooflines(wl, lg_wl)
+            del lg_wl
+            torch.cuda.empty_cache()
+            w = leg("silk_mnn", 32, steps=2, note="BASELINE configs[2]")
+            del w
+            torch.cuda.empty_cache()
+            w = leg("sp_mnn", 1, steps=50, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
+            del w
+            w = leg("sp_mnn", 32, calibrate=wl.calibrated is False, steps=10,
+                    note="the other descriptor regime: " + ("calibrated" if not wl.calibrated else "round-1 un-calibrated weights (near-constant descriptors)"))
+            del w
+            torch.cuda.empty_cache()
+        else:
+            stages = stage_rooflines(wl, wl if args.config == "sp_lg" else None)
 
     if rank == 0:
+        wl_desc = f"B{B} " + WORKLOADS[args.config][2]
         out = {
             "metric": "event-image pairs/s (extract+match, 346x260, 1024 kpts)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "pairs_per_gpu_per_step": B, "global_batch": B * world, "event_bins": ce,
+            "config": {"workload": wl_desc, "pairs_per_gpu_per_step": B, "global_batch": B * world, "event_bins": wl.ce,
                        "parallelism": f"dp{world} (pairs sharded, metric all-reduce only)", "log_assignment": bool(args.log_assignment),
                        "dense_outputs": bool(args.dense),
+                       "weights": "seeded synthetic, descriptor-head bias calibrated (per-channel mean removed)" if wl.calibrated
+                       else "seeded synthetic, un-calibrated (near-constant descriptors)",
                        "mean_keypoints": [round(stats["keypoints0"] / pairs_total, 1), round(stats["keypoints1"] / pairs_total, 1)],
                        "mean_matches": round(stats["matches"] / pairs_total, 1),
                        "harness_metrics_mean": ([round(v, 5) for v in (metric_sums / pairs_total).tolist()] if args.with_metrics else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if stages:
+            out["roofline_stages"] = stages
+        if extras:
+            out["extra_configs"] = extras
+        if rccl is not None:
+            out["rccl"] = rccl
         if cpu_torch is not None:
             out["cpu_baseline_torch"] = cpu_torch
         print(json.dumps(out))
+        sys.stdout.flush()
     if distributed:
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and (args.gpus > 1 or args.spawn):
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_run_gloo:
+        if not under_launcher:  # one-rank rehearsal
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        return dry_run_gloo(args)
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -48,6 +48,8 @@ SIGNATURES = {
     "einx_version": (c_char_p, []),
     "einx_last_error": (c_char_p, []),
     "einx_device_count": (c_int, []),
+    "einx_profile_enable": (c_int, [c_int]),
+    "einx_profile_report": (c_int, [c_char_p, c_size_t]),
     "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "einx_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -18,7 +18,12 @@ def lib():
     return _lib.load()
 
 
-def _dev_check(*tensors):
+I32, I64, U8 = torch.int32, torch.int64, torch.uint8
+
+
+def _dev_check(*tensors, dt=F32):
+    """Every tensor must be a contiguous HIP tensor of dtype `dt`: the kernels read raw pointers and
+    assume the element size (an fp16/fp64/int64 tensor would be read out of bounds or as garbage)."""
     for t in tensors:
         if t is None:
             continue
@@ -26,6 +31,9 @@ def _dev_check(*tensors):
             raise RuntimeError(
                 "einx: tensors must live on a HIP device (torch device type 'cuda'); there is no CPU path. "
                 f"Got a tensor on {t.device}.")
+        if t.dtype != dt:
+            raise TypeError(f"einx: expected a {dt} tensor, got {t.dtype} (the kernels compute in fp32 with int32 counts/indices; "
+                            "cast at the call site, e.g. x.float())")
         if not t.is_contiguous():
             raise RuntimeError("einx: tensors must be contiguous")
 
@@ -112,7 +120,9 @@ def div_inplace(x, divisor):
 # ------------------------------------------------------------------------------ detector
 def score_map(logits, mask=None, pads=(0, 0, 0, 0), dilate=False, border=0):
     """-> (probability [B,C,hc,wc], score [B,1,Hp,Wp])."""
-    _dev_check(logits, mask)
+    _dev_check(logits)
+    if mask is not None and mask.device.type != "cuda":
+        raise RuntimeError(f"einx: the mask must live on a HIP device, got {mask.device}")
     B, C, hc, wc = logits.shape
     cell = 8 if C == 65 else 1
     Hp, Wp = hc * cell, wc * cell
@@ -184,7 +194,8 @@ def detect(score, *, top_k, radius, det_thr, pads=(0, 0, 0, 0), ordering="yx", c
 def desc_sample(raw, indices, counts, padded_size, bilinear, scale, raw_cl=None):
     """raw [B,D,hc,wc].  raw_cl: the channels-last copy [B,hc*wc,D] from normalize_map(want_cl=True);
     when given (bilinear only) the taps are read from it -- same values, coalesced rows."""
-    _dev_check(raw, indices, counts, raw_cl)
+    _dev_check(raw, raw_cl)
+    _dev_check(indices, counts, dt=I32)
     B, D, hc, wc = raw.shape
     cap = indices.shape[1]
     out = torch.empty((B, cap, D), dtype=F32, device=raw.device)
@@ -227,7 +238,8 @@ class MatchResult:
 
 
 def mnn(desc0, n, desc1, m, want_la=True):
-    _dev_check(desc0, desc1, n, m)
+    _dev_check(desc0, desc1)
+    _dev_check(n, m, dt=I32)
     B, cap0, D = desc0.shape
     cap1 = desc1.shape[1]
     L = lib()
@@ -246,7 +258,9 @@ def mnn(desc0, n, desc1, m, want_la=True):
 
 
 def gather_matches(r, kpts0, kpts1, n, cols):
-    _dev_check(kpts0, kpts1, n)
+    _dev_check(kpts0, kpts1)
+    _dev_check(n, dt=I32)
+    _dev_check(r.matches0, dt=I64)
     B, cap0, _ = kpts0.shape
     cap1 = kpts1.shape[1]
     dev = kpts0.device
@@ -271,7 +285,8 @@ def compact_matches(r):
 def lightglue(weights, pb0, pb1, want_la=True, want_ref=False, all_layers=False):
     """weights: _lib.LgWeights; pb0/pb1: PairBatch (kpts [B,cap,3], desc [B,cap,Din], counts).
     all_layers: ref0/ref1 are [B,n_layers,cap,d] (training-mode ref_descriptors) instead of [B,cap,d]."""
-    _dev_check(pb0.kpts, pb0.desc, pb0.counts, pb1.kpts, pb1.desc, pb1.counts)
+    _dev_check(pb0.kpts, pb0.desc, pb1.kpts, pb1.desc)
+    _dev_check(pb0.counts, pb1.counts, dt=I32)
     B, cap0, cap1 = pb0.B, pb0.cap, pb1.cap
     L = lib()
     dev = pb0.desc.device
@@ -301,7 +316,8 @@ def lightglue(weights, pb0, pb1, want_la=True, want_ref=False, all_layers=False)
 
 def similarity(desc0, n, desc1, m):
     """[B,cap0,cap1] descriptor similarity (MNN.py:88); zero outside the first n[b] x m[b] block."""
-    _dev_check(desc0, desc1, n, m)
+    _dev_check(desc0, desc1)
+    _dev_check(n, m, dt=I32)
     B, cap0, D = desc0.shape
     cap1 = desc1.shape[1]
     sim = torch.empty((B, cap0, cap1), dtype=F32, device=desc0.device)

@@ -36,7 +36,8 @@ def pair_metrics(kpts0, desc0, n, kpts1, desc1, m, mk0, mk1, nmatch, size0, size
         hom = homography.to(dev, torch.float32).reshape(B, 9).contiguous()
     ws = torch.empty(L.einx_metrics_ws_bytes(ctypes.byref(p)), dtype=torch.uint8, device=dev)
     out = torch.empty((B, 1 + p.n_mma + 3 * p.n_vdd), dtype=torch.float64, device=dev)
-    N._dev_check(kpts0, kpts1, desc0, desc1, n, m, mk0, mk1, nmatch)
+    N._dev_check(kpts0, kpts1, desc0, desc1, mk0, mk1)
+    N._dev_check(n, m, nmatch, dt=torch.int32)
     check(L.einx_pair_metrics(ctypes.byref(p), N._ptr(kpts0), N._ptr(kpts1), N._ptr(desc0), N._ptr(desc1), N._ptr(n), N._ptr(m), N._ptr(mk0),
                               N._ptr(mk1), N._ptr(nmatch), N._ptr(hom), N._ptr(ws), N._ptr(out), N._stream(kpts0)), "einx_pair_metrics")
     return out

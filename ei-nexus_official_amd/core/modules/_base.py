@@ -31,6 +31,10 @@ class NativeExtractor(nn.Module):
         self.dense_outputs = True  # reference-complete dict; set False to skip the 92 MB/image dense maps
         self._engine = None
         self._scale_host = None
+        self._sig = None
+        # runs for THIS module also when a parent's load_state_dict recurses into it (EIM, the
+        # Extractor wrappers, ImageImageMatcher), which never calls the child's own load_state_dict
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh())
 
     # -- cache invalidation: anything that moves or replaces parameters drops the native images
     def _apply(self, fn, *a, **k):
@@ -40,6 +44,11 @@ class NativeExtractor(nn.Module):
     def load_state_dict(self, *a, **k):
         self._engine = self._scale_host = None
         return super().load_state_dict(*a, **k)
+
+    def _signature(self):
+        """(storage, version) of every parameter and buffer: in-place edits (`p.data.copy_`, optimiser
+        steps, `load_state_dict`) bump `_version`, `.to()` / re-assignment change the storage."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def refresh(self):
         """Call after editing parameters in place (weights or descriptor_scale_factor)."""
@@ -54,6 +63,10 @@ class NativeExtractor(nn.Module):
         raise NotImplementedError
 
     def engine(self):
+        sig = self._signature()
+        if sig != self._sig:
+            self._engine = self._scale_host = None
+            self._sig = sig
         if self._engine is None:
             eng = ExtractorEngine(self.kind, top_k=self.detection_top_k, radius=self.nms_radius, border=self.remove_borders,
                                   det_thr=self.detection_threshold, ordering=self.ordering, cell=self.cell_size)

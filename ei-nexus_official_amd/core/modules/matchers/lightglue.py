@@ -113,6 +113,9 @@ class LightGlue(nn.Module):
         self.want_log_assignment = True
         self.fold_message_projection = True  # inference-time weight folding (see _pack); False = layer by layer as written
         self._packed = None
+        self._sig = None
+        # also reached when a parent module's load_state_dict recurses into this one
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh())
 
     def _apply(self, fn, *a, **k):
         self._packed = None
@@ -127,6 +130,9 @@ class LightGlue(nn.Module):
 
     def _pack(self):
         """ctypes image of the parameter pointers (weights stay in their nn.Parameter storage)."""
+        sig = tuple((t.data_ptr(), t._version) for t in self.parameters())
+        if sig != self._sig:  # in-place parameter edits and moves drop the folded weight images too
+            self._packed, self._sig = None, sig
         if self._packed is not None:
             return self._packed
         c = self.conf

@@ -5,6 +5,10 @@ import torch
 from ...._native import desc_sample, normalize_map, upsample_normalize
 
 
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.to(torch.float32)
+
+
 def _scale(scale_factor):
     return float(scale_factor.detach()) if torch.is_tensor(scale_factor) else float(scale_factor)
 
@@ -13,7 +17,7 @@ def normalize_descriptors(raw_descriptors, scale_factor=1.0, normalize=True):
     """L2 normalisation over dim 1 times scale (descriptor_util.py:21-28)."""
     if not normalize:
         raise NotImplementedError("einx: un-normalised descriptors are not used by EI-Nexus")
-    return normalize_map(raw_descriptors.contiguous(), _scale(scale_factor))
+    return normalize_map(_f32(raw_descriptors).contiguous(), _scale(scale_factor))
 
 
 def get_dense_descriptors(normalized_descriptors):
@@ -41,7 +45,7 @@ def sparsify_full_resolution_descriptors(raw_descriptors, positions, scale_facto
     """integer gather + normalise for cell-1 networks (descriptor_util.py:50-71)."""
     if not normalize:
         raise NotImplementedError
-    raw = raw_descriptors.contiguous()
+    raw = _f32(raw_descriptors).contiguous()
     H, W = raw.shape[-2:]
     idx, cnt = _pack_positions(positions, W)
     out = desc_sample(raw, idx, cnt, (H, W), bilinear=False, scale=_scale(scale_factor))
@@ -52,7 +56,7 @@ def sparsify_low_resolution_descriptors(raw_descriptors, positions, image_size, 
     """bilinear grid_sample at keypoints + normalise for cell-8 networks (descriptor_util.py:74-128)."""
     if not normalize:
         raise NotImplementedError
-    raw = raw_descriptors.contiguous()
+    raw = _f32(raw_descriptors).contiguous()
     Hp, Wp = int(image_size[0]), int(image_size[1])
     idx, cnt = _pack_positions(positions, Wp)
     out = desc_sample(raw, idx, cnt, (Hp, Wp), bilinear=True, scale=_scale(scale_factor))
@@ -61,4 +65,4 @@ def sparsify_low_resolution_descriptors(raw_descriptors, positions, image_size, 
 
 def upsample_descriptors(raw_descriptors, image_size, scale_factor=1.0):
     """bilinear resize + normalise (descriptor_util.py:131-138)."""
-    return upsample_normalize(raw_descriptors.contiguous(), image_size, (0, 0, 0, 0), _scale(scale_factor))
+    return upsample_normalize(_f32(raw_descriptors).contiguous(), image_size, (0, 0, 0, 0), _scale(scale_factor))

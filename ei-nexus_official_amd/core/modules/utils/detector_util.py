@@ -7,11 +7,17 @@ import torch
 from ...._native import detect, remove_border, score_map
 
 
+def _f32(t):
+    """the kernels compute in fp32; other float dtypes (autocast halves, doubles), which the reference's
+    torch ops would accept, are cast here instead of being misread through a raw pointer"""
+    return t if t.dtype == torch.float32 else t.to(torch.float32)
+
+
 def logits_to_prob(logits, channel_dim=1):
     """softmax over 65 channels / sigmoid for 1 channel (detector_util.py:18-40)."""
     if channel_dim != 1 or logits.dim() != 4:
         raise NotImplementedError("einx: logits must be [B,C,h,w] with channel_dim=1")
-    prob, _ = score_map(logits.contiguous())
+    prob, _ = score_map(_f32(logits).contiguous())
     return prob
 
 
@@ -46,7 +52,7 @@ def fast_nms(image_probs, nms_dist=4, max_iter=-1, min_value=0.0):
     if max_iter != -1 or min_value != 0.0:
         raise NotImplementedError
     shape = image_probs.shape
-    m = image_probs.reshape(-1, shape[-2], shape[-1]).contiguous()
+    m = _f32(image_probs).reshape(-1, shape[-2], shape[-1]).contiguous()
     iters = 8
     while True:
         d = detect(m, top_k=0, radius=nms_dist, det_thr=_neg_inf(), cap=1, nms_iters=iters)
@@ -59,7 +65,7 @@ def prob_map_to_points_map(prob_map, prob_thresh=0.015, nms_dist=4, border_dist=
     """border removal (in place on prob_map) -> NMS -> top-k / threshold (detector_util.py:80-135)."""
     if not use_fast_nms:
         raise NotImplementedError("einx implements the fast_nms path the extractors use")
-    remove_border_points(prob_map, border_dist)
+    remove_border_points(prob_map, border_dist)  # in place: needs an fp32 map (TypeError otherwise)
     m = prob_map.squeeze(1) if prob_map.dim() == 4 else prob_map
     m = m.contiguous()
     iters = 8
@@ -73,7 +79,7 @@ def prob_map_to_points_map(prob_map, prob_thresh=0.015, nms_dist=4, border_dist=
 def prob_map_to_positions_with_prob(prob_map, threshold=0.0, ordering="yx"):
     """raster-order nonzero + 0.5, with the probability as third column (detector_util.py:451-484)."""
     m = prob_map.squeeze(1) if prob_map.dim() == 4 else prob_map
-    m = m.contiguous()
+    m = _f32(m).contiguous()
     B, H, W = m.shape
     d = detect(m, top_k=0, radius=0, det_thr=float(threshold), ordering=ordering, cap=H * W, want_nms=False)
     counts = d.counts.cpu().tolist()

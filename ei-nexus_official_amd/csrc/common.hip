@@ -1,6 +1,12 @@
 // Error channel, version and device probing for libeinx_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "einx_common.h"
 
@@ -15,6 +21,74 @@ void einx_set_error(const char* fmt, ...) {
 
 EINX_EXPORT const char* einx_version(void) { return "einx-hip 0.1 (gfx950)"; }
 EINX_EXPORT const char* einx_last_error(void) { return g_err; }
+
+// ---- per-kernel-class timing with HIP events on the launch stream (measurement aid: bench.py's
+// roofline_stages).  Off by default: a scope costs one relaxed load when disabled.
+namespace {
+struct ProfRec {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+volatile int g_prof_on = 0;
+}  // namespace
+
+EinxProfScope::EinxProfScope(const char* name, hipStream_t s) : stream_(s), idx_(-1) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  r.name = name;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  idx_ = (int)g_prof_recs.size();
+  g_prof_recs.push_back(r);
+}
+
+EinxProfScope::~EinxProfScope() {
+  if (idx_ < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx_ < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx_].e1, stream_);
+}
+
+EINX_EXPORT int einx_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof_recs.clear();
+  g_prof_on = on ? 1 : 0;
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_profile_report(char* buf, size_t cap) {
+  EINX_CHECK_ARG(buf && cap > 0, "null buffer");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::map<std::string, std::pair<int, double>> agg;
+  std::vector<std::string> order;
+  for (auto& r : g_prof_recs) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    auto it = agg.find(r.name);
+    if (it == agg.end()) {
+      agg[r.name] = {1, (double)ms};
+      order.push_back(r.name);
+    } else {
+      it->second.first += 1;
+      it->second.second += ms;
+    }
+  }
+  size_t off = 0;
+  buf[0] = 0;
+  for (auto& n : order) {
+    const int w = snprintf(buf + off, cap - off, "%s %d %.6f\n", n.c_str(), agg[n].first, agg[n].second);
+    if (w < 0 || (size_t)w >= cap - off) break;
+    off += (size_t)w;
+  }
+  return EINX_OK;
+}
 
 EINX_EXPORT int einx_device_count(void) {
   int n = 0;

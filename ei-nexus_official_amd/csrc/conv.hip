@@ -366,6 +366,16 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean
 // channels (the largest chunk any kernel variant stages) so that chunk loads never need bounds
 int native_krows(int cin, int taps) { return einx_cdiv(cin, 32) * 32 * taps; }
 
+// tuning switch (tools only): EINX_CONV_EXP=<bitmask> selects experimental wave layouts, read once per process
+int conv_exp() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("EINX_CONV_EXP");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 struct TileCfg {
   int th, tw, slots;  // slots = pixel slots a workgroup launches for this tile
 };
@@ -374,8 +384,9 @@ template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool P
 void launch(const ConvArgs& a, int B, hipStream_t s) {
   // the offset-table reload (EXACT) is used where it measured faster (bench.py --layer-table, B=32): every
   // 3x3 tile except 11x22, whose 768-workgroup launches on the 256-channel heads ran 20 % slower with it
-  const bool exact = (a.Cin % CK) == 0 && KS == 3 && !(TH == 11 && TW == 22);
+  const bool exact = (a.Cin % CK) == 0 && KS == 3 && (!(TH == 11 && TW == 22) || ((conv_exp() & 8) && a.Cin <= 64));
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
+  EINX_PROF(KS == 1 ? "conv_block_kernel 1x1" : (CK < 8 ? "conv_block_kernel 3x3 first layer" : "conv_block_kernel 3x3"), s);
   if (exact) hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, true>), grid, dim3(WM * WN * 64), 0, s, a);
   else hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, false>), grid, dim3(WM * WN * 64), 0, s, a);
 }
@@ -496,8 +507,14 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   if (d->pool) {
     switch (best) {
       case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s); break;
-      case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
-      default: launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s); break;
+      case 1:
+        if (conv_exp() & 1) launch<3, 12, 16, 2, 6, 1, 1, 8, true>(a, B, s);
+        else launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s);
+        break;
+      default:
+        if (conv_exp() & 2) launch<3, 22, 8, 2, 6, 1, 1, 8, true>(a, B, s);
+        else launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s);
+        break;
     }
   } else {
     switch (best) {
@@ -509,7 +526,10 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
       case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;
-      case 3: launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s); break;
+      case 3:
+        if (conv_exp() & 4) launch<3, 11, 22, 2, 8, 1, 1, 8, false>(a, B, s);
+        else launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s);
+        break;
       default: launch<3, 11, 11, 2, 2, 1, 2, 8, false>(a, B, s); break;
     }
   }

@@ -321,6 +321,7 @@ EINX_EXPORT int einx_desc_sample(const float* raw, int B, int D, int hc, int wc,
   EINX_CHECK_ARG(!channels_last || bilinear, "the channels-last layout is implemented for bilinear sampling");
   dim3 grid((unsigned)einx_cdiv(cap, 4), (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
+  EINX_PROF("desc_sample_kernel", s);
   if (bilinear && channels_last)
     hipLaunchKernelGGL((desc_sample_kernel<true, true>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
   else if (bilinear)
@@ -335,6 +336,7 @@ EINX_EXPORT int einx_normalize_map(const float* raw, int B, int D, int P, float 
   EINX_CHECK_ARG(raw && out, "null pointer");
   EINX_CHECK_ARG(B > 0 && D > 0 && P > 0, "bad shape");
   hipStream_t s = (hipStream_t)stream;
+  EINX_PROF("normalize_map", s);
   if (D <= 256) {
     hipLaunchKernelGGL(normalize_map_tile_kernel<64>, dim3((unsigned)einx_cdiv(P, 64), (unsigned)B), dim3(256), (size_t)D * 64 * sizeof(float), s,
                        raw, D, P, scale, out, raw_cl);

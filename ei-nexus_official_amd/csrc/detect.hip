@@ -812,6 +812,7 @@ EINX_EXPORT int einx_score_map(const float* logits, int B, int C, int hc, int wc
   EINX_CHECK_ARG(C == 65 || C == 1, "detector head must have 65 or 1 channels");
   EINX_CHECK_ARG(B > 0 && hc > 0 && wc > 0, "bad shape");
   hipStream_t s = (hipStream_t)stream;
+  EINX_PROF("score_map (score65/score1)", s);
   if (C == 65) {
     const int n = B * hc * wc;
     hipLaunchKernelGGL(score65_kernel, dim3(einx_cdiv(n, 32)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
@@ -874,6 +875,7 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
     const dim3 grid((unsigned)(tilesX * tilesY * p->B));
     for (int it = 0; it < nIt; ++it) {
       float* dst = (it & 1) ? buf1 : buf0;
+      EINX_PROF("nms_pass", s);
       switch (p->radius) {
         case 1: hipLaunchKernelGGL(nms_pass_kernel<1>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
         case 2: hipLaunchKernelGGL(nms_pass_kernel<2>, grid, dim3(NMS_THREADS), 0, s, cur, dst, p->Hp, p->Wp, tilesX, tilesY, flags, it, nIt); break;
@@ -906,8 +908,12 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
   a.det_thr = p->det_thr;
   a.lo = a.hi = 0;
   if (p->top_k > 0 && p->top_k < N) topk_ranks(N, p->top_k, &a.lo, &a.hi);
-  hipLaunchKernelGGL(select_compact_kernel, dim3(p->B), dim3(SEL_THREADS), 0, s, a);
+  {
+    EINX_PROF("select_compact_kernel", s);
+    hipLaunchKernelGGL(select_compact_kernel, dim3(p->B), dim3(SEL_THREADS), 0, s, a);
+  }
   if (nms_out) {
+    EINX_PROF("nms_crop_kernel", s);
     EINX_CHECK_LAUNCH();
     const size_t n = (size_t)p->B * p->H * p->W;
     hipLaunchKernelGGL(nms_crop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.map, thr, p->B, p->Hp, p->Wp, p->h0, p->w0, p->H, p->W,

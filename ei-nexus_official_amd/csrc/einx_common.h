@@ -27,6 +27,20 @@ void einx_set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+// RAII timing scope around one kernel launch (or a group of launches) on `stream`; a no-op unless
+// einx_profile_enable(1) was called.  Usage: `EinxProfScope prof("lg_gemm", stream);` before the launch.
+class EinxProfScope {
+ public:
+  EinxProfScope(const char* name, hipStream_t s);
+  ~EinxProfScope();
+
+ private:
+  hipStream_t stream_;
+  int idx_;
+};
+
+#define EINX_PROF(name, stream) EinxProfScope einx_prof_scope_(name, (hipStream_t)(stream))
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

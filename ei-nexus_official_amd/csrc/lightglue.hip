@@ -576,6 +576,7 @@ int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx,
   g.div = div;
   g.B = B;
   const dim3 grid(gemm_grid(einx_cdiv(N, BN) * einx_cdiv(s.cap, BM) * B));
+  EINX_PROF("lg_gemm_kernel", st);
   if (epi == EPI_BIAS) hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, st, g);
   else if (epi == EPI_DIV) hipLaunchKernelGGL(lg_gemm_kernel<EPI_DIV>, grid, dim3(THREADS), 0, st, g);
   else hipLaunchKernelGGL(lg_gemm_kernel<EPI_RESID>, grid, dim3(THREADS), 0, st, g);
@@ -605,6 +606,7 @@ int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const float* X, const fl
   g.Yk = k;
   g.Yv = v;
   const dim3 grid(gemm_grid(einx_cdiv(3 * D, BN) * einx_cdiv(s.cap, BM) * B));
+  EINX_PROF("lg_gemm_kernel", st);
   hipLaunchKernelGGL(lg_gemm_kernel<EPI_ROPE>, grid, dim3(THREADS), 0, st, g);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -621,6 +623,7 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
   a.capq = capq;
   a.capk = capk;
   a.scale = 0.125f;  // 1/sqrt(64): SDPA scale (self) = (64^-1/4)^2 (cross, lightglue.py:316)
+  EINX_PROF("lg_attn_kernel", st);
   hipLaunchKernelGGL(lg_attn_kernel, dim3((unsigned)einx_cdiv(capq, 128), HEADS, (unsigned)B), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -629,7 +632,10 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
 int ffn(hipStream_t st, const Side& s, int B, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
         const float* w3, const float* b3) {
   if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
-  hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+  {
+    EINX_PROF("lg_ln_gelu_kernel", st);
+    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+  }
   if (hipGetLastError() != hipSuccess) return -1;
   return gemm(st, EPI_RESID, s, B, s.h, 2 * D, nullptr, 0, 0x7fffffff, 2 * D, w3, b3, D, s.x, D);
 }
@@ -814,6 +820,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   }
   const dim3 grid((unsigned)einx_cdiv(cap1, BN), (unsigned)einx_cdiv(cap0, BM), (unsigned)B);
   const int mx = cap0 > cap1 ? cap0 : cap1;
+  EINX_PROF("lg_assignment (3 tile passes + lse + finalize)", st);
   hipLaunchKernelGGL((mnn_tile_kernel<1, false>), grid, dim3(THREADS), 0, st, a);
   LG_CHECK(0);
   hipLaunchKernelGGL(mnn_lse_kernel, dim3((unsigned)einx_cdiv(mx + 1, 256), (unsigned)B), dim3(256), 0, st, a);

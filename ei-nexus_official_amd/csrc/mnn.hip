@@ -59,7 +59,10 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
     return EINX_ERR_LAUNCH;
   }
   const dim3 grid((unsigned)einx_cdiv(cap1, BN), (unsigned)einx_cdiv(cap0, BM), (unsigned)B);
-  hipLaunchKernelGGL(mnn_tile_kernel<0>, grid, dim3(THREADS), 0, s, a);
+  {
+    EINX_PROF("mnn_tile_kernel<0>", s);
+    hipLaunchKernelGGL(mnn_tile_kernel<0>, grid, dim3(THREADS), 0, s, a);
+  }
   EINX_CHECK_LAUNCH();
   const int mx = cap0 > cap1 ? cap0 : cap1;
   hipLaunchKernelGGL(mnn_finalize_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, s, a.rowkey, a.colkey, n, m,

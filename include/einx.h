@@ -32,6 +32,14 @@ const char* einx_last_error(void);
 /* number of visible HIP devices (0 without a GPU); never initialises a context beyond that */
 int einx_device_count(void);
 
+/* Measurement aid (no reference counterpart; the reference's scripts time with wall clocks around
+ * whole forwards, test_events-image_same-time.py:196-208): while enabled, every kernel launch of
+ * this library is bracketed by HIP events recorded on the launch stream.  einx_profile_report
+ * waits for them and writes one text line per kernel class, "name calls total_ms\n", into `buf`
+ * (host memory).  einx_profile_enable(0|1) also clears the collected records. */
+int einx_profile_enable(int on);
+int einx_profile_report(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution blocks  (K1/K2 of SURVEY.md 2.3)
  * replaces: nn.Conv2d(3x3,pad 1 | 1x1) + ReLU + BatchNorm2d(eval) + MaxPool2d(2,2)

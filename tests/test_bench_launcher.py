@@ -1,0 +1,57 @@
+"""bench.py as its own rank launcher (`python bench.py --gpus N` spawns N ranks before any GPU call):
+rehearsed on CPU with gloo through the same launcher code, and the no-GPU failure mode is loud."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=240, env=env)
+
+
+def test_launcher_spawns_two_gloo_ranks():
+    r = _run("--gpus", "2", "--dry-run-gloo", "--steps", "4")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # only rank 0 prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True
+    B, steps = 32, 4
+    assert d["pairs"] == 2 * steps * B  # whole-job aggregate over both ranks (the accumulator all-reduce)
+    assert d["keypoints0"] == steps * (B * 1000 + 0) + steps * (B * 1000 + 1)
+    assert d["matches"] == steps * 10 + steps * 20
+    assert d["config"]["global_batch"] == 2 * B
+
+
+def test_launcher_passes_config_and_batch():
+    r = _run("--gpus", "2", "--dry-run-gloo", "--steps", "1", "--config", "sp_lg", "--batch", "64")
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["pairs_per_gpu_per_step"] == 64 and d["config"]["global_batch"] == 128
+    assert "LightGlue" in d["config"]["workload"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box without a GPU")
+def test_without_gpu_every_rank_fails_loudly_and_nothing_hangs():
+    r = _run("--gpus", "2", "--steps", "1")
+    assert r.returncode != 0
+    assert "rank 0" in r.stderr and "rank 1" in r.stderr and "HIP device" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no bench line without a measurement
+
+
+def test_rank_env_is_honoured_without_relaunch():
+    """Under torchrun (RANK/WORLD_SIZE already set) bench.py must be a rank, not a launcher."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run-gloo", "--steps", "2"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["pairs"] == 64

@@ -92,3 +92,44 @@ def test_padder_and_ranks():
     xp = p.pad(x)[0]
     assert xp.shape[-2:] == (264, 352)
     assert torch.equal(p.unpad(xp)[0], x)
+
+
+def test_parent_load_state_dict_invalidates_native_weight_images():
+    """nn.Module.load_state_dict on a PARENT recurses through _load_from_state_dict and never
+    calls the child's load_state_dict override; the cached kernel-native images must still be dropped."""
+    model = pkg.EIM(pkg.default_config("SP_LG"), device="cpu").eval()
+    ext = model.image_extractor.extractor
+    lg = model.matcher.matcher
+    sentinel = object()
+    ext._engine, ext._scale_host, lg._packed = sentinel, 1.0, sentinel
+    model.load_state_dict(model.state_dict())
+    assert ext._engine is None and ext._scale_host is None and lg._packed is None
+    # in-place parameter edits (optimiser steps, p.data.copy_) change the signature the caches are keyed on
+    ev = model.event_extractor.extractor
+    s0 = ev._signature()
+    with torch.no_grad():
+        next(ev.parameters()).add_(1.0)
+    assert ev._signature() != s0
+
+
+def test_native_wrappers_reject_wrong_dtypes():
+    """raw-pointer kernels assume fp32 / int32; anything else must raise, not be misread."""
+    nat = pkg.native
+
+    class FakeCuda:  # a tensor that claims to be on a HIP device, enough for the checks that run before any launch
+        def __init__(self, t):
+            self.t = t
+            self.device = torch.device("cuda", 0)
+            self.dtype = t.dtype
+
+        def is_contiguous(self):
+            return True
+
+    for bad in (torch.float16, torch.bfloat16, torch.float64, torch.int64):
+        with pytest.raises(TypeError, match="expected a torch.float32"):
+            nat._dev_check(FakeCuda(torch.zeros(4, dtype=bad)))
+    with pytest.raises(TypeError, match="expected a torch.int32"):
+        nat._dev_check(FakeCuda(torch.zeros(4, dtype=torch.int64)), dt=torch.int32)
+    nat._dev_check(FakeCuda(torch.zeros(4)), None)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        nat._dev_check(torch.zeros(4))
