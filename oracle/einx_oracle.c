@@ -544,6 +544,61 @@ EXPORT void orc_mnn(const float* d0, int n, const float* d1, int m, int D, int64
   free(sim);
 }
 
+/* find_nn with the optional thresholds (core/modules/matchers/MNN.py:11-22) + mutual_check (:25-32).
+ * k = 2 if ratio_thresh else 1; sim.topk(k) per row (per column for matches1, :89-92):
+ *   dist = 2 * (1 - sim_nn)                                  (fp32)
+ *   mask &= dist[0] <= ratio_thresh**2 * dist[1]             (scalar rounded to fp32 by torch, product in fp32)
+ *   mask &= dist[0] <= distance_thresh**2
+ * The second neighbour counts multiplicity (topk returns an equal value twice), the first index wins ties.
+ * use_ratio needs at least two candidates per row and per column (torch.topk raises otherwise): returns -1. */
+static void find_nn_rows(const float* sim, int n, int m, size_t si, size_t sj, int use_ratio, float ratio_sq, int use_dist, float dist_sq,
+                         int64_t* out) {
+  for (int i = 0; i < n; ++i) {
+    int best = 0;
+    for (int j = 1; j < m; ++j)
+      if (sim[i * si + j * sj] > sim[i * si + best * sj]) best = j;
+    const float d0 = 2.0f * (1.0f - sim[i * si + best * sj]);
+    int ok = 1;
+    if (use_ratio) {
+      int sec = -1;
+      for (int j = 0; j < m; ++j) {
+        if (j == best) continue;
+        if (sec < 0 || sim[i * si + j * sj] > sim[i * si + sec * sj]) sec = j;
+      }
+      const float d1 = 2.0f * (1.0f - sim[i * si + sec * sj]);
+      ok = ok && (d0 <= ratio_sq * d1);
+    }
+    if (use_dist) ok = ok && (d0 <= dist_sq);
+    out[i] = ok ? best : -1;
+  }
+}
+
+EXPORT int orc_mnn_thresh(const float* d0, int n, const float* d1, int m, int D, int use_ratio, float ratio_sq, int use_dist, float dist_sq,
+                          int64_t* m0, int64_t* m1, float* s0, float* s1) {
+  if (use_ratio && (n < 2 || m < 2)) return -1;
+  float* sim = (float*)malloc(sizeof(float) * (size_t)n * m);
+#pragma omp parallel for
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < D; ++k) acc = fmaf(d0[(size_t)i * D + k], d1[(size_t)j * D + k], acc);
+      sim[(size_t)i * m + j] = acc;
+    }
+  find_nn_rows(sim, n, m, (size_t)m, 1, use_ratio, ratio_sq, use_dist, dist_sq, m0);
+  find_nn_rows(sim, m, n, 1, (size_t)m, use_ratio, ratio_sq, use_dist, dist_sq, m1);
+  int64_t* t0 = (int64_t*)malloc(sizeof(int64_t) * n);
+  memcpy(t0, m0, sizeof(int64_t) * n);
+  for (int i = 0; i < n; ++i)  /* loop0 = m1[m0 > -1 ? m0 : 0]; keep m0 if m0 > -1 and loop0 == i */
+    if (!(m0[i] > -1 && m1[m0[i]] == i)) m0[i] = -1;
+  for (int j = 0; j < m; ++j)
+    if (!(m1[j] > -1 && t0[m1[j]] == j)) m1[j] = -1;
+  free(t0);
+  for (int i = 0; i < n; ++i) s0[i] = m0[i] > -1 ? 1.0f : 0.0f;
+  for (int j = 0; j < m; ++j) s1[j] = m1[j] > -1 ? 1.0f : 0.0f;
+  free(sim);
+  return 0;
+}
+
 /* =======================================================================================
  * LightGlue building blocks (core/modules/matchers/lightglue.py).
  * ===================================================================================== */

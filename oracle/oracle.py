@@ -223,6 +223,25 @@ def mnn(d0, d1, want_la=True, want_sim=False):
     return dict(matches0=m0, matches1=m1, matching_scores0=s0, matching_scores1=s1, log_assignment=la, similarity=sim)
 
 
+def mnn_thresh(d0, d1, ratio_thresh=None, distance_thresh=None):
+    """find_nn with ratio / distance thresholds + mutual check (MNN.py:11-32); the Python scalars are squared
+    in double and rounded to fp32 once, as torch does for `tensor <= scalar` / `scalar * tensor`."""
+    d0, d1 = _c(d0), _c(d1)
+    n, D = d0.shape
+    m = d1.shape[0]
+    m0, m1 = np.empty((n,), np.int64), np.empty((m,), np.int64)
+    s0, s1 = np.empty((n,), np.float32), np.empty((m,), np.float32)
+    r2 = np.float32(float(ratio_thresh) ** 2) if ratio_thresh else np.float32(0)
+    t2 = np.float32(float(distance_thresh) ** 2) if distance_thresh else np.float32(0)
+    L = lib()
+    L.orc_mnn_thresh.restype = ctypes.c_int
+    rc = L.orc_mnn_thresh(_f(d0), n, _f(d1), m, D, int(bool(ratio_thresh)), ctypes.c_float(r2), int(bool(distance_thresh)), ctypes.c_float(t2),
+                          m0.ctypes.data_as(c_i64), m1.ctypes.data_as(c_i64), _f(s0), _f(s1))
+    if rc != 0:
+        raise RuntimeError("selected index k out of range")  # what torch.topk(2) raises on a single candidate
+    return dict(matches0=m0, matches1=m1, matching_scores0=s0, matching_scores1=s1)
+
+
 # ------------------------------------------------------------------------------ extractors
 def _blk(sd, prefix, conv, bn):
     w, b = sd[f"{prefix}{conv}.weight"], sd[f"{prefix}{conv}.bias"]
