@@ -237,7 +237,8 @@ class MatchResult:
         self.mk0_flat = self.mk1_flat = None
 
 
-def mnn(desc0, n, desc1, m, want_la=True):
+def mnn(desc0, n, desc1, m, want_la=True, ratio_thresh=None, distance_thresh=None):
+    """ratio_thresh / distance_thresh: find_nn's optional thresholds (MNN.py:12-22), falsy = off."""
     _dev_check(desc0, desc1)
     _dev_check(n, m, dt=I32)
     B, cap0, D = desc0.shape
@@ -252,6 +253,14 @@ def mnn(desc0, n, desc1, m, want_la=True):
     r.scores1 = torch.empty((B, cap1), dtype=F32, device=dev)
     r.la = torch.empty((B, cap0 + 1, cap1 + 1), dtype=F32, device=dev) if want_la else None
     r.ref0 = r.ref1 = None
+    if ratio_thresh or distance_thresh:
+        # the squared Python scalars are rounded to fp32 once, as torch does for `tensor <= scalar` / `scalar * tensor`
+        r2 = float(np.float32(float(ratio_thresh) ** 2)) if ratio_thresh else 0.0
+        t2 = float(np.float32(float(distance_thresh) ** 2)) if distance_thresh else 0.0
+        check(L.einx_mnn_thresh(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, int(bool(ratio_thresh)), r2,
+                                int(bool(distance_thresh)), t2, _ptr(ws), _ptr(r.matches0), _ptr(r.matches1), _ptr(r.scores0), _ptr(r.scores1),
+                                _ptr(r.la), _stream(desc0)), "einx_mnn_thresh")
+        return r
     check(L.einx_mnn(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, _ptr(ws), _ptr(r.matches0), _ptr(r.matches1),
                      _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _stream(desc0)), "einx_mnn")
     return r

@@ -1,8 +1,41 @@
-"""ValidDescriptorsDistance with the reference's class name and `update_one` signature
-(core/metrics/keypoints_metrics.py:160-290), computed by csrc/metrics.hip."""
+"""Repeatability and ValidDescriptorsDistance with the reference's class names and `update_one` /
+`update_batch` signatures (core/metrics/keypoints_metrics.py:54-157, :160-329), computed by csrc/metrics.hip."""
 import torch
 
 from ._native_metrics import single_pair
+
+
+class Repeatability:
+    """(count1 + count2) / (N + M) of mutual nearest warped keypoints within `distance_thresh`
+    (keypoints_metrics.py:54-157).  The same neighbour pass as ValidDescriptorsDistance's repeatability
+    (identical whenever either image has keypoints; with none on both sides the reference emits no entry).
+    ordering "xy": rows are (x, y); "yx": rows are (y, x) -- note the opposite convention of
+    ValidDescriptorsDistance (keypoints_metrics.py:86-91 vs :193-198)."""
+
+    def __init__(self, name, distance_thresh=3, ordering="xy"):
+        assert ordering in ["xy", "yx"]
+        self.distance_thresh = distance_thresh
+        self.metric_name = name
+        self.ordering = ordering
+
+    @torch.no_grad()
+    def update_one(self, points1, points2, img1_shape, img2_shape, homography):
+        assert homography.shape == (3, 3)
+        if points1.shape[0] + points2.shape[0] == 0:
+            return {}
+        r = single_pair(points1, points2, None, None, None, None, img1_shape, img2_shape, homography, (), (self.distance_thresh,),
+                        ordering=self.ordering)
+        return {self.metric_name: r[f"VDD_Repeatability@{self.distance_thresh}"]}
+
+    @torch.no_grad()
+    def update_batch(self, points1, points2, img1_shape, img2_shape, homography):
+        assert len(points1) == len(points2) == len(homography)
+        vals = []
+        for i in range(len(points1)):
+            one = self.update_one(points1[i], points2[i], img1_shape, img2_shape, homography[i])
+            if self.metric_name in one:
+                vals.append(one[self.metric_name])
+        return {self.metric_name: torch.tensor(vals).mean().item()}
 
 
 class ValidDescriptorsDistance:

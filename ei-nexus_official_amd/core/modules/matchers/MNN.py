@@ -3,8 +3,8 @@
 Drop-in for NearestNeighborMatcher (reference core/modules/matchers/MNN.py:35-140): same
 constructor and the same output dict, minus `similarity` unless `return_similarity` is set (the
 reference's Matcher wrapper drops it anyway, Matchers.py:177-186).  The ratio / distance
-thresholds are disabled in every shipped config (configs/model/SP_MNN.yaml:65-66) and are not
-implemented.
+thresholds of find_nn (MNN.py:12-22; off in every shipped config, configs/model/SP_MNN.yaml:65-66)
+run as a second-neighbour tile pass + a masked finalize (einx_mnn_thresh).
 """
 import torch
 from torch import nn
@@ -16,8 +16,6 @@ from ._batched import from_feats, materialize_matches, stacked_outputs
 class NearestNeighborMatcher(nn.Module):
     def __init__(self, ratio_thresh=None, distance_thresh=None, mutual_check=True):
         super().__init__()
-        if ratio_thresh or distance_thresh:
-            raise NotImplementedError("einx MNN implements the shipped configuration (no ratio / distance threshold)")
         if not mutual_check:
             raise NotImplementedError("einx MNN always applies the mutual check, as every EI-Nexus config does")
         self.ratio_thresh = ratio_thresh
@@ -28,7 +26,8 @@ class NearestNeighborMatcher(nn.Module):
 
     def match_batched(self, pb0, pb1):
         """device-side: no host sync"""
-        r = N.mnn(pb0.desc, pb0.counts, pb1.desc, pb1.counts, want_la=self.want_log_assignment)
+        r = N.mnn(pb0.desc, pb0.counts, pb1.desc, pb1.counts, want_la=self.want_log_assignment, ratio_thresh=self.ratio_thresh,
+                  distance_thresh=self.distance_thresh)
         return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 3)
 
     @torch.no_grad()
@@ -51,6 +50,8 @@ class NearestNeighborMatcher(nn.Module):
         nm = r.nmatch.cpu().tolist()
         n = pb0.counts_host or pb0.counts.cpu().tolist()
         m = pb1.counts_host or pb1.counts.cpu().tolist()
+        if self.ratio_thresh and any((0 < a < 2 or 0 < b < 2) and a > 0 and b > 0 for a, b in zip(n, m)):
+            raise RuntimeError("selected index k out of range")  # sim.topk(2) on a single candidate (MNN.py:13-14)
         if pb0.B == 1:
             out = {k: v[0] for k, v in materialize_matches(r, n, m, nm, 3).items()}
             if self.return_similarity and n[0] and m[0]:

@@ -33,10 +33,15 @@ struct MnnArgs {
   const float* cert1;  // [B,cap1] logsigmoid(z1)
   const float* dust0;  // [B,cap0] logsigmoid(-z0): last column of the assignment
   const float* dust1;  // [B,cap1] logsigmoid(-z1): last row
+  // find_nn thresholds (MNN.py:12-22): second-best similarity per row / column as ordered 32-bit keys (MODE 4)
+  unsigned* row2;  // [B,cap0]
+  unsigned* col2;  // [B,cap1]
 };
 
 // MODE 0: arg-max keys.  MODE 1: per-chunk softmax statistics.  MODE 2: write log_assignment.
 // MODE 3: write the raw similarity tile to a.la as [B,cap0,cap1] (MNN.py:88 `similarity`).
+// MODE 4: second neighbour (topk(2)[1], MNN.py:13-14): per row the maximum over all columns but the arg-max
+//         column found by MODE 0 (an equal value at another index counts, as topk returns it), same per column.
 // LG: values are LightGlue's assignment scores (needs rowlse/collse from MODE 1 + mnn_lse_kernel).
 template <int MODE, bool LG = false>
 __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
@@ -173,6 +178,38 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
         o[1] = s;
       }
     }
+  } else if (MODE == 4) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int j = j0 + col_of(nt);
+      const int besti = j < m ? (int)(0xFFFFFFFFu - (unsigned)(a.colkey[(size_t)b * a.cap1 + j] & 0xFFFFFFFFull)) : -1;
+      unsigned key = 0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + row_of(mt, r);
+          if (i < n && i != besti) key = max(key, einx_ordered_key(f.acc[mt][nt][r]));
+        }
+      key = max(key, (unsigned)__shfl_xor((int)key, 32, 64));
+      if (half == 0 && j < m && key) atomicMax(&a.col2[(size_t)b * a.cap1 + j], key);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + row_of(mt, r);
+        const int bestj = i < n ? (int)(0xFFFFFFFFu - (unsigned)(a.rowkey[(size_t)b * a.cap0 + i] & 0xFFFFFFFFull)) : -1;
+        unsigned key = 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int j = j0 + col_of(nt);
+          if (j < m && j != bestj) key = max(key, einx_ordered_key(f.acc[mt][nt][r]));
+        }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, off, 64));
+        if ((lane & 31) == 0 && i < n && key) atomicMax(&a.row2[(size_t)b * a.cap0 + i], key);
+      }
   } else if (MODE == 3) {
     float* sim = a.la + (size_t)b * a.cap0 * a.cap1;
 #pragma unroll
@@ -267,6 +304,46 @@ __global__ void mnn_finalize_kernel(const unsigned long long* rowkey, const unsi
       const int i = (int)(0xFFFFFFFFu - (unsigned)(ck[t] & 0xFFFFFFFFull));
       const int back = (int)(0xFFFFFFFFu - (unsigned)(rk[i] & 0xFFFFFFFFull));
       if (back == t) r = i;
+    }
+    m1[(size_t)b * cap1 + t] = r;
+    s1[(size_t)b * cap1 + t] = r > -1 ? 1.0f : 0.0f;
+  }
+}
+
+// find_nn with thresholds (MNN.py:12-22) + mutual check on the masked matches (:25-32)
+__device__ __forceinline__ int thresh_match(unsigned long long key, unsigned second, int use_ratio, float ratio_sq, int use_dist, float dist_sq) {
+  const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  const float d0 = 2.0f * (1.0f - einx_ordered_unkey((unsigned)(key >> 32)));
+  bool ok = true;
+  if (use_ratio && second) ok = ok && (d0 <= ratio_sq * (2.0f * (1.0f - einx_ordered_unkey(second))));
+  if (use_dist) ok = ok && (d0 <= dist_sq);
+  return ok ? idx : -1;
+}
+
+__global__ void mnn_finalize_thresh_kernel(const unsigned long long* rowkey, const unsigned long long* colkey, const unsigned* row2,
+                                           const unsigned* col2, const int32_t* nn, const int32_t* mm, int cap0, int cap1, int use_ratio,
+                                           float ratio_sq, int use_dist, float dist_sq, int64_t* m0, int64_t* m1, float* s0, float* s1) {
+  const int b = blockIdx.y;
+  const int n = min(nn[b], cap0), m = min(mm[b], cap1);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long* rk = rowkey + (size_t)b * cap0;
+  const unsigned long long* ck = colkey + (size_t)b * cap1;
+  const unsigned* r2 = row2 + (size_t)b * cap0;
+  const unsigned* c2 = col2 + (size_t)b * cap1;
+  if (t < cap0) {
+    int64_t r = -1;
+    if (t < n && m > 0) {
+      const int j = thresh_match(rk[t], r2[t], use_ratio, ratio_sq, use_dist, dist_sq);
+      if (j >= 0 && thresh_match(ck[j], c2[j], use_ratio, ratio_sq, use_dist, dist_sq) == t) r = j;
+    }
+    m0[(size_t)b * cap0 + t] = r;
+    s0[(size_t)b * cap0 + t] = r > -1 ? 1.0f : 0.0f;
+  }
+  if (t < cap1) {
+    int64_t r = -1;
+    if (t < m && n > 0) {
+      const int i = thresh_match(ck[t], c2[t], use_ratio, ratio_sq, use_dist, dist_sq);
+      if (i >= 0 && thresh_match(rk[i], r2[i], use_ratio, ratio_sq, use_dist, dist_sq) == t) r = i;
     }
     m1[(size_t)b * cap1 + t] = r;
     s1[(size_t)b * cap1 + t] = r > -1 ? 1.0f : 0.0f;

@@ -21,11 +21,18 @@ EINX_EXPORT size_t einx_mnn_ws_bytes(int B, int cap0, int cap1) {
   bytes += align256((size_t)B * cap0 * 8) + align256((size_t)B * cap1 * 8);
   bytes += align256((size_t)B * cap0 * nc64 * 8) + align256((size_t)B * cap1 * nr64 * 8);
   bytes += align256((size_t)B * cap0 * 8) + align256((size_t)B * cap1 * 8);
+  bytes += align256((size_t)B * cap0 * 4) + align256((size_t)B * cap1 * 4);  // second-neighbour keys (einx_mnn_thresh)
   return bytes;
 }
 
 EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
                          void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, void* stream) {
+  return einx_mnn_thresh(desc0, n, cap0, desc1, m, cap1, B, D, 0, 0.0f, 0, 0.0f, ws, matches0, matches1, scores0, scores1, la, stream);
+}
+
+EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
+                                int use_ratio, float ratio_sq, int use_dist, float dist_sq, void* ws, int64_t* matches0, int64_t* matches1,
+                                float* scores0, float* scores1, float* la, void* stream) {
   EINX_CHECK_ARG(desc0 && desc1 && n && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
   EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0 && D > 0 && D % 4 == 0, "bad shape (D must be a multiple of 4)");
   hipStream_t s = (hipStream_t)stream;
@@ -51,10 +58,19 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
   a.rowlse = (float*)p;
   p += align256((size_t)B * cap0 * 8);
   a.collse = (float*)p;
+  p += align256((size_t)B * cap1 * 8);
+  a.row2 = (unsigned*)p;
+  p += align256((size_t)B * cap0 * 4);
+  a.col2 = (unsigned*)p;
   a.la = la;
   a.cert0 = a.cert1 = a.dust0 = a.dust1 = nullptr;
   const size_t keybytes = align256((size_t)B * cap0 * 8) + align256((size_t)B * cap1 * 8);
   if (hipMemsetAsync(ws, 0, keybytes, s) != hipSuccess) {
+    einx_set_error("einx_mnn: memset failed");
+    return EINX_ERR_LAUNCH;
+  }
+  const bool thresh = use_ratio || use_dist;
+  if (use_ratio && hipMemsetAsync(a.row2, 0, align256((size_t)B * cap0 * 4) + align256((size_t)B * cap1 * 4), s) != hipSuccess) {
     einx_set_error("einx_mnn: memset failed");
     return EINX_ERR_LAUNCH;
   }
@@ -65,8 +81,17 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
   }
   EINX_CHECK_LAUNCH();
   const int mx = cap0 > cap1 ? cap0 : cap1;
-  hipLaunchKernelGGL(mnn_finalize_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, s, a.rowkey, a.colkey, n, m,
-                     cap0, cap1, matches0, matches1, scores0, scores1);
+  if (thresh) {
+    if (use_ratio) {
+      hipLaunchKernelGGL(mnn_tile_kernel<4>, grid, dim3(THREADS), 0, s, a);
+      EINX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(mnn_finalize_thresh_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, s, a.rowkey, a.colkey, a.row2,
+                       a.col2, n, m, cap0, cap1, use_ratio, ratio_sq, use_dist, dist_sq, matches0, matches1, scores0, scores1);
+  } else {
+    hipLaunchKernelGGL(mnn_finalize_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, s, a.rowkey, a.colkey, n, m,
+                       cap0, cap1, matches0, matches1, scores0, scores1);
+  }
   EINX_CHECK_LAUNCH();
   if (la) {
     hipLaunchKernelGGL(mnn_tile_kernel<1>, grid, dim3(THREADS), 0, s, a);

@@ -168,6 +168,15 @@ int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int 
 size_t einx_mnn_ws_bytes(int B, int cap0, int cap1);
 int einx_mnn(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
              void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, void* stream);
+/* the same with find_nn's optional thresholds (MNN.py:12-22): dist = 2*(1-sim) of the best / second-best
+ * neighbour per row (per column for matches1); a match is kept when dist0 <= ratio_sq*dist1 (use_ratio) and
+ * dist0 <= dist_sq (use_dist); the mutual check (:25-32) runs on the masked matches.  ratio_sq / dist_sq are the
+ * squared thresholds rounded to fp32 (what torch computes for `tensor <= python_float`).  Rows / columns with a
+ * single candidate have no second neighbour: the ratio test passes there (torch.topk(2) raises; the Python
+ * wrapper raises the same error when it knows the counts). */
+int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
+                    int use_ratio, float ratio_sq, int use_dist, float dist_sq, void* ws, int64_t* matches0, int64_t* matches1,
+                    float* scores0, float* scores1, float* la, void* stream);
 
 /* similarity = einsum("bnd,bmd->bnm") (MNN.py:88), returned by the reference's un-frozen Matcher
  * branch (Matchers.py:204-222).  sim [B,cap0,cap1]; entries outside [n[b], m[b]] are zero. */

@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -655,6 +655,134 @@ def gen_train():
 
 
 GROUPS = {"train": gen_train, "metrics": gen_metrics, "events": gen_events, "post": gen_post, "desc": gen_desc, "mnn": gen_mnn, "conv": gen_conv, "lg": gen_lg, "e2e": gen_e2e}
+
+# =========================================================================================
+# r2 (round 2): cases the first fixture set did not pin
+#   - NMS tie maps WITH survivors (first-max-wins of fast_nms, detector_util.py:286-335)
+#   - degenerate descriptors into MNN (topk(1) tie behaviour, MNN.py:12-14,88-101)
+#   - find_nn's ratio / distance thresholds (MNN.py:12-22)
+#   - Repeatability (core/metrics/keypoints_metrics.py:54-157)
+# =========================================================================================
+def tie_map(c):
+    """quantised maps: `levels` distinct values -> many exact ties inside every 9x9 window"""
+    u = synth.uniform01(c["seed"], (c["B"], 1, c["H"], c["W"]))
+    return (np.floor(u * np.float32(c["levels"])) / np.float32(c["levels"])).astype(np.float32)
+
+
+R2_TIE_CASES = [
+    dict(name="tie8_40x48", seed=112, B=2, H=40, W=48, levels=8, k=0, radius=4, border=4, thr=0.0),
+    dict(name="tie4_64x88", seed=113, B=3, H=64, W=88, levels=4, k=0, radius=4, border=4, thr=0.0),
+    dict(name="tie16_r2_50x70", seed=114, B=2, H=50, W=70, levels=16, k=0, radius=2, border=1, thr=0.0),
+    dict(name="tie64_k_264x352", seed=115, B=1, H=264, W=352, levels=64, k=1024, radius=4, border=4, thr=1.0),
+    dict(name="tie256_k_64x88", seed=116, B=2, H=64, W=88, levels=256, k=40, radius=4, border=4, thr=1.0),
+]
+
+
+def r2_mnn_inputs(c):
+    kind, n, m, D = c["kind"], c["n"], c["m"], c["D"]
+    if kind == "alleq":  # every descriptor is the same unit vector on both sides
+        v = synth.synth_unit_descriptors(c["seed"], 1, D)
+        return np.repeat(v, n, 0).copy(), np.repeat(v, m, 0).copy()
+    if kind == "dup":  # duplicated rows inside each side and exact copies across sides
+        d0 = synth.synth_unit_descriptors(c["seed"], n, D)
+        d1 = synth.synth_unit_descriptors(c["seed"] + 1, m, D)
+        d0[n // 2:] = d0[:n - n // 2]          # row i + n/2 == row i
+        d1[:m // 3] = d0[:m // 3]              # exact copies of side-0 rows (which are themselves duplicated)
+        d1[m // 3:2 * (m // 3)] = d1[:m // 3]  # and duplicated once more inside side 1
+        return d0, d1
+    if kind == "zero":  # all-zero descriptors: sim == 0 everywhere
+        return np.zeros((n, D), np.float32), np.zeros((m, D), np.float32)
+    d0, d1, _, _ = mnn_inputs(dict(seed=c["seed"], n=n, m=m, D=D, scale=c.get("scale", 1.0), shared=c.get("shared", 0)))
+    return d0, d1
+
+
+R2_MNN_CASES = [
+    dict(name="alleq", kind="alleq", seed=121, n=40, m=37, D=256),
+    dict(name="dup", kind="dup", seed=122, n=64, m=48, D=128),
+    dict(name="zero", kind="zero", seed=123, n=9, m=12, D=64),
+    dict(name="ratio", kind="rand", seed=124, n=200, m=180, D=64, shared=90, ratio=0.9, dist=None),
+    dict(name="dist", kind="rand", seed=125, n=150, m=170, D=128, shared=70, ratio=None, dist=0.7),
+    dict(name="both", kind="rand", seed=126, n=257, m=300, D=256, shared=120, ratio=0.95, dist=0.75),
+    dict(name="ratio_dup", kind="dup", seed=127, n=64, m=48, D=128, ratio=0.8, dist=None),
+]
+
+R2_REP_CASES = [
+    dict(name="rep_identity", seed=131, n=300, m=280, hom=None, ordering="yx"),
+    dict(name="rep_homography", seed=132, n=400, m=350, hom=[1.02, 0.015, -3.0, -0.01, 0.98, 2.5, 1e-5, -2e-5, 1.0], ordering="yx"),
+    dict(name="rep_xy", seed=133, n=120, m=90, hom=[0.99, -0.02, 4.0, 0.015, 1.01, -3.5, -1e-5, 1e-5, 1.0], ordering="xy"),
+    dict(name="rep_empty1", seed=134, n=0, m=40, hom=None, ordering="yx"),
+]
+
+
+def gen_r2():
+    from core.metrics.keypoints_metrics import Repeatability
+    out = {"meta": meta(tie_cases=R2_TIE_CASES, mnn_cases=R2_MNN_CASES, rep_cases=R2_REP_CASES)}
+    for c in R2_TIE_CASES:
+        score = torch.from_numpy(tie_map(c).copy())
+        nms = ref_det.prob_map_to_points_map(score, prob_thresh=c["thr"], nms_dist=c["radius"], border_dist=c["border"],
+                                             use_fast_nms=True, top_k=(c["k"] or None))
+        pos = ref_det.prob_map_to_positions_with_prob(nms, threshold=0.0, ordering="yx")
+        n = c["name"]
+        out[f"{n}.counts"] = np.array([p.shape[0] for p in pos], np.int64)
+        out[f"{n}.positions"] = torch.cat(pos, 0).numpy()
+        flat = nms.reshape(-1)
+        nz = torch.nonzero(flat).squeeze(1)
+        out[f"{n}.nms_idx"] = nz.numpy()
+        out[f"{n}.nms_val"] = flat[nz].numpy()
+        if c["k"] == 0 and c["H"] * c["W"] <= 64 * 88:
+            sc2 = torch.from_numpy(tie_map(c).copy())
+            slow = ref_det.prob_map_to_points_map(sc2, c["thr"], c["radius"], c["border"], use_fast_nms=False)
+            out[f"{n}.original_nms_equal"] = np.array([int(torch.equal(slow, nms))])
+        print(n, out[f"{n}.counts"])
+        assert out[f"{n}.counts"].sum() > 0, "tie case must keep survivors"
+    for c in R2_MNN_CASES:
+        d0, d1 = r2_mnn_inputs(c)
+        k0 = np.concatenate([synth.uniform(c["seed"] + 4, (c["n"], 2), 0, 260), synth.uniform01(c["seed"] + 5, (c["n"], 1))], 1).astype(np.float32)
+        k1 = np.concatenate([synth.uniform(c["seed"] + 6, (c["m"], 2), 0, 260), synth.uniform01(c["seed"] + 7, (c["m"], 1))], 1).astype(np.float32)
+        mm = NearestNeighborMatcher(ratio_thresh=c.get("ratio") or False, distance_thresh=c.get("dist") or False, mutual_check=True)
+        f0 = {"sparse_descriptors": torch.from_numpy(d0)[None], "sparse_positions": torch.from_numpy(k0)[None]}
+        f1 = {"sparse_descriptors": torch.from_numpy(d1)[None], "sparse_positions": torch.from_numpy(k1)[None]}
+        n = c["name"]
+        try:
+            r = mm(f0, f1)
+        except RuntimeError as e:  # zero matches: torch.stack([]) (MNN.py:126-127)
+            out[f"{n}.raises"] = np.frombuffer(str(e).encode()[:60], dtype=np.uint8)
+            print(n, "raises", str(e)[:60])
+            # the match vectors up to the failing stack are still defined by find_nn + mutual_check
+            sim = torch.einsum("bnd,bmd->bnm", f0["sparse_descriptors"], f1["sparse_descriptors"])
+            from core.modules.matchers.MNN import find_nn, mutual_check
+            m0 = find_nn(sim, mm.ratio_thresh, mm.distance_thresh)
+            m1 = find_nn(sim.transpose(1, 2), mm.ratio_thresh, mm.distance_thresh)
+            m0, m1 = mutual_check(m0, m1)
+            out[f"{n}.matches0"], out[f"{n}.matches1"] = m0.numpy(), m1.numpy()
+            continue
+        out[f"{n}.matches0"] = r["matches0"].numpy()
+        out[f"{n}.matches1"] = r["matches1"].numpy()
+        out[f"{n}.matched_kpts0"] = r["matched_kpts0"].numpy()
+        out[f"{n}.matched_kpts1"] = r["matched_kpts1"].numpy()
+        print(n, int((r["matches0"] > -1).sum()), "matches of", c["n"])
+    for c in R2_REP_CASES:
+        mc = dict(c, D=8)
+        if c["n"] == 0:
+            mc["n"] = 10
+        k0, k1, _, _, _, _ = metric_inputs(mc)
+        if c["n"] == 0:
+            k0 = k0[:0]
+        if c["ordering"] == "xy":  # rows (x, y): swap the (y, x) recipe columns
+            k0, k1 = k0[:, [1, 0, 2]].copy(), k1[:, [1, 0, 2]].copy()
+        Hm = torch.eye(3) if c["hom"] is None else torch.tensor(c["hom"], dtype=torch.float32).reshape(3, 3)
+        vals = []
+        for t in (1, 3):
+            d = Repeatability(f"repeatability@{t}", distance_thresh=t, ordering=c["ordering"]).update_one(
+                torch.from_numpy(k0[:, :2].copy()), torch.from_numpy(k1[:, :2].copy()), (260, 346), (260, 346), Hm)
+            vals.append(d.get(f"repeatability@{t}", float("nan")))
+        out[f"{c['name']}.values"] = np.array(vals, np.float64)
+        print(c["name"], vals)
+    save("r2.npz", **out)
+
+
+GROUPS["r2"] = gen_r2
+
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -160,3 +160,41 @@ def metric_inputs(c):
     mk0 = k0[:M].copy()
     mk1 = k1[:M].copy()
     return [a.astype(np.float32) for a in (k0, k1, d0, d1, mk0, mk1)]
+
+
+# ---- round-2 fixture recipes (tests/golden/gen_golden.py::gen_r2) ---------------------------------
+def tie_map(c):
+    u = synth.uniform01(c["seed"], (c["B"], 1, c["H"], c["W"]))
+    return (np.floor(u * np.float32(c["levels"])) / np.float32(c["levels"])).astype(np.float32)
+
+
+def r2_mnn_inputs(c):
+    kind, n, m, D = c["kind"], c["n"], c["m"], c["D"]
+    if kind == "alleq":
+        v = synth.synth_unit_descriptors(c["seed"], 1, D)
+        d0, d1 = np.repeat(v, n, 0).copy(), np.repeat(v, m, 0).copy()
+    elif kind == "dup":
+        d0 = synth.synth_unit_descriptors(c["seed"], n, D)
+        d1 = synth.synth_unit_descriptors(c["seed"] + 1, m, D)
+        d0[n // 2:] = d0[:n - n // 2]
+        d1[:m // 3] = d0[:m // 3]
+        d1[m // 3:2 * (m // 3)] = d1[:m // 3]
+    elif kind == "zero":
+        d0, d1 = np.zeros((n, D), np.float32), np.zeros((m, D), np.float32)
+    else:
+        d0, d1, _, _ = mnn_inputs(dict(seed=c["seed"], n=n, m=m, D=D, scale=c.get("scale", 1.0), shared=c.get("shared", 0)))
+    k0 = np.concatenate([synth.uniform(c["seed"] + 4, (n, 2), 0, 260), synth.uniform01(c["seed"] + 5, (n, 1))], 1).astype(np.float32)
+    k1 = np.concatenate([synth.uniform(c["seed"] + 6, (m, 2), 0, 260), synth.uniform01(c["seed"] + 7, (m, 1))], 1).astype(np.float32)
+    return d0, d1, k0, k1
+
+
+def rep_inputs(c):
+    mc = dict(c, D=8)
+    if c["n"] == 0:
+        mc["n"] = 10
+    k0, k1, _, _, _, _ = metric_inputs(mc)
+    if c["n"] == 0:
+        k0 = k0[:0]
+    if c["ordering"] == "xy":
+        k0, k1 = k0[:, [1, 0, 2]].copy(), k1[:, [1, 0, 2]].copy()
+    return k0[:, :2].copy(), k1[:, :2].copy()

@@ -1,0 +1,339 @@
+"""Round-2 GPU parity tests (-m gpu): the gaps VERDICT r1 listed.
+
+* BASELINE.json's own batch sizes: sampled pairs (first / middle / last) of B=32 SP+MNN, B=32 SiLK+MNN and
+  B=64 SP+LightGlue against per-pair oracle runs (persistent XCD-aware workgroups, blockIdx.z = pair and the
+  3-workgroups-per-CU attention only show their indexing at these sizes);
+* round-2 fixtures generated from the reference (tests/golden/r2.npz): tie maps with survivors, find_nn's
+  ratio / distance thresholds, Repeatability; exact-tie descriptor inputs against the oracle's first-index rule;
+* the documented drop-in (`install_as_core()`) driven through the reference scripts' own import lines;
+* a parent-level load_state_dict after a forward really changes the weights the kernels use.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_pkg, r2_mnn_inputs, rep_inputs, sub_dict, synth, tie_map
+
+pytestmark = pytest.mark.gpu
+pkg = load_pkg()
+DEV = "cuda:0"
+FTOL = 1e-4
+
+_Z = np.load(os.path.join(GOLDEN, "r2.npz"))
+_META = json.loads(bytes(_Z["meta"]).decode())
+TIES = {c["name"]: c for c in _META["tie_cases"]}
+MNNS = {c["name"]: c for c in _META["mnn_cases"]}
+REPS = {c["name"]: c for c in _META["rep_cases"]}
+TIED = ("alleq", "dup", "zero", "ratio_dup")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    yield
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ BASELINE batch sizes vs per-pair oracle
+def _bench_like_model(cfg_name, seed=11):
+    cfg = pkg.default_config(cfg_name, event_channels=5)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    return cfg, model, sd
+
+
+def _calibrate(model, sd, ev, img, mask):
+    """bench.py's descriptor-bias calibration (distinct descriptors -> tens of matches per pair)"""
+    ef, imf, _ = model(ev, img.clone(), mask)
+    msd = model.state_dict()
+    over = {}
+    for prefix, feats in (("event_extractor.extractor.", ef), ("image_extractor.extractor.", imf)):
+        mean = feats["raw_descriptors"].mean(dim=(0, 2, 3))
+        key = [k for k in msd if k.startswith(prefix) and (k.endswith("convDb.bias") or k.endswith("_desH2.1.bias"))]
+        assert len(key) == 1
+        over[key[0]] = (msd[key[0]] - mean).detach().cpu()
+    model.load_state_dict(over, strict=False)
+    for k, v in over.items():
+        sd[k] = v.numpy()
+
+
+def _oracle_pair(oracle, cfg, sd, ev, mask, img, b):
+    et, it = cfg.event_extractor.type, cfg.image_extractor.type
+    oe = oracle.extractor_forward(et, sub_dict(sd, "event_extractor.extractor."), ev[b:b + 1].copy(), mask[b:b + 1], top_k=1024,
+                                  scale=cfg.event_extractor[et].descriptor_scale_factor)
+    oi = oracle.extractor_forward(it, sub_dict(sd, "image_extractor.extractor."), img[b:b + 1].copy(), None, top_k=1024,
+                                  scale=cfg.image_extractor[it].descriptor_scale_factor)
+    return oe, oi
+
+
+@pytest.mark.parametrize("cfg_name,B", [("SP_MNN", 32), ("SiLK_MNN", 32)])
+def test_baseline_batch_sampled_pairs_vs_oracle_mnn(oracle, cfg_name, B):
+    """configs[1] / configs[2] at their real batch size: pairs 0, B/2, B-1 bit-equal to per-pair oracle runs
+    (keypoints + scores, descriptors, match indices, matched keypoints)."""
+    cfg, model, sd = _bench_like_model(cfg_name)
+    ev, mask = synth.synth_events(10_000, B, 5)
+    img = synth.synth_image(10_000, B)
+    ev_t, mask_t, img_t = _t(ev), _t(mask), _t(img)
+    _calibrate(model, sd, ev_t, img_t, mask_t)
+    ef, imf, m = model(ev_t, img_t.clone(), mask_t)
+    nmatch = []
+    for b in (0, B // 2, B - 1):
+        oe, oi = _oracle_pair(oracle, cfg, sd, ev, mask, img, b)
+        for got, exp in ((ef, oe), (imf, oi)):
+            assert np.array_equal(_np(got["sparse_positions"][b]), exp["sparse_positions"][0]), f"pair {b}: keypoints"
+            assert np.array_equal(_np(got["sparse_descriptors"][b]), exp["sparse_descriptors"][0]), f"pair {b}: descriptors"
+        r = oracle.mnn(oe["sparse_descriptors"][0], oi["sparse_descriptors"][0], want_la=False)
+        assert np.array_equal(_np(m["matches0"][b])[0], r["matches0"]), f"pair {b}: matches0"
+        assert np.array_equal(_np(m["matches1"][b])[0], r["matches1"]), f"pair {b}: matches1"
+        mk0, mk1 = oracle.matched_kpts(oe["sparse_positions"][0], oi["sparse_positions"][0], r["matches0"], 3)
+        assert np.array_equal(_np(m["matched_kpts0"][b]), mk0) and np.array_equal(_np(m["matched_kpts1"][b]), mk1)
+        nmatch.append(int((r["matches0"] > -1).sum()))
+    assert min(nmatch) >= 5, f"calibrated descriptors should give real matches, got {nmatch}"
+
+
+def test_baseline_batch_sampled_pairs_vs_oracle_lightglue(oracle):
+    """configs[3]: B=64 SP+LightGlue; extractor outputs bit-equal, match assignments equal, floats to 1e-4."""
+    B = 64
+    cfg, model, sd = _bench_like_model("SP_LG")
+    ev, mask = synth.synth_events(10_000, B, 5)
+    img = synth.synth_image(10_000, B)
+    ev_t, mask_t, img_t = _t(ev), _t(mask), _t(img)
+    _calibrate(model, sd, ev_t, img_t, mask_t)
+    ef, imf, m = model(ev_t, img_t.clone(), mask_t)
+    for b in (0, B // 2, B - 1):
+        oe, oi = _oracle_pair(oracle, cfg, sd, ev, mask, img, b)
+        for got, exp in ((ef, oe), (imf, oi)):
+            assert np.array_equal(_np(got["sparse_positions"][b]), exp["sparse_positions"][0]), f"pair {b}: keypoints"
+            assert np.array_equal(_np(got["sparse_descriptors"][b]), exp["sparse_descriptors"][0]), f"pair {b}: descriptors"
+        r = oracle.lightglue(sub_dict(sd, "matcher.matcher."), oe["sparse_positions"][0], oe["sparse_descriptors"][0],
+                             oi["sparse_positions"][0], oi["sparse_descriptors"][0])
+        g0, e0 = _np(m["matches0"][b])[0], np.asarray(r["matches0"]).reshape(-1)
+        if not np.array_equal(g0, e0):
+            # flash-style attention sums in a different order than the oracle: an assignment may flip only where the
+            # oracle's own decision margin is inside the 1e-4 float tolerance
+            la = r["log_assignment"]
+            bad = np.nonzero(g0 != e0)[0]
+            assert len(bad) <= 2, f"pair {b}: {len(bad)} assignments differ"
+            for i in bad:
+                row = np.sort(la[i, :-1])[::-1]
+                assert row[0] - row[1] < 5e-4, f"pair {b}: row {i} differs with margin {row[0] - row[1]}"
+        gla = _np(m["log_assignment"][b])[0] if m["log_assignment"][b] is not None else None
+        if gla is not None:
+            np.testing.assert_allclose(gla[::53, ::47], r["log_assignment"][::53, ::47], atol=5e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ r2 fixtures: tie maps with survivors
+@pytest.mark.parametrize("name", list(TIES))
+def test_tie_maps_with_survivors_vs_reference(name):
+    from importlib import import_module
+    du = import_module(pkg.__name__ + ".core.modules.utils.detector_util")
+    c = TIES[name]
+    score = _t(tie_map(c))
+    nms = du.prob_map_to_points_map(score, prob_thresh=c["thr"], nms_dist=c["radius"], border_dist=c["border"], use_fast_nms=True,
+                                    top_k=(c["k"] or None))
+    pos = du.prob_map_to_positions_with_prob(nms, threshold=0.0, ordering="yx")
+    counts = _Z[f"{name}.counts"]
+    assert counts.sum() > 0
+    assert [int(p.shape[0]) for p in pos] == counts.tolist()
+    assert np.array_equal(np.concatenate([_np(p) for p in pos], 0), _Z[f"{name}.positions"])
+    flat = _np(nms).reshape(-1)
+    nz = np.nonzero(flat)[0]
+    assert np.array_equal(nz, _Z[f"{name}.nms_idx"])
+    assert np.array_equal(flat[nz], _Z[f"{name}.nms_val"])
+
+
+# ------------------------------------------------------------------ r2 fixtures: MNN thresholds / exact ties
+def _mnn_feats(d0, d1, k0, k1):
+    size = torch.tensor([260, 346])
+    f0 = {"sparse_descriptors": _t(d0)[None], "sparse_positions": _t(k0)[None], "image_size": [size]}
+    f1 = {"sparse_descriptors": _t(d1)[None], "sparse_positions": _t(k1)[None], "image_size": [size]}
+    return f0, f1
+
+
+@pytest.mark.parametrize("name", [n for n in MNNS if n not in TIED])
+def test_mnn_thresholds_vs_reference(oracle, name):
+    c = MNNS[name]
+    d0, d1, k0, k1 = r2_mnn_inputs(c)
+    mm = pkg.NearestNeighborMatcher(ratio_thresh=c.get("ratio") or False, distance_thresh=c.get("dist") or False, mutual_check=True)
+    r = mm(*_mnn_feats(d0, d1, k0, k1))
+    assert np.array_equal(_np(r["matches0"]), _Z[f"{name}.matches0"])
+    assert np.array_equal(_np(r["matches1"]), _Z[f"{name}.matches1"])
+    assert np.array_equal(_np(r["matched_kpts0"]), _Z[f"{name}.matched_kpts0"])
+    assert np.array_equal(_np(r["matched_kpts1"]), _Z[f"{name}.matched_kpts1"])
+    exp = oracle.mnn_thresh(d0, d1, c.get("ratio"), c.get("dist"))
+    assert np.array_equal(_np(r["matching_scores0"])[0], exp["matching_scores0"])
+
+
+@pytest.mark.parametrize("name", TIED)
+def test_mnn_exact_ties_first_index_rule(oracle, name):
+    """exact ties in sim: the kernels implement the build's first-index rule bit for bit like the oracle (the
+    reference's own pick among equals is an artefact of torch's partial sort, see test_r2_golden_cpu.py)."""
+    c = MNNS[name]
+    d0, d1, k0, k1 = r2_mnn_inputs(c)
+    mm = pkg.NearestNeighborMatcher(ratio_thresh=c.get("ratio") or False, distance_thresh=False, mutual_check=True)
+    r = mm(*_mnn_feats(d0, d1, k0, k1))
+    exp = oracle.mnn_thresh(d0, d1, c.get("ratio"), None) if c.get("ratio") else oracle.mnn(d0, d1, want_la=False)
+    assert np.array_equal(_np(r["matches0"])[0], exp["matches0"])
+    assert np.array_equal(_np(r["matches1"])[0], exp["matches1"])
+    assert int((exp["matches0"] > -1).sum()) >= 1
+
+
+def test_mnn_thresholds_in_a_ragged_batch(oracle):
+    """the thresholded matcher inside a batch with different counts per pair (device-side counts)"""
+    nat = pkg.native
+    cases = [MNNS["ratio"], MNNS["both"], MNNS["dist"]]
+    ins = [r2_mnn_inputs(c) for c in cases]
+    cap0, cap1, D = 300, 300, 64
+    B = len(ins)
+    d0 = np.zeros((B, cap0, 256), np.float32)
+    d1 = np.zeros((B, cap1, 256), np.float32)
+    n, m = [], []
+    for b, (a0, a1, _, _) in enumerate(ins):
+        d0[b, :a0.shape[0], :a0.shape[1]] = a0
+        d1[b, :a1.shape[0], :a1.shape[1]] = a1
+        n.append(a0.shape[0])
+        m.append(a1.shape[0])
+    r = nat.mnn(_t(d0), torch.tensor(n, dtype=torch.int32, device=DEV), _t(d1), torch.tensor(m, dtype=torch.int32, device=DEV),
+                want_la=False, ratio_thresh=0.9, distance_thresh=0.8)
+    for b in range(B):
+        exp = oracle.mnn_thresh(d0[b, :n[b]], d1[b, :m[b]], 0.9, 0.8)
+        assert np.array_equal(_np(r.matches0)[b, :n[b]], exp["matches0"])
+        assert np.array_equal(_np(r.matches1)[b, :m[b]], exp["matches1"])
+        assert (_np(r.matches0)[b, n[b]:] == -1).all()
+
+
+def test_ratio_threshold_single_candidate_raises():
+    d0, d1, k0, k1 = r2_mnn_inputs(MNNS["dup"])
+    mm = pkg.NearestNeighborMatcher(ratio_thresh=0.8, distance_thresh=False, mutual_check=True)
+    with pytest.raises(RuntimeError, match="out of range"):
+        mm(*_mnn_feats(d0[:5], d1[:1], k0[:5], k1[:1]))
+
+
+# ------------------------------------------------------------------ r2 fixtures: Repeatability
+@pytest.mark.parametrize("name", list(REPS))
+def test_repeatability_class_vs_reference(name):
+    from importlib import import_module
+    km = import_module(pkg.__name__ + ".core.metrics.keypoints_metrics")
+    c = REPS[name]
+    p0, p1 = rep_inputs(c)
+    Hm = torch.eye(3) if c["hom"] is None else torch.tensor(c["hom"], dtype=torch.float32).reshape(3, 3)
+    got = []
+    for t in (1, 3):
+        d = km.Repeatability(f"repeatability@{t}", distance_thresh=t, ordering=c["ordering"]).update_one(
+            _t(p0), _t(p1), (260, 346), (260, 346), Hm.to(DEV))
+        got.append(d.get(f"repeatability@{t}", float("nan")))
+    np.testing.assert_allclose(np.array(got), _Z[f"{name}.values"], atol=1e-7, rtol=1e-6)
+    # update_batch = mean over the pairs that produced a value (keypoints_metrics.py:134-157)
+    R = km.Repeatability("r", distance_thresh=3, ordering=c["ordering"])
+    both = R.update_batch([_t(p0), _t(p0)], [_t(p1), _t(p1)], (260, 346), (260, 346), torch.stack([Hm, Hm]).to(DEV))
+    assert abs(both["r"] - float(_Z[f"{name}.values"][1])) < 1e-6
+    assert km.Repeatability("r", 3).update_one(_t(p0[:0]), _t(p1[:0]), (260, 346), (260, 346), Hm.to(DEV)) == {}
+
+
+# ------------------------------------------------------------------ the documented drop-in: install_as_core()
+def test_install_as_core_runs_reference_style_imports_and_a_forward(oracle):
+    """INTEGRATION.md's drop-in: after install_as_core() the import lines of the reference's evaluation script
+    (test_events-image_same-time.py:13,19-25,30-44) resolve to the native build; one forward through them."""
+    saved = {k: v for k, v in sys.modules.items() if k == "core" or k.startswith("core.")}
+    try:
+        pkg.install_as_core()
+        ns = {}
+        exec("from core.modules import build_model\n"
+             "from core.modules.EIM import EIM\n"
+             "from core.metrics.keypoints_metrics import Repeatability, ValidDescriptorsDistance\n"
+             "from core.metrics.matching_metrics import (MeanMatchingAccuracy, MatchingRatio, HomographyEstimation,\n"
+             "                                           RelativePoseEstimation, compute_auc)\n"
+             "from core.modules.utils.detector_util import (logits_to_prob, depth_to_space, prob_map_to_points_map,\n"
+             "                                              prob_map_to_positions_with_prob, get_dense_positions)\n"
+             "from core.modules.utils.descriptor_util import (normalize_descriptors, get_dense_descriptors,\n"
+             "                                                sparsify_full_resolution_descriptors,\n"
+             "                                                sparsify_low_resolution_descriptors, upsample_descriptors)\n", ns)
+        assert ns["EIM"] is pkg.EIM
+        with pytest.raises(NotImplementedError, match="OpenCV"):
+            ns["HomographyEstimation"]("HE")
+        assert abs(ns["compute_auc"]([0.5, 1.2, 3.0, 7.0, float("inf"), 2.2], [5])["5"] - 0.5839999961853027) < 1e-12
+        cfg = pkg.default_config("SP_MNN", event_channels=5)
+        for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+            sec.detection_top_k = 64
+        model = ns["build_model"](cfg, DEV, None).eval()
+        sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=5)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        ev, mask = synth.synth_events(9, 1, 5, 90, 122)
+        img = synth.synth_image(9, 1, 90, 122)
+        ef, imf, m = model(_t(ev), _t(img), _t(mask))
+        oe = oracle.extractor_forward("vgg", sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=64)
+        assert np.array_equal(_np(ef["sparse_positions"][0]), oe["sparse_positions"][0])
+        # the harness-style metric calls of the script (:236-262) on this forward
+        vdd = ns["ValidDescriptorsDistance"]("VDD", [1, 3]).update_one(ef["sparse_positions"][0], imf["sparse_positions"][0],
+                                                                      ef["sparse_descriptors"][0], imf["sparse_descriptors"][0],
+                                                                      (90, 122), (90, 122), torch.eye(3, device=DEV))
+        rep = ns["Repeatability"]("rep@3", distance_thresh=3, ordering="yx").update_one(
+            ef["sparse_positions"][0][:, :2].contiguous(), imf["sparse_positions"][0][:, :2].contiguous(), (90, 122), (90, 122),
+            torch.eye(3, device=DEV))
+        assert abs(rep["rep@3"] - vdd["VDD_Repeatability@3"]) < 1e-9
+    finally:
+        for k in [k for k in sys.modules if k == "core" or k.startswith("core.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+# ------------------------------------------------------------------ parent load_state_dict after a forward
+def test_parent_load_state_dict_after_forward_uses_the_new_weights(oracle):
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 64
+    model = pkg.EIM(cfg, device=DEV).eval()
+    keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    ev, mask = synth.synth_events(9, 1, 5, 90, 122)
+    img = synth.synth_image(9, 1, 90, 122)
+    outs = []
+    for seed in (5, 6):  # second load goes through EIM.load_state_dict AFTER a forward built the native images
+        sd = synth.synth_state_dict(keys, seed=seed)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        ef, imf, m = model(_t(ev), _t(img), _t(mask))
+        oe = oracle.extractor_forward("vgg", sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=64)
+        oi = oracle.extractor_forward("superpointv1", sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=64)
+        assert np.array_equal(_np(ef["sparse_descriptors"][0]), oe["sparse_descriptors"][0]), f"seed {seed}: stale event weights"
+        assert np.array_equal(_np(imf["sparse_descriptors"][0]), oi["sparse_descriptors"][0]), f"seed {seed}: stale image weights"
+        outs.append(_np(ef["logits"]).copy())
+    assert not np.array_equal(outs[0], outs[1])
+    # in-place edit of one parameter (no load_state_dict at all) is picked up too
+    with torch.no_grad():
+        model.image_extractor.extractor.convPb.bias.add_(0.25)
+    sd["image_extractor.extractor.convPb.bias"] = sd["image_extractor.extractor.convPb.bias"] + np.float32(0.25)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=64)
+    assert np.array_equal(_np(imf["logits"]), oi["logits"])
+
+
+def test_wrong_dtype_inputs_raise_or_are_cast():
+    from importlib import import_module
+    du = import_module(pkg.__name__ + ".core.modules.utils.detector_util")
+    s32 = _t(synth.uniform01(3, (1, 1, 40, 48)))
+    ref = du.fast_nms(s32.clone(), 4)
+    for dt in (torch.float64, torch.float16):
+        got = du.fast_nms(s32.to(dt), 4)  # the reference helpers accept any float dtype: cast, never misread
+        if dt == torch.float64:
+            assert torch.equal(got, ref)
+        else:
+            assert got.dtype == torch.float32 and got.shape == ref.shape
+    with pytest.raises(TypeError, match="float32"):
+        pkg.native.detect(s32.double(), top_k=10, radius=4, det_thr=1.0)
+    with pytest.raises(TypeError, match="int32"):
+        pkg.native.mnn(torch.zeros(1, 8, 64, device=DEV), torch.tensor([8], device=DEV), torch.zeros(1, 8, 64, device=DEV),
+                       torch.tensor([8], device=DEV))
