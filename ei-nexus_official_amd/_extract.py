@@ -7,8 +7,11 @@ Reference behaviour mirrored (file:line): core/modules/event_extractors/EventExt
 and :331-434, core/modules/image_extractors/superpoint_extractor.py:345-480,
 core/modules/image_extractors/silk_extractor.py:177-257.
 """
+import ctypes
+
 import torch
 
+from . import _lib
 from . import _native as N
 
 
@@ -50,6 +53,7 @@ class BatchedFeats:
         self.dense = False
         self._prepared = None
         self._full_lists = None
+        self._ns = None
 
     # ------------------------------------------------------------------ device handles
     @property
@@ -100,6 +104,7 @@ class BatchedFeats:
         out["nms"] = self.det.nms
         cap = self.det.cap
         ns = [min(int(c), cap) for c in counts_host]
+        self._ns = ns  # what the lists below were cut to (matchers check the lists against it)
         if all(v == cap for v in ns):
             # common case (every image filled its top-k quota): one unbind instead of B slicing calls,
             # normally already done by prepare() while the device was busy
@@ -116,6 +121,16 @@ class BatchedFeats:
         return out
 
 
+def _mask_u8(mask, H, W):
+    if mask is None:
+        return None
+    if mask.device.type != "cuda":
+        raise RuntimeError(f"einx: the mask must live on a HIP device, got {mask.device}")
+    if tuple(mask.shape[-2:]) != (H, W):
+        raise ValueError(f"mask spatial size {tuple(mask.shape[-2:])} does not match the image ({H},{W})")
+    return mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+
+
 class ExtractorEngine:
     """Holds the kernel-native layer images of one network and runs the batched forward."""
 
@@ -127,6 +142,83 @@ class ExtractorEngine:
         self.det_head = []
         self.desc_head = []
         self.nms_iters = 8
+        self._handle = None
+        self._handle_key = None
+        self._shapes = {}
+
+    # ------------------------------------------------------------------ handle-level C ABI (one call per forward)
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            try:
+                N.lib().einx_extractor_destroy(h)
+            except Exception:
+                pass
+
+    def handle(self, scale, dilate_mask, input_div):
+        """einx_extractor for this network (include/einx.h): rebuilt when a call-time parameter changes."""
+        key = (float(scale), bool(dilate_mask), float(input_div), self.top_k, self.radius, self.border, self.det_thr, self.ordering)
+        if self._handle is not None and self._handle_key == key:
+            return self._handle
+        L = N.lib()
+        if self._handle:
+            L.einx_extractor_destroy(self._handle)
+            self._handle = None
+        arr = lambda layers: (_lib.ConvDesc * len(layers))(*[l.desc for l in layers])  # noqa: E731
+        bb, det, desc = arr(self.backbone), arr(self.det_head), arr(self.desc_head)
+        d = _lib.ExtractorDesc(self.cell, len(self.backbone), len(self.det_head), len(self.desc_head), bb, det, desc, int(bool(dilate_mask)),
+                               int(self.border), int(self.radius), int(self.top_k or 0), float(self.det_thr), int(self.ordering == "xy"),
+                               float(scale), float(input_div))
+        h = L.einx_extractor_create(ctypes.byref(d))
+        if not h:
+            raise _lib.EinxError("einx_extractor_create failed: " + L.einx_last_error().decode(errors="replace"))
+        self._handle, self._handle_key, self._shapes = h, key, {}
+        return h
+
+    def shapes(self, h, H, W):
+        s = self._shapes.get((H, W))
+        if s is None:
+            s = _lib.ExtractShapes()
+            _lib.check(N.lib().einx_extract_shapes(h, H, W, ctypes.byref(s)), "einx_extract_shapes")
+            self._shapes[(H, W)] = s
+        return s
+
+    def _run_handle(self, h, sh, x, mask, pads, scale, dense, nms_iters):
+        L = N.lib()
+        dev = x.device
+        B, _, H, W = x.shape
+        F32 = torch.float32
+        cap, hc, wc, Hp, Wp, D = sh.cap, sh.hc, sh.wc, sh.Hp, sh.Wp, sh.desc_dim
+        e = lambda *shape, dt=F32: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
+        bf = BatchedFeats()
+        bf.kind, bf.cell, bf.B = self.kind, self.cell, B
+        bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
+        bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
+        bf.feats, bf.logits, bf.raw = e(B, sh.feat_channels, hc, wc), e(B, sh.det_channels, hc, wc), e(B, D, hc, wc)
+        bf.prob, bf.score = e(B, sh.det_channels, hc, wc), e(B, 1, Hp, Wp)
+        if self.cell == 8:
+            bf.coarse, bf.raw_cl = e(B, D, hc, wc), e(B, hc * wc, D)
+        det = N.Detection()
+        det.positions, det.indices = e(B, cap, 3), e(B, cap, dt=torch.int32)
+        det.counts, det.thr, det.not_converged = e(B, dt=torch.int32), e(B), e(B, dt=torch.int32)
+        det.nms = e(B, H, W)
+        det.cap, det.padded, det.pads = cap, (Hp, Wp), pads
+        bf.det = det
+        bf.sparse_desc = e(B, cap, D)
+        ws = e(L.einx_extract_ws_bytes(h, B, H, W, cap, nms_iters), dt=torch.uint8)
+        m8 = _mask_u8(mask, H, W)
+        P = N._ptr
+        out = _lib.ExtractOut(P(bf.feats), P(bf.logits), P(bf.raw), P(bf.prob), P(bf.score), P(bf.coarse), P(bf.raw_cl), P(det.nms),
+                              P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap)
+        _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), ctypes.byref(out), N._stream(x)), "einx_extract")
+        if dense:
+            w0, w1, h0, h1 = pads
+            if self.cell == 8:
+                bf.normalized = N.upsample_normalize(bf.raw, (Hp, Wp), pads, scale)
+            else:
+                nd = N.normalize_map(bf.raw, scale)
+                bf.normalized = nd[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+        return bf
 
     def redetect(self, bf, nms_iters=None):
         """NMS fix-point + top-k + compaction + sparse descriptor sampling on bf.score (also the
@@ -149,21 +241,43 @@ class ExtractorEngine:
     def grow_nms_iters(self):
         """The fix-point needed more passes than enqueued: quadruple the budget and keep it
         (skipped passes cost ~4 us each, a redo costs a host round trip)."""
-        self.nms_iters = min(self.nms_iters * 4, 4096)
+        self.nms_iters = min(self.nms_iters * 4, 65536)
+        self._calm = 0
         return self.nms_iters
 
-    def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None):
+    def note_converged(self):
+        """A grown budget decays again: after 64 consecutive forwards that converged, halve it (never below 8),
+        so one pathological image does not make every later call enqueue thousands of (skipped) passes."""
+        if self.nms_iters > 8:
+            self._calm = getattr(self, "_calm", 0) + 1
+            if self._calm >= 64:
+                self.nms_iters = max(8, self.nms_iters // 2)
+                self._calm = 0
+
+    def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None, input_div=0.0):
+        """One einx_extract call (handle-level ABI) enqueues the whole network; the op-by-op path below it serves the
+        unbounded-capacity configurations (no top-k: the descriptor buffer is sized from the real counts)."""
         if x.dim() != 4:
             raise ValueError(f"Expected 4D tensor, got {x.dim()}D tensor instead.")
         if x.dtype != torch.float32:
             raise TypeError("einx extractors compute in fp32; pass a float32 tensor")
         if x.device.type != "cuda":
             raise RuntimeError("einx: input must be on a HIP device (no CPU path)")
+        if input_div and not x.is_contiguous():
+            raise RuntimeError("einx: the input must be contiguous (it is scaled in place like the reference does)")
         x = x.contiguous()
-        B, _, H, W = x.shape
+        B, C, H, W = x.shape
+        if C != self.backbone[0].cin:
+            raise ValueError(f"conv expects {self.backbone[0].cin} input channels, got {C}")
         pads = N.padder_pads(H, W, self.cell)
         w0, w1, h0, h1 = pads
         Hp, Wp = H + h0 + h1, W + w0 + w1
+        h = self.handle(scale, dilate_mask, input_div)
+        sh = self.shapes(h, H, W)
+        if sh.cap <= 8192:
+            return self._run_handle(h, sh, x, mask, pads, scale, dense, nms_iters or self.nms_iters)
+        if input_div:
+            N.div_inplace(x, input_div)
         t = x
         first = True
         for layer in self.backbone:

@@ -25,6 +25,23 @@ class DetectParams(ctypes.Structure):
                 ("nms_iters", ctypes.c_int32)]
 
 
+class ExtractorDesc(ctypes.Structure):
+    _fields_ = [("cell", ctypes.c_int32), ("n_backbone", ctypes.c_int32), ("n_det", ctypes.c_int32), ("n_desc", ctypes.c_int32),
+                ("backbone", ctypes.POINTER(ConvDesc)), ("det_head", ctypes.POINTER(ConvDesc)), ("desc_head", ctypes.POINTER(ConvDesc)),
+                ("dilate_mask", ctypes.c_int32), ("border", ctypes.c_int32), ("nms_radius", ctypes.c_int32), ("top_k", ctypes.c_int32),
+                ("det_thr", c_float), ("ordering_xy", ctypes.c_int32), ("desc_scale", c_float), ("input_div", c_float)]
+
+
+class ExtractShapes(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("Hp", "Wp", "h0", "w0", "hc", "wc", "feat_channels", "det_channels", "desc_dim", "cap")]
+
+
+class ExtractOut(ctypes.Structure):
+    _names = ("feats", "logits", "raw", "prob", "score", "coarse", "raw_cl", "nms", "positions", "indices", "counts", "thr", "not_converged",
+              "sparse_desc")
+    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32)]
+
+
 class MetricParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("B", "cap0", "cap1", "D", "cols", "H0", "W0", "H1", "W1", "kp_yx", "n_mma", "n_vdd")] + \
                [("mma_thr", c_float * 4), ("vdd_thr", c_float * 4)]
@@ -50,6 +67,11 @@ SIGNATURES = {
     "einx_device_count": (c_int, []),
     "einx_profile_enable": (c_int, [c_int]),
     "einx_profile_report": (c_int, [c_char_p, c_size_t]),
+    "einx_extractor_create": (c_void_p, [ctypes.POINTER(ExtractorDesc)]),
+    "einx_extractor_destroy": (None, [c_void_p]),
+    "einx_extract_shapes": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(ExtractShapes)]),
+    "einx_extract_ws_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "einx_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(ExtractOut), c_void_p]),
     "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "einx_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

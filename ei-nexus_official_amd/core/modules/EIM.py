@@ -56,7 +56,7 @@ class EIM(nn.Module):
                 ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
             im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
             cur.wait_stream(side)
-            for t in (ev.feats, ev.logits, ev.raw, ev.prob, ev.score, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
+            for t in (ev.feats, ev.logits, ev.raw, ev.raw_cl, ev.prob, ev.score, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
                       ev.det.indices, ev.det.counts, ev.det.thr, ev.det.not_converged, ev.det.nms):
                 if t is not None:
                     t.record_stream(cur)  # allocated on the side stream, consumed on the caller's stream
@@ -103,7 +103,11 @@ class EIM(nn.Module):
         pre = full_batch_lists(mr) if mr is not None else None
         early["event"].synchronize()
         host = early["host"]
+        retries = 0
         while bool(host[2].any()) or bool(host[3].any()):
+            retries += 1
+            if retries > 8:  # 8 * 4**8 passes: cannot happen on a finite map (each pass removes at least one pixel or stops)
+                raise RuntimeError("einx: the NMS fix-point did not converge within the maximum pass budget")
             # the NMS fix-point of some image needed more passes than were enqueued: redo only the
             # detection tail (and the matcher) with a larger, remembered, pass budget (rare: blocking read-back)
             for flag, bf, wrapper in ((bool(host[2].any()), ev, self.event_extractor), (bool(host[3].any()), im, self.image_extractor)):
@@ -117,6 +121,9 @@ class EIM(nn.Module):
             if mr is not None:
                 nm_host = mr.nmatch.cpu()
                 nm_event = None
+        if retries == 0:
+            self.event_extractor.extractor.engine().note_converged()
+            self.image_extractor.extractor.engine().note_converged()
         n, m = host[0].tolist(), host[1].tolist()
         events_feats = ev.materialize(n)
         image_feats = im.materialize(m)

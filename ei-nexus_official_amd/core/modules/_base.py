@@ -16,6 +16,7 @@ class NativeExtractor(nn.Module):
     cell_size = 8
     uses_batchnorm = True
     dilate_mask = False
+    input_div = 0.0  # SuperPointv1: the input tensor is divided by 255 IN PLACE inside the forward (reference quirk)
 
     def _init_common(self, nms_radius, detection_top_k, detection_threshold, remove_borders, ordering, descriptor_scale_factor,
                      learnable_descriptor_scale_factor):
@@ -90,13 +91,15 @@ class NativeExtractor(nn.Module):
         if self._scale_host is None:  # one device read per engine build, not one host sync per forward
             self._scale_host = float(self.descriptor_scale_factor.detach())
         scale = self._scale_host
-        return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask,
-                                 dense=self.dense_outputs if dense is None else dense, nms_iters=nms_iters)
+        return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
+                       nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div)
 
     def forward(self, x, score_mask=None, **kwargs):
         bf = self.extract_batched(x, score_mask)
-        while True:
+        for _ in range(9):
             host = torch.stack([bf.det.counts, bf.det.not_converged]).cpu()
             if not bool(host[1].any()):
+                self.engine().note_converged()
                 return bf.materialize(host[0].tolist())
             self.engine().redetect(bf, self.engine().grow_nms_iters())  # NMS fix-point needs more passes
+        raise RuntimeError("einx: the NMS fix-point did not converge within the maximum pass budget")

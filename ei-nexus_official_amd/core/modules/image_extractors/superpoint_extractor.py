@@ -16,6 +16,7 @@ class SuperPointv1(NativeExtractor):
     cell_size = 8
     uses_batchnorm = False
     dilate_mask = False  # score_mask is used as given (:381-382, :411-412)
+    input_div = 255.0    # `image /= 255.0` on the caller's tensor (:372)
 
     def __init__(self, descriptor_dim=256, nms_radius=4, detection_top_k=2048, detection_threshold=0.0005, remove_borders=4,
                  ordering="yx", descriptor_scale_factor=1.0, learnable_descriptor_scale_factor=False):
@@ -55,5 +56,4 @@ class SuperPointv1(NativeExtractor):
             raise NotImplementedError("einx SuperPointv1 takes single-channel images (the EI-Nexus pipelines feed grayscale)")
         if not image.is_contiguous():
             raise RuntimeError("einx: image must be contiguous (it is scaled in place like the reference does)")
-        N.div_inplace(image, 255.0)  # the caller's tensor is modified, exactly like `image /= 255.0`
-        return image
+        return image  # `image /= 255.0` happens in place inside the extractor call (input_div)

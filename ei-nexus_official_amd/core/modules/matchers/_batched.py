@@ -17,6 +17,25 @@ def from_batched(bf):
     return pb
 
 
+def _lists_untouched(feats, pos, desc):
+    """The hidden device batch may stand in for the lists only while the lists still ARE views of it: a caller
+    may legally filter / replace feats['sparse_positions'] / ['sparse_descriptors'] between the extractor and
+    the matcher (the reference reads the lists), and then the lists win."""
+    bf = feats._batched
+    if torch.is_tensor(pos) or torch.is_tensor(desc) or len(pos) != bf.B or len(desc) != bf.B:
+        return False
+    kp, ds, ns = bf.det.positions, bf.sparse_desc, getattr(bf, "_ns", None)
+    if ns is None:
+        return False
+    for b in range(bf.B):
+        p, d = pos[b], desc[b]
+        if p.shape[0] != ns[b] or d.shape[0] != ns[b] or p.data_ptr() != kp[b].data_ptr() or d.data_ptr() != ds[b].data_ptr():
+            return False
+        if p.shape[0] and (p.stride(0) != kp.stride(1) or d.stride(0) != ds.stride(1)):
+            return False
+    return True
+
+
 def from_feats(feats):
     """Accepts the reference-style dict (lists of per-image tensors, or stacked tensors)."""
     pos, desc = feats["sparse_positions"], feats["sparse_descriptors"]
@@ -36,7 +55,7 @@ def from_feats(feats):
         pb.image_size = (int(size[0]), int(size[1]))
         pb.cap, pb.B = n, B
         return pb
-    if isinstance(feats, FeatsDict) and feats._batched is not None:
+    if isinstance(feats, FeatsDict) and feats._batched is not None and _lists_untouched(feats, pos, desc):
         pb = from_batched(feats._batched)
         pb.counts_host = [int(p.shape[0]) for p in feats["sparse_positions"]]
         return pb

@@ -1,0 +1,233 @@
+// extract.hip -- handle-level entry points: ONE call enqueues a whole extractor (SURVEY 8b's coarse ABI).
+//
+// einx_extractor_create copies the layer descriptors of one network (weights stay in caller-owned device
+// memory, already repacked by einx_conv_repack / folded by einx_bn_fold); einx_extract then enqueues, on the
+// given stream and without any host synchronisation,
+//   [input /= 255]  ->  backbone convs (replicate pad folded into layer 1)  ->  detector head  ->  descriptor head
+//   ->  [coarse-descriptor normalisation + channels-last raw copy]  ->  score map (softmax / sigmoid, pixel
+//   shuffle, mask dilation, border)  ->  NMS fix-point + top-k + positions  ->  sparse descriptor sampling,
+// i.e. everything VGGExtractor / VGGExtractorNP / SuperPointv1 / SiLKModel .forward does up to the output dict
+// (reference core/modules/event_extractors/EventExtractors.py:517-624,:331-434,
+// image_extractors/superpoint_extractor.py:345-480, image_extractors/silk_extractor.py:177-257).
+// Intermediate activations live in a caller-provided workspace (two ping-pong buffers + the detector's
+// workspace); every tensor of the reference's output dict is written to caller-provided outputs.
+// The op-level entry points (einx_conv_block, einx_score_map, ...) stay exported for the unit tests; this file
+// only sequences them, so a handle-level forward is bit-identical to the op-by-op forward.
+#include <new>
+#include <vector>
+
+#include "einx_common.h"
+
+struct einx_extractor {
+  einx_extractor_desc d;
+  std::vector<einx_conv_desc> backbone, det, desc;
+};
+
+namespace {
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Plan {
+  int Hp, Wp, h0, w0;       // padded size, top/left pad
+  int hc, wc;               // head resolution
+  size_t buf_elems[2];      // ping-pong activation buffers (floats per image)
+  size_t head_elems;        // scratch for the 3x3 head layers' outputs (floats per image)
+};
+
+// Padder.__init__ arithmetic (core/modules/utils/util.py:6-15)
+void padder(int h, int w, int p, int* w0, int* w1, int* h0, int* h1) {
+  const int hp = (((h / p) + 1) * p - h) % p;
+  const int wp = (((w / p) + 1) * p - w) % p;
+  *w0 = wp / 2;
+  *w1 = wp - wp / 2;
+  *h0 = hp / 2;
+  *h1 = hp - hp / 2;
+}
+
+bool make_plan(const einx_extractor* e, int H, int W, Plan* pl) {
+  int w0, w1, h0, h1;
+  padder(H, W, e->d.cell, &w0, &w1, &h0, &h1);
+  pl->Hp = H + h0 + h1;
+  pl->Wp = W + w0 + w1;
+  pl->h0 = h0;
+  pl->w0 = w0;
+  int h = pl->Hp, w = pl->Wp;
+  pl->buf_elems[0] = pl->buf_elems[1] = 0;
+  const int nb = (int)e->backbone.size();
+  for (int i = 0; i < nb; ++i) {
+    const einx_conv_desc& c = e->backbone[i];
+    if (c.pool) {
+      if ((h & 1) || (w & 1)) return false;
+      h /= 2;
+      w /= 2;
+    }
+    if (i + 1 < nb) {  // the last backbone layer writes the `backbone_feats` output, not a scratch buffer
+      const size_t n = (size_t)c.cout * h * w;
+      if (n > pl->buf_elems[i & 1]) pl->buf_elems[i & 1] = n;
+    }
+  }
+  pl->hc = h;
+  pl->wc = w;
+  size_t he = 0;
+  for (size_t i = 0; i + 1 < e->det.size(); ++i) he = std::max(he, (size_t)e->det[i].cout * h * w);
+  for (size_t i = 0; i + 1 < e->desc.size(); ++i) he = std::max(he, (size_t)e->desc[i].cout * h * w);
+  pl->head_elems = he;
+  return h * e->d.cell == pl->Hp && w * e->d.cell == pl->Wp;
+}
+
+int topk_cap(int N, int top_k, float det_thr) {
+  // rows a batch image can produce: N-1-lo for the quantile threshold of detection_top_k (see einx_detect), else N
+  if (top_k <= 0 || top_k >= N || det_thr < 1.0f) return N;
+  const float q = (float)(N - top_k) / (float)N;
+  const float rank = q * (float)(N - 1);
+  const int lo = (int)floorf(rank);
+  return N - 1 - lo;
+}
+
+void detect_params(const einx_extractor* e, const Plan& pl, int B, int H, int W, int cap, int nms_iters, einx_detect_params* p) {
+  p->B = B;
+  p->Hp = pl.Hp;
+  p->Wp = pl.Wp;
+  p->H = H;
+  p->W = W;
+  p->h0 = pl.h0;
+  p->w0 = pl.w0;
+  p->radius = e->d.nms_radius;
+  p->top_k = e->d.top_k;
+  p->det_thr = e->d.det_thr;
+  p->ordering_xy = e->d.ordering_xy;
+  p->cap = cap;
+  p->nms_iters = nms_iters;
+}
+
+}  // namespace
+
+EINX_EXPORT einx_extractor* einx_extractor_create(const einx_extractor_desc* d) {
+  if (!d || !d->backbone || !d->det_head || !d->desc_head || d->n_backbone <= 0 || d->n_det <= 0 || d->n_desc <= 0) {
+    einx_set_error("einx_extractor_create: null / empty layer lists");
+    return nullptr;
+  }
+  if (d->cell != 8 && d->cell != 1) {
+    einx_set_error("einx_extractor_create: cell must be 8 (SuperPoint-shaped) or 1 (SiLK-shaped)");
+    return nullptr;
+  }
+  einx_extractor* e = new (std::nothrow) einx_extractor();
+  if (!e) return nullptr;
+  e->d = *d;
+  e->backbone.assign(d->backbone, d->backbone + d->n_backbone);
+  e->det.assign(d->det_head, d->det_head + d->n_det);
+  e->desc.assign(d->desc_head, d->desc_head + d->n_desc);
+  e->d.backbone = e->backbone.data();
+  e->d.det_head = e->det.data();
+  e->d.desc_head = e->desc.data();
+  const int want = d->cell == 8 ? 65 : 1;
+  if (e->det.back().cout != want || e->backbone.back().cout != e->det.front().cin || e->backbone.back().cout != e->desc.front().cin) {
+    einx_set_error("einx_extractor_create: head shapes do not fit (detector head must end in %d channels)", want);
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+EINX_EXPORT void einx_extractor_destroy(einx_extractor* e) { delete e; }
+
+EINX_EXPORT int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* s) {
+  EINX_CHECK_ARG(e && s, "null pointer");
+  Plan pl;
+  EINX_CHECK_ARG(H > 0 && W > 0 && make_plan(e, H, W, &pl), "image size does not fit the network's pooling / cell size");
+  s->Hp = pl.Hp;
+  s->Wp = pl.Wp;
+  s->h0 = pl.h0;
+  s->w0 = pl.w0;
+  s->hc = pl.hc;
+  s->wc = pl.wc;
+  s->feat_channels = e->backbone.back().cout;
+  s->det_channels = e->det.back().cout;
+  s->desc_dim = e->desc.back().cout;
+  s->cap = topk_cap(pl.Hp * pl.Wp, e->d.top_k, e->d.det_thr);
+  return EINX_OK;
+}
+
+EINX_EXPORT size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int cap, int nms_iters) {
+  Plan pl;
+  if (!e || B <= 0 || !make_plan(e, H, W, &pl)) return 0;
+  einx_detect_params p;
+  detect_params(e, pl, B, H, W, cap > 0 ? cap : 1, nms_iters > 0 ? nms_iters : 1, &p);
+  size_t bytes = 0;
+  bytes += align256(pl.buf_elems[0] * B * sizeof(float)) + align256(pl.buf_elems[1] * B * sizeof(float));
+  bytes += align256(pl.head_elems * B * sizeof(float));
+  bytes += align256(einx_detect_ws_bytes(&p));
+  return bytes + 256;
+}
+
+EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
+                             const einx_extract_out* o, void* stream) {
+  EINX_CHECK_ARG(e && in && ws && o, "null pointer");
+  EINX_CHECK_ARG(o->feats && o->logits && o->raw && o->prob && o->score && o->positions && o->indices && o->counts && o->thr &&
+                     o->not_converged && o->sparse_desc,
+                 "null output pointer");
+  EINX_CHECK_ARG(B > 0 && H > 0 && W > 0 && o->cap > 0, "bad shape");
+  Plan pl;
+  EINX_CHECK_ARG(make_plan(e, H, W, &pl), "image size does not fit the network's pooling / cell size");
+  EINX_CHECK_ARG(e->d.cell == 1 || (o->coarse && o->raw_cl), "cell-8 networks need the coarse / raw_cl outputs");
+  char* p = (char*)ws;
+  float* buf[2];
+  buf[0] = (float*)p;
+  p += align256(pl.buf_elems[0] * B * sizeof(float));
+  buf[1] = (float*)p;
+  p += align256(pl.buf_elems[1] * B * sizeof(float));
+  float* head = (float*)p;
+  p += align256(pl.head_elems * B * sizeof(float));
+  void* det_ws = p;
+  int rc;
+  if (e->d.input_div != 0.0f && e->d.input_div != 1.0f) {  // SuperPointv1: `image /= 255.0` in place on the caller's tensor
+    rc = einx_div_inplace(in, (size_t)B * e->backbone.front().cin * H * W, e->d.input_div, stream);
+    if (rc) return rc;
+  }
+  // ---- backbone
+  const float* cur = in;
+  int h = pl.Hp, w = pl.Wp;
+  const int nb = (int)e->backbone.size();
+  for (int i = 0; i < nb; ++i) {
+    const einx_conv_desc& c = e->backbone[i];
+    float* out = (i + 1 < nb) ? buf[i & 1] : o->feats;
+    if (i == 0) rc = einx_conv_block(cur, B, H, W, pl.h0, pl.w0, pl.Hp, pl.Wp, &c, out, stream);
+    else rc = einx_conv_block(cur, B, h, w, 0, 0, h, w, &c, out, stream);
+    if (rc) return rc;
+    if (c.pool) {
+      h /= 2;
+      w /= 2;
+    }
+    cur = out;
+  }
+  // ---- heads (the hidden 3x3 layer of each head goes through the scratch buffer)
+  auto run_head = [&](const std::vector<einx_conv_desc>& L, float* final_out) -> int {
+    const float* x = o->feats;
+    for (size_t i = 0; i < L.size(); ++i) {
+      float* out = (i + 1 < L.size()) ? head : final_out;
+      const int r = einx_conv_block(x, B, h, w, 0, 0, h, w, &L[i], out, stream);
+      if (r) return r;
+      x = out;
+    }
+    return 0;
+  };
+  if ((rc = run_head(e->det, o->logits))) return rc;
+  if ((rc = run_head(e->desc, o->raw))) return rc;
+  const int D = e->desc.back().cout;
+  // ---- dense by-product first (depends on `raw` only; overlaps the other extractor's convolutions)
+  if (e->d.cell == 8) {
+    rc = einx_normalize_map(o->raw, B, D, h * w, e->d.desc_scale, o->coarse, o->raw_cl, stream);
+    if (rc) return rc;
+  }
+  rc = einx_score_map(o->logits, B, e->det.back().cout, h, w, mask, H, W, pl.h0, pl.w0, e->d.dilate_mask, e->d.border, o->prob, o->score,
+                      stream);
+  if (rc) return rc;
+  einx_detect_params dp;
+  detect_params(e, pl, B, H, W, o->cap, nms_iters > 0 ? nms_iters : 8, &dp);
+  rc = einx_detect(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, stream);
+  if (rc) return rc;
+  const bool bilinear = e->d.cell == 8;
+  const bool use_cl = bilinear && D <= 512;
+  return einx_desc_sample(use_cl ? o->raw_cl : o->raw, B, D, h, w, pl.Hp, pl.Wp, bilinear ? 1 : 0, use_cl ? 1 : 0, o->indices, o->counts,
+                          o->cap, e->d.desc_scale, o->sparse_desc, stream);
+}

@@ -258,6 +258,67 @@ int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Handle-level extractor: ONE call enqueues a whole network (SURVEY.md 8b's coarse ABI)
+ * replaces: VGGExtractor.forward / VGGExtractorNP.forward
+ *             core/modules/event_extractors/EventExtractors.py:517-624, :331-434
+ *           SuperPointv1.forward  core/modules/image_extractors/superpoint_extractor.py:345-480
+ *           SiLKModel.forward     core/modules/image_extractors/silk_extractor.py:177-257
+ * up to (not including) the Python output dict.  The handle owns copies of the layer descriptors only;
+ * weights stay in caller-owned device memory (einx_conv_repack / einx_bn_fold images).  einx_extract makes no
+ * allocation and no host synchronisation; it is bit-identical to the same sequence of op-level calls.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct einx_extractor einx_extractor; /* opaque */
+
+typedef struct einx_extractor_desc {
+  int32_t cell;        /* 8: SuperPoint-shaped (65-channel detector head, coarse descriptors); 1: SiLK-shaped */
+  int32_t n_backbone, n_det, n_desc;
+  const einx_conv_desc* backbone; /* host arrays, copied by einx_extractor_create */
+  const einx_conv_desc* det_head;
+  const einx_conv_desc* desc_head;
+  int32_t dilate_mask; /* event extractors dilate the events mask 3x3 (EventExtractors.py:544-550) */
+  int32_t border;      /* remove_borders */
+  int32_t nms_radius;
+  int32_t top_k;       /* detection_top_k (0 = none) */
+  float det_thr;       /* detection_threshold */
+  int32_t ordering_xy; /* 0: (y,x,p)  1: (x,y,p) */
+  float desc_scale;    /* descriptor_scale_factor */
+  float input_div;     /* SuperPointv1 scales its input in place (`image /= 255.0`, superpoint_extractor.py:372); 0 = off */
+} einx_extractor_desc;
+
+typedef struct einx_extract_shapes_t {
+  int32_t Hp, Wp, h0, w0; /* padded size and top/left padding (Padder, utils/util.py:6-15) */
+  int32_t hc, wc;         /* head resolution (Hp/cell, Wp/cell) */
+  int32_t feat_channels, det_channels, desc_dim;
+  int32_t cap;            /* keypoint rows per image the detector can emit (top-k quantile arithmetic) */
+} einx_extract_shapes_t;
+
+typedef struct einx_extract_out {
+  float* feats;     /* [B,feat_channels,hc,wc]   backbone_feats */
+  float* logits;    /* [B,det_channels,hc,wc] */
+  float* raw;       /* [B,desc_dim,hc,wc]        raw_descriptors */
+  float* prob;      /* [B,det_channels,hc,wc]    probability */
+  float* score;     /* [B,1,Hp,Wp]               padded score map (masked, border-zeroed) */
+  float* coarse;    /* [B,desc_dim,hc,wc]        coarse_descriptors (cell 8) or NULL */
+  float* raw_cl;    /* [B,hc*wc,desc_dim]        channels-last raw copy for the sparse sampler (cell 8) or NULL */
+  float* nms;       /* [B,H,W]                   thresholded NMS map, cropped, or NULL */
+  float* positions; /* [B,cap,3] */
+  int32_t* indices; /* [B,cap] */
+  int32_t* counts;  /* [B] */
+  float* thr;       /* [B] */
+  int32_t* not_converged; /* [B] see einx_detect */
+  float* sparse_desc;     /* [B,cap,desc_dim] */
+  int32_t cap;
+} einx_extract_out;
+
+einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
+void einx_extractor_destroy(einx_extractor* e);
+int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* shapes);
+size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int cap, int nms_iters);
+/* in [B,cin,H,W] (modified in place only when input_div is set); mask [B,1,H,W] uint8 or NULL */
+int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
+                 const einx_extract_out* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Evaluation metrics of the reference's test harness (the step after the path)
  *   MatchingRatio            core/metrics/matching_metrics.py:30-51
  *   MeanMatchingAccuracy@t   core/metrics/matching_metrics.py:84-156   (points ordering "yx")

@@ -337,3 +337,80 @@ def test_wrong_dtype_inputs_raise_or_are_cast():
     with pytest.raises(TypeError, match="int32"):
         pkg.native.mnn(torch.zeros(1, 8, 64, device=DEV), torch.tensor([8], device=DEV), torch.zeros(1, 8, 64, device=DEV),
                        torch.tensor([8], device=DEV))
+
+
+def test_matcher_uses_edited_feature_lists(oracle):
+    """a caller may filter feats['sparse_positions'] / ['sparse_descriptors'] between the extractor and
+    Matcher(feats0, feats1) (legal with the reference, which reads the lists); the hidden device batch must not be
+    used then."""
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 64
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ev, mask = synth.synth_events(9, 2, 5, 90, 122)
+    img = synth.synth_image(9, 2, 90, 122)
+    ef = model.event_extractor(_t(ev), _t(mask))
+    imf = model.image_extractor(_t(img))
+    full = model.matcher(ef, imf)
+    for b in range(2):
+        exp = oracle.mnn(_np(ef["sparse_descriptors"][b]), _np(imf["sparse_descriptors"][b]), want_la=False)
+        assert np.array_equal(_np(full["matches0"][b])[0], exp["matches0"])
+    # keep every second keypoint of image 0 on the event side (new tensors, new lengths)
+    keep = [ef["sparse_positions"][b].shape[0] for b in range(2)]
+    ef["sparse_positions"] = [p[::2].contiguous() for p in ef["sparse_positions"]]
+    ef["sparse_descriptors"] = [d[::2].contiguous() for d in ef["sparse_descriptors"]]
+    cut = model.matcher(ef, imf)
+    for b in range(2):
+        n = (keep[b] + 1) // 2
+        assert tuple(cut["matches0"][b].shape) == (1, n)
+        exp = oracle.mnn(_np(ef["sparse_descriptors"][b]), _np(imf["sparse_descriptors"][b]), want_la=False)
+        assert np.array_equal(_np(cut["matches0"][b])[0], exp["matches0"])
+        assert np.array_equal(_np(cut["matches1"][b])[0], exp["matches1"])
+    # a shortened VIEW of the original rows (same storage, fewer rows) must be honoured too
+    imf["sparse_positions"] = [p[:10] for p in imf["sparse_positions"]]
+    imf["sparse_descriptors"] = [d[:10] for d in imf["sparse_descriptors"]]
+    cut2 = model.matcher(ef, imf)
+    for b in range(2):
+        exp = oracle.mnn(_np(ef["sparse_descriptors"][b]), _np(imf["sparse_descriptors"][b]), want_la=False)
+        assert tuple(cut2["matches1"][b].shape) == (1, 10)
+        assert np.array_equal(_np(cut2["matches0"][b])[0], exp["matches0"])
+
+
+def test_handle_level_extract_equals_op_level_calls():
+    """einx_extract (one call per network) against the same network run layer by layer through the op-level ABI."""
+    nat = pkg.native
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ev, mask = synth.synth_events(21, 3, 5, 100, 130)
+    ext = model.event_extractor.extractor
+    ext.dense_outputs = False
+    bf = ext.extract_batched(_t(ev), _t(mask))
+    eng = ext.engine()
+    pads = nat.padder_pads(100, 130, 8)
+    Hp, Wp = 100 + pads[2] + pads[3], 130 + pads[0] + pads[1]
+    t = _t(ev)
+    for i, layer in enumerate(eng.backbone):
+        t = layer(t, fold=(pads[2], pads[0], Hp, Wp) if i == 0 else None)
+    assert torch.equal(t, bf.feats)
+    d = t
+    for layer in eng.det_head:
+        d = layer(d)
+    assert torch.equal(d, bf.logits)
+    r = t
+    for layer in eng.desc_head:
+        r = layer(r)
+    assert torch.equal(r, bf.raw)
+    coarse, raw_cl = nat.normalize_map(r, 1.0, want_cl=True)
+    prob, score = nat.score_map(d, _t(mask), pads, dilate=True, border=4)
+    assert torch.equal(prob, bf.prob) and torch.equal(score, bf.score) and torch.equal(coarse, bf.coarse)
+    det = nat.detect(score, top_k=1024, radius=4, det_thr=1.0, pads=pads)
+    assert det.cap == bf.det.cap
+    assert torch.equal(det.counts, bf.det.counts) and torch.equal(det.nms, bf.det.nms)
+    n = int(det.counts.min())
+    assert torch.equal(det.positions[:, :n], bf.det.positions[:, :n])
+    sp = nat.desc_sample(r, det.indices, det.counts, (Hp, Wp), bilinear=True, scale=1.0, raw_cl=raw_cl)
+    assert torch.equal(sp[:, :n], bf.sparse_desc[:, :n])
