@@ -34,6 +34,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP maps streams onto a small pool of hardware queues (4 by default).  RCCL's own streams take some of them, and
+# the event extractor's side stream then shares a queue with the main stream: the two extractors serialise and the
+# step is 5 % slower (measured: 3380 -> 3200 pairs/s, back to 3375 with 8 queues; profiles/README.md).  The HIP
+# runtime reads this when it initialises, which in this process happens after this line (torch is imported later).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_HBM_BYTES = 8.0e12
 SP_PAIR_BYTES = 188.8e6  # algorithmic HBM bytes of the conv stage per pair
@@ -466,6 +472,8 @@ def run_rank(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if os.environ.get("EINX_BENCH_NO_PG") == "1":  # tools: a launched rank without a process group (A/B of the RCCL overhead)
+        distributed = False
     rccl = None
     if distributed:  # under a launcher (also with one rank): RCCL process group, one process per GPU
         dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)

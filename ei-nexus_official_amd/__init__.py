@@ -10,7 +10,14 @@ include/einx.h).  Importing it loads libeinx_hip.so and fails loudly if the libr
 To use it under the reference's import paths put the package directory on sys.path:
 `sys.path.insert(0, ".../ei-nexus_official_amd"); from core.modules import build_model`.
 """
-from . import _lib
+import os as _os
+
+# see bench.py / INTEGRATION.md: with RCCL initialised, 4 hardware queues are not enough for the two-stream
+# extractor schedule (effective when the HIP runtime has not been initialised yet; set it in the environment of
+# the launcher otherwise)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import _lib  # noqa: E402
 
 _lib.load()  # no fallback: raise now if the HIP extension is not built
 

@@ -8,6 +8,7 @@ and :331-434, core/modules/image_extractors/superpoint_extractor.py:345-480,
 core/modules/image_extractors/silk_extractor.py:177-257.
 """
 import ctypes
+import os
 
 import torch
 
@@ -133,6 +134,8 @@ def _mask_u8(mask, H, W):
 
 class ExtractorEngine:
     """Holds the kernel-native layer images of one network and runs the batched forward."""
+
+    use_handle = os.environ.get("EINX_OP_LEVEL", "0") != "1"  # tools: EINX_OP_LEVEL=1 enqueues layer by layer through the op-level ABI
 
     def __init__(self, kind, *, top_k, radius, border, det_thr, ordering, cell):
         self.kind = kind
@@ -274,7 +277,7 @@ class ExtractorEngine:
         Hp, Wp = H + h0 + h1, W + w0 + w1
         h = self.handle(scale, dilate_mask, input_div)
         sh = self.shapes(h, H, W)
-        if sh.cap <= 8192:
+        if sh.cap <= 8192 and self.use_handle:
             return self._run_handle(h, sh, x, mask, pads, scale, dense, nms_iters or self.nms_iters)
         if input_div:
             N.div_inplace(x, input_div)

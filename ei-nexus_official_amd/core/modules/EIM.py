@@ -39,7 +39,7 @@ class EIM(nn.Module):
     def _side_stream(self, device):
         st = getattr(self, "_einx_side_stream", None)
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
+            st = torch.cuda.Stream(device=device, priority=int(os.environ.get("EINX_SIDE_PRIO", "0")))
             self._einx_side_stream = st
         return st
 
