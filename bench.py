@@ -242,6 +242,27 @@ class Workload:
         return el / steps, nm / (steps * self.B)
 
 
+def timed_stream(wl, steps, depth=2):
+    """the same K forwards through EIM.forward_stream (up to `depth` batches in flight)"""
+    torch = wl.torch
+
+    def gen(n):
+        for _ in range(n):
+            wl.img.copy_(wl.img_src)
+            yield (wl.ev, wl.img, wl.mask)
+
+    for _ in wl.model.forward_stream(gen(3), depth=depth):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nm = 0
+    for _, _, m in wl.model.forward_stream(gen(steps), depth=depth):
+        nm += sum(int(t.shape[0]) for t in m["matched_kpts0"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return el / steps, nm / (steps * wl.B)
+
+
 def hip_time(torch, fn, reps, warm=2):
     """mean seconds per call, HIP events on the stream the kernels are launched on (torch's current stream)"""
     for _ in range(warm):
@@ -595,6 +616,13 @@ def run_rank(args):
             torch.cuda.empty_cache()
             w = leg("sp_mnn", 1, steps=50, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
             del w
+            sec, mm = timed_stream(wl, 20)
+            extras.append({"config": "sp_mnn", "workload": f"B{B} " + WORKLOADS["sp_mnn"][2], "pairs_per_step": B,
+                           "calibrated_descriptors": bool(wl.calibrated), "value": round(B / sec, 2), "unit": "pairs/s",
+                           "ms_per_step": round(sec * 1e3, 3), "steps": 20, "mean_matches": round(mm, 1),
+                           "note": "EIM.forward_stream, 2 batches in flight: the next batch's convolutions are enqueued before the host "
+                                   "waits for the previous batch's counts (same kernels and outputs; the headline above is the "
+                                   "synchronous EIM.forward, one batch at a time like the reference)"})
             w = leg("sp_mnn", 32, calibrate=wl.calibrated is False, steps=10,
                     note="the other descriptor regime: " + ("calibrated" if not wl.calibrated else "round-1 un-calibrated weights (near-constant descriptors)"))
             del w

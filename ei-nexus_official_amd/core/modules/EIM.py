@@ -78,31 +78,37 @@ class EIM(nn.Module):
             buf = self._host_bufs[name] = torch.empty(shape, dtype=torch.int32, pin_memory=True)
         return buf
 
-    def forward(self, events, image, events_mask=None, image_mask=None):
-        """The host reads the counts back in two steps: the per-image keypoint counts are copied (pinned buffer,
-        non-blocking) as soon as both extractors are done, so the feature lists are built while the matcher still
-        runs; the per-pair match counts follow.  Both copies complete before this function returns: from the
-        caller's point of view it is one synchronous forward like the reference's."""
+    def _enqueue(self, events, image, events_mask=None, image_mask=None, slot=0):
+        """Device side of one forward, nothing waits: both extractors, the matcher, the two small count read-backs
+        (non-blocking copies into pinned buffers of `slot`, each followed by an event) and every output that does
+        not depend on the counts."""
         B = events.shape[0]
-        early = {}
+        p = {"B": B, "slot": slot}
 
         def read_detection(ev, im):
             rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged])
-            early["host"] = self._pinned("det", (4, B)).copy_(rows, non_blocking=True)
-            early["event"] = torch.cuda.Event()
-            early["event"].record()
+            p["det_host"] = self._pinned(f"det{slot}", (4, B)).copy_(rows, non_blocking=True)
+            p["det_event"] = torch.cuda.Event()
+            p["det_event"].record()
 
         ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=read_detection)
-        nm_event = None
+        p["ev"], p["im"], p["mr"] = ev, im, mr
+        p["nm_event"] = None
         if mr is not None:
-            nm_host = self._pinned("nmatch", (B,)).copy_(mr.nmatch, non_blocking=True)
-            nm_event = torch.cuda.Event()
-            nm_event.record()
+            p["nm_host"] = self._pinned(f"nmatch{slot}", (B,)).copy_(mr.nmatch, non_blocking=True)
+            p["nm_event"] = torch.cuda.Event()
+            p["nm_event"].record()
         ev.prepare()  # count-independent outputs are built while the device still works on the tail
         im.prepare()
-        pre = full_batch_lists(mr) if mr is not None else None
-        early["event"].synchronize()
-        host = early["host"]
+        p["pre"] = full_batch_lists(mr) if mr is not None else None
+        return p
+
+    def _finish(self, p):
+        """Host side of one forward: wait for the two read-backs, cut the per-pair lists."""
+        ev, im, mr, pre = p["ev"], p["im"], p["mr"], p["pre"]
+        p["det_event"].synchronize()
+        host = p["det_host"]
+        nm_host, nm_event = p.get("nm_host"), p["nm_event"]
         retries = 0
         while bool(host[2].any()) or bool(host[3].any()):
             retries += 1
@@ -141,6 +147,31 @@ class EIM(nn.Module):
             # the two feature dicts in place
             matches = self.matcher(events_feats, image_feats)
         return events_feats, image_feats, matches
+
+    def forward(self, events, image, events_mask=None, image_mask=None):
+        """The host reads the counts back in two steps: the per-image keypoint counts are copied (pinned buffer,
+        non-blocking) as soon as both extractors are done, so the feature lists are built while the matcher still
+        runs; the per-pair match counts follow.  Both copies complete before this function returns: from the
+        caller's point of view it is one synchronous forward like the reference's."""
+        return self._finish(self._enqueue(events, image, events_mask, image_mask))
+
+    def forward_stream(self, batches, depth=2):
+        """Throughput mode for evaluation loops (the reference's scripts iterate a DataLoader and call the model once per
+        batch, test_events-image_same-time.py:130-194): `batches` yields (events, image[, events_mask[, image_mask]])
+        tuples, results come back in order, one `forward` result per batch.  Up to `depth` batches are in flight: the
+        next batch's convolutions are enqueued before the host waits for the previous batch's counts, so the
+        latency-bound detection / matching tail and the host-side list building hide under them.  Same kernels, same
+        outputs as `forward`; every input tensor must stay untouched until its result has been yielded."""
+        from collections import deque
+        pending = deque()
+        k = 0
+        for args in batches:
+            pending.append(self._enqueue(*args, slot=k % max(depth, 1)))
+            k += 1
+            if len(pending) >= max(depth, 1):
+                yield self._finish(pending.popleft())
+        while pending:
+            yield self._finish(pending.popleft())
 
     def count_parameters(self, model):
         return sum(p.numel() for p in model.parameters() if p.requires_grad)

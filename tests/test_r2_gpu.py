@@ -414,3 +414,33 @@ def test_handle_level_extract_equals_op_level_calls():
     assert torch.equal(det.positions[:, :n], bf.det.positions[:, :n])
     sp = nat.desc_sample(r, det.indices, det.counts, (Hp, Wp), bilinear=True, scale=1.0, raw_cl=raw_cl)
     assert torch.equal(sp[:, :n], bf.sparse_desc[:, :n])
+
+
+def test_forward_stream_equals_forward():
+    """EIM.forward_stream (batches in flight) returns, in order, exactly what EIM.forward returns batch by batch."""
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 128
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    batches = []
+    for i in range(4):
+        ev, mask = synth.synth_events(40 + i, 3, 5, 120, 160)
+        batches.append((_t(ev), synth.synth_image(40 + i, 3, 120, 160), _t(mask)))
+    ref = [model(ev, _t(img), mask) for ev, img, mask in batches]
+    got = list(model.forward_stream(((ev, _t(img), mask) for ev, img, mask in batches), depth=2))
+    assert len(got) == len(ref)
+    for (e0, i0, m0), (e1, i1, m1) in zip(ref, got):
+        for a, b in ((e0, e1), (i0, i1)):
+            for key in ("score", "nms", "logits", "raw_descriptors"):
+                assert torch.equal(a[key], b[key]), key
+            for x, y in zip(a["sparse_positions"], b["sparse_positions"]):
+                assert torch.equal(x, y)
+            for x, y in zip(a["sparse_descriptors"], b["sparse_descriptors"]):
+                assert torch.equal(x, y)
+        for key in ("matches0", "matches1", "matched_kpts0", "matched_kpts1", "log_assignment"):
+            for x, y in zip(m0[key], m1[key]):
+                assert torch.equal(x, y), key
+    ev, img, mask = batches[0]
+    assert [len(list(model.forward_stream(iter([(ev, _t(img), mask)]), depth=d))) for d in (1, 3)] == [1, 1]
