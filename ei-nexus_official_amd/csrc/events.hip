@@ -8,6 +8,8 @@
 //
 // Scatter-add (the reference's put_(accumulate=True)): the voxel grid accumulates in LDS tiles (fp32 LDS atomics,
 // exact up to summation order), the count image uses integer global atomics and is bit-exact.
+#include <mutex>
+
 #include "einx_common.h"
 
 namespace {
@@ -225,6 +227,20 @@ EINX_EXPORT size_t einx_events_ws_bytes(int B, int H, int W) {
 }
 
 namespace {
+// The caller's offsets array is pageable memory that it may free as soon as the call returns, so it is first copied
+// (synchronously, a few hundred bytes) into a library-owned PINNED staging buffer; the asynchronous host-to-device
+// copy then reads that.  One buffer per host thread, reused once the previous copy's event has completed.
+struct PinnedOffsets {
+  int64_t* p = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  ~PinnedOffsets() {
+    if (p) (void)hipHostFree(p);
+    if (done) (void)hipEventDestroy(done);
+  }
+};
+thread_local PinnedOffsets g_offs;
+
 // copies the host offsets to the workspace and returns the largest per-sample event count (-1 on bad input)
 long long stage_offsets(const int64_t* offsets_host, int B, int H, int W, void* ws, hipStream_t s, int64_t** dev) {
   long long mx = 0;
@@ -236,8 +252,35 @@ long long stage_offsets(const int64_t* offsets_host, int B, int H, int W, void* 
   char* p = (char*)ws + (size_t)B * 32 + (size_t)B * H * W * sizeof(int32_t) + (size_t)B * 8;
   p = (char*)(((size_t)p + 7) & ~(size_t)7);
   *dev = (int64_t*)p;
-  if (hipMemcpyAsync(p, offsets_host, ((size_t)B + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+  PinnedOffsets& st = g_offs;
+  const size_t need = (size_t)B + 1;
+  if (st.done && hipEventSynchronize(st.done) != hipSuccess) return -2;  // the previous call's copy has left the buffer
+  if (need > st.cap) {
+    if (st.p) (void)hipHostFree(st.p);
+    st.p = nullptr;
+    st.cap = 0;
+    if (hipHostMalloc((void**)&st.p, need * 2 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) return -2;
+    st.cap = need * 2;
+  }
+  if (!st.done && hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return -2;
+  for (size_t i = 0; i < need; ++i) st.p[i] = offsets_host[i];
+  if (hipMemcpyAsync(p, st.p, need * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+  if (hipEventRecord(st.done, s) != hipSuccess) return -2;
   return mx;
+}
+
+// hipFuncSetAttribute is per device: remember the largest dynamic-LDS size granted on each one
+int reserve_voxel_lds(size_t lds) {
+  static std::mutex mu;
+  static size_t granted[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (lds <= granted[dev]) return 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&voxel_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return -1;
+  granted[dev] = lds;
+  return 0;
 }
 }  // namespace
 
@@ -270,13 +313,9 @@ EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t,
   rows = rows < 1 ? 1 : (rows > H ? H : rows);
   const size_t lds = (size_t)bins * rows * W * sizeof(float);
   EINX_CHECK_ARG(lds <= 150 * 1024, "bins * W too large for the LDS tile scatter");
-  static size_t lds_attr = 0;
-  if (lds > lds_attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&voxel_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      einx_set_error("einx_voxel_grid: cannot reserve %zu bytes of LDS", lds);
-      return EINX_ERR_LAUNCH;
-    }
-    lds_attr = lds;
+  if (reserve_voxel_lds(lds) != 0) {
+    einx_set_error("einx_voxel_grid: cannot reserve %zu bytes of LDS", lds);
+    return EINX_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(voxel_tile_kernel, dim3((unsigned)einx_cdiv(H, rows), (unsigned)B), dim3(1024), lds, s, a, rows, normalize ? stats : nullptr);
   EINX_CHECK_LAUNCH();
