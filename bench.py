@@ -345,10 +345,13 @@ def dominant_kernel_roofline(wl, value_per_gpu, kernel_only=False):
     flops = conv_layer_flops(l1.cin, l1.cout, l1.ks, Hp, Wp) * B
     ach = flops / dur / 1e12
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv1b.json")
-    if wl.config == "sp_mnn" and B == 32 and os.path.exists(pmc):
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv1b.json")))
+    if wl.config == "sp_mnn" and B == 32 and pmcs:
+        pmc = pmcs[-1]  # the latest round's counter passes
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-        traffic_src = "replayed from profiles/r01_pmc_conv1b.json (FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over this kernel; not re-measured by this run)"
+        traffic_src = (f"replayed from profiles/{os.path.basename(pmc)} (FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over this "
+                       "kernel, tools/collect_profiles.sh; PMC counters cannot be read from inside this process, so this run did not re-measure them)")
     tile = "8,32,2,4,1,2,8"
     kname = f"conv_block_kernel<3,{tile},{'true' if l1.pool else 'false'},true> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
     return {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

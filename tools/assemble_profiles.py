@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 PR = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def last_json_line(path):
@@ -37,6 +37,18 @@ def main():
         j = last_json_line(os.path.join(EV, src))
         json.dump(j, open(os.path.join(PR, f"{R}_{dst}"), "w"), indent=1)
         print(dst, j["value"], j["unit"], "roofline", j.get("roofline", {}).get("achieved"))
+    for src, dst in (("bench_spawn1", "rccl_one_rank_launcher.log"), ("bench_torchrun1", "rccl_one_rank_torchrun.log")):
+        if os.path.exists(os.path.join(EV, src + ".json")):
+            with open(os.path.join(PR, f"{R}_{dst}"), "w") as fo:
+                fo.write("# " + ("python bench.py --gpus 1 --spawn --no-cpu-baseline --no-extras" if "spawn" in src else
+                                 "python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 ... bench.py --gpus 1 "
+                                 "--no-cpu-baseline --no-extras") + "\n")
+                fo.write(open(os.path.join(EV, src + ".err")).read())
+                fo.write(open(os.path.join(EV, src + ".json")).read())
+    for src, dst in (("layer_table.txt", "conv_layer_table.txt"), ("latency_b1.txt", "latency_b1.txt")):
+        if os.path.exists(os.path.join(EV, src)):
+            txt = "\n".join(ln for ln in open(os.path.join(EV, src)).read().splitlines() if "amdgpu.ids" not in ln)
+            open(os.path.join(PR, f"{R}_{dst}"), "w").write(txt + "\n")
     for src, dst in (("prof_overlap", "sp_mnn_b32_kernel_stats.csv"), ("prof_single", "sp_mnn_b32_kernel_stats_single_stream.csv"),
                      ("prof_lg", "sp_lg_b64_kernel_stats.csv")):
         f = glob.glob(os.path.join(EV, src, "**", "*kernel_stats.csv"), recursive=True)[0]
@@ -130,10 +142,46 @@ def write_readme(pmc, busy):
         A("")
         A(f"CPU baseline of the headline line: {cb['value']} {cb['unit']} ({cb['kind']}, {cb['cores']} host threads; {cb['sample']}).")
     A("")
+    if b.get("extra_configs"):
+        A("")
+        A("`extra_configs` of the headline line (short legs inside the same `python bench.py` run, i.e. what the driver's run also measures):")
+        A("")
+        A("| config | pairs/step | pairs/s | ms/step | mean matches | note |")
+        A("|---|---|---|---|---|---|")
+        for e in b["extra_configs"]:
+            A(f"| {e['config']} | {e['pairs_per_step']} | {e['value']:.0f} | {e['ms_per_step']:.3f} | {e['mean_matches']} | {e.get('note', '')[:110]} |")
+    if cb and "verified_pairs" in cb:
+        A("")
+        A(f"Post-run verification (outside the timed region): {cb['verified_pairs']} of {cb['verified_of']} pairs of the CPU sample have GPU outputs "
+          f"equal to the oracle's ({cb['verified_what']}).  `mean_matches` of the headline line: {b['config']['mean_matches']} "
+          f"({b['config']['weights']}).")
+    for name, tag in (("rccl_one_rank_launcher.log", "bench.py's own launcher"), ("rccl_one_rank_torchrun.log", "torchrun")):
+        f = os.path.join(PR, f"{R}_{name}")
+        if os.path.exists(f):
+            j = last_json_line(f)
+            A("")
+            A(f"One-rank RCCL launch through {tag} (`{R}_{name}`): {j['value']:.0f} pairs/s, `rccl` = {json.dumps(j.get('rccl'))}.")
+    if b.get("roofline_stages"):
+        A("")
+        A("## Stage rooflines (`roofline_stages` of the headline line: HIP events around every launch of one forward, library-side `einx_profile_*`)")
+        A("")
+        A("| stage | ms | achieved | fraction of the fp32-MFMA peak | other |")
+        A("|---|---|---|---|---|")
+        for st in b["roofline_stages"]:
+            if "achieved" in st:
+                other = ""
+                if "hbm" in st:
+                    other = f"HBM view: {st['hbm']['achieved_GBps']:.0f} GB/s algorithmic = {st['hbm']['frac'] * 100:.1f} % of 8 TB/s"
+                if "other_kernels_ms" in st:
+                    other = "other kernels (ms): " + json.dumps(st["other_kernels_ms"])
+                A(f"| {st['stage']} | {st['ms']} | {st['achieved']} {st['unit']} | {st['frac'] * 100:.1f} % | {other} |")
+            else:
+                A(f"| {st['stage']} | | | | {json.dumps(st.get('kernels_ms'))} |")
+    A("")
     A("## Dominant kernel: `conv_block_kernel<3,8,32,2,4,1,2,8,true,true>` (conv1b, 64->64 3x3 @264x352 + ReLU + 2x2 max-pool, B=32)")
     A("")
     A(f"* algorithmic work per launch: {flop / 1e9:.1f} GFLOP (2 x 64 x 64 x 9 x 264 x 352 x 32); algorithmic bytes {pmc['algorithmic_bytes_per_launch'] / 1e6:.1f} MB.")
-    A(f"* `roofline` in the bench line (HIP events around 10 back-to-back launches on the launch stream): {rf['launch_ms']:.3f} ms -> "
+    A(f"* `roofline` in the bench line (HIP events around {rf.get('launches_timed', 10)} back-to-back launches on the launch stream): {rf['launch_ms']:.3f} ms -> "
       f"**{rf['achieved']:.1f} TFLOP/s = {rf['frac'] * 100:.1f} %** of the 157.3 TFLOP/s dense fp32-MFMA peak.")
     if ko:
         A(f"* `{R}_conv1b_kernel_only_stats.csv` (`rocprofv3 --kernel-trace --stats -- python3 bench.py --kernel-only`, the same launches alone): "
@@ -169,6 +217,15 @@ def write_readme(pmc, busy):
     for r in stats("sp_lg_b64_kernel_stats")[:12]:
         A(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
     A("")
+    extra = os.path.join(PR, f"{R}_notes.md")
+    if os.path.exists(extra):  # hand-written findings of the round (experiments, A/B runs), kept next to the raw logs
+        A(open(extra).read())
+    older = sorted(f for f in os.listdir(PR) if re.match(r"r\d+_", f) and not f.startswith(R + "_"))
+    if older:
+        A("## Earlier rounds")
+        A("")
+        A("Files of earlier rounds are kept as they were: " + ", ".join(f"`{f}`" for f in older) + ".")
+        A("")
     open(os.path.join(PR, "README.md"), "w").write("\n".join(lines))
 
 

@@ -9,21 +9,26 @@ O=$R/gpurun_out/ev
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_sp_mnn.json 2> $O/bench_sp_mnn.err
-python bench.py --log-assignment --dense --no-cpu-baseline > $O/bench_sp_mnn_full.json 2>> $O/bench.err
-python bench.py --with-metrics --no-cpu-baseline > $O/bench_sp_mnn_metrics.json 2>> $O/bench.err
+python bench.py --log-assignment --dense --no-cpu-baseline --no-extras > $O/bench_sp_mnn_full.json 2>> $O/bench.err
+python bench.py --with-metrics --no-cpu-baseline --no-extras > $O/bench_sp_mnn_metrics.json 2>> $O/bench.err
 python bench.py --config sp_lg --cpu-pairs 2 > $O/bench_sp_lg.json 2>> $O/bench.err
-python bench.py --config silk_mnn --no-cpu-baseline > $O/bench_silk.json 2>> $O/bench.err
+python bench.py --config silk_mnn --cpu-pairs 2 > $O/bench_silk.json 2>> $O/bench.err
+# one-rank RCCL group through bench.py's own launcher, and through torchrun (the driver's launch pattern)
+python bench.py --gpus 1 --spawn --no-cpu-baseline --no-extras > $O/bench_spawn1.json 2> $O/bench_spawn1.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-extras > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+python bench.py --layer-table > $O/layer_table.txt 2>> $O/bench.err
+python tools/latency_b1.py 1 > $O/latency_b1.txt 2>> $O/bench.err
 echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_overlap -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_overlap.log 2>&1
-EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_single.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lg -o p -- python3 $R/bench.py --config sp_lg --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_lg.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_overlap -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_overlap.log 2>&1
+EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_single.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lg -o p -- python3 $R/bench.py --config sp_lg --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_lg.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kernel_only -o p -- python3 $R/bench.py --kernel-only > $O/prof_kernel_only.log 2>&1
 echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --kernel-only > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_busy.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_busy.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy_lg -o p -- python3 $R/tools/lg_bench.py --skip-linear --reps 1 > $O/pmc_busy_lg.log 2>&1
 echo "pmc done"
 ls $O
