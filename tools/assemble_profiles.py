@@ -181,8 +181,10 @@ def write_readme(pmc, busy):
     A("## Dominant kernel: `conv_block_kernel<3,8,32,2,4,1,2,8,true,true>` (conv1b, 64->64 3x3 @264x352 + ReLU + 2x2 max-pool, B=32)")
     A("")
     A(f"* algorithmic work per launch: {flop / 1e9:.1f} GFLOP (2 x 64 x 64 x 9 x 264 x 352 x 32); algorithmic bytes {pmc['algorithmic_bytes_per_launch'] / 1e6:.1f} MB.")
-    A(f"* `roofline` in the bench line (HIP events around {rf.get('launches_timed', 10)} back-to-back launches on the launch stream): {rf['launch_ms']:.3f} ms -> "
-      f"**{rf['achieved']:.1f} TFLOP/s = {rf['frac'] * 100:.1f} %** of the 157.3 TFLOP/s dense fp32-MFMA peak.")
+    A(f"* `roofline` in the bench line (mean of {rf.get('launches_timed', 10)} per-launch HIP-event pairs on the launch stream): {rf['launch_ms']:.3f} ms -> "
+      f"**{rf['achieved']:.1f} TFLOP/s = {rf['frac'] * 100:.1f} %** of the 157.3 TFLOP/s dense fp32-MFMA peak."
+      + (f"  Back to back (one event pair around all launches, launch i+1 fills the CUs while launch i drains): {rf['back_to_back_ms']:.3f} ms = "
+         f"{rf['back_to_back_TFLOPs']:.1f} TFLOP/s." if "back_to_back_ms" in rf else ""))
     if ko:
         A(f"* `{R}_conv1b_kernel_only_stats.csv` (`rocprofv3 --kernel-trace --stats -- python3 bench.py --kernel-only`, the same launches alone): "
           f"{ko[0]} launches, average {ko[1]:.3f} ms = {flop / ko[1] / 1e9:.1f} TFLOP/s.")

@@ -9,7 +9,7 @@ SRC=$ROOT/ei-nexus_official_amd/csrc
 OUT=/tmp/einx_var_$NAME
 mkdir -p "$OUT" "$ROOT/ab_libs"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall -Wno-unused-function $*"
-for f in common conv detect desc mnn lightglue events metrics; do
+for f in common conv detect desc mnn lightglue events metrics extract; do
   /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$OUT/$f.o" &
 done
 wait
