@@ -271,9 +271,14 @@ constexpr int KPITCH = 68;  // K rows padded to 68 floats: 16-byte aligned for d
 __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[AKB * KPITCH];
   __shared__ __attribute__((aligned(16))) float Vs[AKB * DH];
-  const int b = blockIdx.z, h = blockIdx.y;
+  // the query blocks of one (pair, head) read the same K / V: keep them on one XCD (see xcd_contiguous)
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+  int item = xcd_contiguous((int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z)), gx * gy * (int)gridDim.z);
+  const int qb = item % gx;
+  item /= gx;
+  const int h = item % gy, b = item / gy;
   const int nq = min(a.nq[b], a.capq), nk = min(a.nk[b], a.capk);
-  const int q0 = blockIdx.x * 128;
+  const int q0 = qb * 128;
   if (q0 >= nq || nk <= 0) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int q = q0 + wave * 32 + l31;

@@ -444,3 +444,19 @@ def test_forward_stream_equals_forward():
                 assert torch.equal(x, y), key
     ev, img, mask = batches[0]
     assert [len(list(model.forward_stream(iter([(ev, _t(img), mask)]), depth=d))) for d in (1, 3)] == [1, 1]
+
+
+def test_bench_one_rank_through_the_launcher_uses_rccl():
+    """`python bench.py --gpus 1 --spawn`: the launcher path of `--gpus N` with one rank on this box's one GPU --
+    a fresh rank process, init_process_group("nccl") = RCCL, the metric all-reduce, one JSON line from rank 0."""
+    import subprocess
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-extras", "--batch", "4"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl"]["world"] == 1 and d["rccl"]["backend"] == "nccl"
+    assert d["value"] > 0 and d["config"]["pairs_per_gpu_per_step"] == 4 and d["roofline"]["frac"] > 0
