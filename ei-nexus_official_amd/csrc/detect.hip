@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass_kernel(const float* src,
   __shared__ uint8_t ismax[MH * MW];
   __shared__ uint8_t rowor[MH * NMS_TW];
   __shared__ int changed;
-  int bid = blockIdx.x;
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);  // neighbouring tiles (shared halo) on one XCD
   const int txi = bid % tilesX;
   bid /= tilesX;
   const int tyi = bid % tilesY;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
   __shared__ uint8_t ismax8[MH * (G + 1)];
   __shared__ uint8_t rowor8[MH * TG];
   __shared__ int changed;
-  int bid = blockIdx.x;
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);  // neighbouring tiles (shared halo) on one XCD
   const int txi = bid % tilesX;
   bid /= tilesX;
   const int tyi = bid % tilesY;

@@ -46,9 +46,14 @@ struct MnnArgs {
 template <int MODE, bool LG = false>
 __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  const int b = blockIdx.z;
+  // XCD-contiguous order (einx_common.h): the column tiles of one row block, then the row blocks of one pair, share an L2
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+  int item = xcd_contiguous((int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z)), gx * gy * (int)gridDim.z);
+  const int jt = item % gx;
+  item /= gx;
+  const int it = item % gy, b = item / gy;
   const int n = min(a.n[b], a.cap0), m = min(a.m[b], a.cap1);
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int i0 = it * BM, j0 = jt * BN;
   if (i0 >= n || j0 >= m) return;
   Frag f;
   tile_nt(a.d0 + (size_t)b * a.cap0 * a.D, a.D, i0, n, a.d1 + (size_t)b * a.cap1 * a.D, a.D, j0, m, a.D, lds, f);
