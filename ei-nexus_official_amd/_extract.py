@@ -50,6 +50,7 @@ class BatchedFeats:
         self.coarse = None
         self.normalized = None
         self.scale = 1.0
+        self.shift = 0.0  # padding=0 networks: keypoints are mapped back by +9 (mapping_positions)
         self.ordering = "yx"
         self.dense = False
         self._prepared = None
@@ -91,7 +92,10 @@ class BatchedFeats:
             out["normalized_descriptors"] = nd
             C = nd.shape[1]
             out["dense_descriptors"] = [nd[b].permute(1, 2, 0).reshape(-1, C) for b in range(self.B)]
-            out["dense_positions"] = list(N.dense_positions(out["score"], self.ordering).unbind(0))
+            dp = N.dense_positions(out["score"], self.ordering)
+            if self.shift:
+                dp[:, :, :2] += self.shift
+            out["dense_positions"] = list(dp.unbind(0))
         # speculative per-image lists for the common case that every image fills its top-k quota
         # (checked against the real counts in materialize)
         self._full_lists = (self.det, list(self.sparse_desc.unbind(0)), list(self.det.positions.unbind(0)))
@@ -148,6 +152,7 @@ class ExtractorEngine:
         self._handle = None
         self._handle_key = None
         self._shapes = {}
+        self.valid_crop = 0  # 9: padding=0 networks (see run)
 
     # ------------------------------------------------------------------ handle-level C ABI (one call per forward)
     def __del__(self):
@@ -236,6 +241,8 @@ class ExtractorEngine:
             det.positions = det.positions[:, :cmax].contiguous()
             det.indices = det.indices[:, :cmax].contiguous()
             det.cap = cmax
+        if self.valid_crop:  # mapping_positions: both coordinates + 9 (the third column is the score); indices stay map-relative
+            det.positions[:, :, :2] += float(self.valid_crop)
         bf.det = det
         bf.sparse_desc = N.desc_sample(bf.raw, det.indices, det.counts, bf.padded, bilinear=(self.cell == 8), scale=bf.scale,
                                        raw_cl=bf.raw_cl)
@@ -275,10 +282,22 @@ class ExtractorEngine:
         pads = N.padder_pads(H, W, self.cell)
         w0, w1, h0, h1 = pads
         Hp, Wp = H + h0 + h1, W + w0 + w1
-        h = self.handle(scale, dilate_mask, input_div)
-        sh = self.shapes(h, H, W)
-        if sh.cap <= 8192 and self.use_handle:
-            return self._run_handle(h, sh, x, mask, pads, scale, dense, nms_iters or self.nms_iters)
+        crop = self.valid_crop
+        if crop:
+            # padding=0 (EventExtractors.py:319-329, silk_extractor.py:142-152): nine un-padded 3x3 layers.  An un-padded layer
+            # equals the padded one away from the border, so the padded network's maps cropped by 8 (backbone_feats) / 9
+            # (logits, raw_descriptors) ARE the un-padded network's maps, value for value; everything downstream runs on the
+            # (H-18) x (W-18) maps and the keypoints are shifted back by +9 (mapping_positions).
+            if mask is not None:
+                raise RuntimeError(f"The shape of the mask {list(mask.shape)} at index 0 does not match the shape of the indexed tensor "
+                                   f"[{B}, 1, {H - 2 * crop}, {W - 2 * crop}] at index 0")  # what `score[~score_mask] = 0` raises in the reference
+            if H <= 2 * crop + 8 or W <= 2 * crop + 8:
+                raise ValueError("image too small for nine un-padded 3x3 convolutions")
+        else:
+            h = self.handle(scale, dilate_mask, input_div)
+            sh = self.shapes(h, H, W)
+            if sh.cap <= 8192 and self.use_handle:
+                return self._run_handle(h, sh, x, mask, pads, scale, dense, nms_iters or self.nms_iters)
         if input_div:
             N.div_inplace(x, input_div)
         t = x
@@ -295,9 +314,15 @@ class ExtractorEngine:
         for layer in self.desc_head:
             d = layer(d)
         raw = d
+        if crop:
+            feats = feats[:, :, crop - 1:-(crop - 1), crop - 1:-(crop - 1)].contiguous()
+            logits = logits[:, :, crop:-crop, crop:-crop].contiguous()
+            raw = raw[:, :, crop:-crop, crop:-crop].contiguous()
+            Hp, Wp = Hp - 2 * crop, Wp - 2 * crop
         bf = BatchedFeats()
         bf.kind, bf.cell, bf.B = self.kind, self.cell, B
         bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
+        bf.shift = float(crop)
         bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
         # dense by-products first: they depend only on `raw`, so they run under the other stream's
         # convolutions instead of lengthening the latency-bound detection tail at the end of the step

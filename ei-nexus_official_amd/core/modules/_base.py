@@ -17,6 +17,7 @@ class NativeExtractor(nn.Module):
     uses_batchnorm = True
     dilate_mask = False
     input_div = 0.0  # SuperPointv1: the input tensor is divided by 255 IN PLACE inside the forward (reference quirk)
+    padding = 1      # 0: un-padded 3x3 convolutions (cell-1 networks; keypoints mapped back by +9)
 
     def _init_common(self, nms_radius, detection_top_k, detection_threshold, remove_borders, ordering, descriptor_scale_factor,
                      learnable_descriptor_scale_factor):
@@ -71,6 +72,7 @@ class NativeExtractor(nn.Module):
         if self._engine is None:
             eng = ExtractorEngine(self.kind, top_k=self.detection_top_k, radius=self.nms_radius, border=self.remove_borders,
                                   det_thr=self.detection_threshold, ordering=self.ordering, cell=self.cell_size)
+            eng.valid_crop = 9 if (getattr(self, "padding", 1) == 0 and self.cell_size == 1) else 0
             bb, det, desc = self._stacks()
             eng.backbone = [self._layer(b, p) for b, p in bb]
             eng.det_head = [self._layer(b) for b in det]

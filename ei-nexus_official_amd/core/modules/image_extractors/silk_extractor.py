@@ -67,8 +67,8 @@ class SiLKModel(NativeExtractor):
     def __init__(self, device, padding, nms_radius=4, detection_top_k=2048, detection_threshold=0.0005, remove_borders=4,
                  ordering="yx", descriptor_scale_factor=1.0, learnable_descriptor_scale_factor=False):
         super().__init__()
-        if padding != 1:
-            raise NotImplementedError("einx implements the shipped padding=1 configuration only")
+        if padding not in (0, 1):
+            raise AssertionError(padding)  # silk_extractor.py:147
         self.device = device
         self.padding = padding
         self._init_common(nms_radius, detection_top_k, detection_threshold, remove_borders, ordering, descriptor_scale_factor,

@@ -7,8 +7,11 @@ from .vgg import vgg_block
 class VGGBackBone(nn.Module):
     def __init__(self, in_channels=1, feat_channels=128, use_batchnorm=False, use_max_pooling=True, padding=1):
         super().__init__()
-        if padding != 1:
-            raise NotImplementedError("einx implements the shipped padding=1 configuration only")
+        if padding not in (0, 1):
+            raise AssertionError(padding)  # backbone.py:26
+        if padding == 0 and use_max_pooling:
+            raise NotImplementedError("einx: padding=0 is implemented for the un-pooled (cell 1) networks, where the reference maps "
+                                      "the keypoints back (+9); the pooled variant is not used by EI-Nexus")
         self.padding = padding
         self.use_max_pooling = use_max_pooling
         chans = [(in_channels, 64), (64, 64), (64, 128), (128, feat_channels)]

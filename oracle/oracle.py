@@ -302,10 +302,14 @@ def silk_net(sd, x, prefix="model."):
     return feats, logits, raw
 
 
-def extractor_forward(kind, sd, x, mask, *, top_k, radius=4, border=4, det_thr=1.0, ordering="yx", scale=1.0, dense=False):
+def extractor_forward(kind, sd, x, mask, *, top_k, radius=4, border=4, det_thr=1.0, ordering="yx", scale=1.0, dense=False, padding=1):
     """kind in {'vgg','vgg_np','superpointv1','silk'}.  x [B,C,H,W] fp32 (image: 0..255; modified
     in place for 'superpointv1' like the reference, superpoint_extractor.py:372).  Returns the
-    reference's output dict (numpy), positions as lists."""
+    reference's output dict (numpy), positions as lists.
+    padding=0 (cell-1 nets only: nine un-padded 3x3 convolutions, EventExtractors.py:319-329 / silk_extractor.py:142-152):
+    an un-padded 3x3 layer equals the padded one away from the border, so the interior of the padded network's maps
+    (8 pixels in for backbone_feats, 9 for logits / raw_descriptors) IS the un-padded network, value for value; the
+    detector runs on the (H-18)x(W-18) maps and the keypoints are shifted by +9 (mapping_positions)."""
     B, _, H, W = x.shape
     cell = 8 if kind in ("vgg", "superpointv1") else 1
     if kind == "superpointv1":
@@ -325,6 +329,15 @@ def extractor_forward(kind, sd, x, mask, *, top_k, radius=4, border=4, det_thr=1
         feats, logits, raw = silk_net(sd, xp)
     else:
         raise ValueError(kind)
+    if padding == 0:
+        if cell != 1:
+            raise NotImplementedError("padding=0 with pooling")
+        if mask is not None:
+            raise RuntimeError("The shape of the mask [%d, 1, %d, %d] at index 0 does not match the shape of the indexed tensor" % (B, H, W))
+        feats = np.ascontiguousarray(feats[:, :, 8:-8, 8:-8])
+        logits = np.ascontiguousarray(logits[:, :, 9:-9, 9:-9])
+        raw = np.ascontiguousarray(raw[:, :, 9:-9, 9:-9])
+        Hp, Wp = Hp - 18, Wp - 18
     prob, score = logits_to_score(logits)
     if mask is not None:
         mask_border(score, mask, pads, dilate=kind in ("vgg", "vgg_np"), border=0)
@@ -334,6 +347,10 @@ def extractor_forward(kind, sd, x, mask, *, top_k, radius=4, border=4, det_thr=1
     else:
         sparse = desc_gather(raw, idx, scale)
     w0, w1, h0, h1 = pads
+    if padding == 0:
+        for p_ in pos:
+            p_[:, 0] += np.float32(9.0)
+            p_[:, 1] += np.float32(9.0)
     out = {
         "image_size": [np.array([H, W], np.int64)] * B,
         "backbone_feats": feats, "logits": logits, "raw_descriptors": raw,

@@ -714,9 +714,71 @@ R2_REP_CASES = [
 ]
 
 
+R2_PAD0_CASES = [
+    dict(name="pad0", event_type="vgg_np", image_type="silk", ce=5, H=52, W=60, B=2, k=30, wseed=9, iseed=7),
+]
+
+
+def gen_r2_pad0(out):
+    """padding=0 (un-padded 3x3 convolutions, keypoints mapped back by +9): SiLKModel and VGGExtractorNP
+    (silk_extractor.py:142-152, EventExtractors.py:319-329); the event extractor is called without a mask (with one the
+    reference fails on the shape mismatch of `score[~score_mask] = 0`)."""
+    for c in R2_PAD0_CASES:
+        cfg = model_cfg(c["event_type"], c["image_type"], "MNN", c["ce"], c["k"])
+        cfg["event_extractor"]["vgg_np"]["padding"] = 0
+        cfg["image_extractor"]["silk"]["padding"] = 0
+        model, keys = build_eim(cfg, c["wseed"])
+        ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"], c["H"], c["W"])
+        img = synth.synth_image(c["iseed"], c["B"], c["H"], c["W"])
+        # As shipped, the reference cannot finish a padding=0 forward: filter_sparse_feats returns LISTS and
+        # mapping_positions only recurses into tuples, so `positions[..., 0]` raises TypeError (EventExtractors.py:326,
+        # silk_extractor.py:149).  Recorded here; the expected values below are the reference's own arithmetic with
+        # mapping_positions applied per list element (the evident intent: +9 on both coordinates).
+        raised = []
+        for ext, args in ((model.event_extractor, (torch.from_numpy(ev), None)), (model.image_extractor, (torch.from_numpy(img.copy()), None))):
+            try:
+                with torch.no_grad():
+                    ext(*args)
+                raised.append(0)
+            except TypeError as e:
+                raised.append(1)
+                print("unpatched reference raises:", str(e))
+        out[f"{c['name']}.reference_raises_typeerror"] = np.array(raised)
+        for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+            cls = type(ext)
+            if not getattr(cls, "_einx_list_fix", False):
+                orig = cls.mapping_positions
+
+                def mp(self, positions, _orig=orig):
+                    if isinstance(positions, list):
+                        return [_orig(self, p_) for p_ in positions]
+                    return _orig(self, positions)
+                cls.mapping_positions = mp
+                cls._einx_list_fix = True
+        with torch.no_grad():
+            ef = model.event_extractor(torch.from_numpy(ev), None)
+            imf = model.image_extractor(torch.from_numpy(img.copy()), None)
+        feats_summary(f"{c['name']}.ev", ef, out, full=True)
+        feats_summary(f"{c['name']}.im", imf, out, full=True)
+        out[f"{c['name']}.ev.dense_positions_probe"] = ef["dense_positions"][0][::97].numpy()
+        out[f"{c['name']}.im.dense_positions_probe"] = imf["dense_positions"][0][::97].numpy()
+        try:
+            with torch.no_grad():
+                model.event_extractor(torch.from_numpy(ev), torch.from_numpy(mask))
+            out[f"{c['name']}.mask_raises"] = np.array([0])
+        except (IndexError, RuntimeError) as e:
+            out[f"{c['name']}.mask_raises"] = np.array([1])
+            print("with a mask the reference raises:", str(e)[:80])
+        c["cfg"] = cfg
+        c["state_keys"] = keys
+        print(c["name"], out[f"{c['name']}.ev.counts"], out[f"{c['name']}.im.counts"], tuple(ef["score"].shape), tuple(ef["backbone_feats"].shape))
+
+
 def gen_r2():
     from core.metrics.keypoints_metrics import Repeatability
-    out = {"meta": meta(tie_cases=R2_TIE_CASES, mnn_cases=R2_MNN_CASES, rep_cases=R2_REP_CASES)}
+    out = {}
+    gen_r2_pad0(out)
+    out["meta"] = meta(tie_cases=R2_TIE_CASES, mnn_cases=R2_MNN_CASES, rep_cases=R2_REP_CASES, pad0_cases=R2_PAD0_CASES)
     for c in R2_TIE_CASES:
         score = torch.from_numpy(tie_map(c).copy())
         nms = ref_det.prob_map_to_points_map(score, prob_thresh=c["thr"], nms_dist=c["radius"], border_dist=c["border"],

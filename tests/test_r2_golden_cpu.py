@@ -103,3 +103,44 @@ def test_repeatability(oracle, name):
     got = oracle.pair_metrics(pad(p0), pad(p1), z0, z1, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), (260, 346), (260, 346),
                               c["hom"], mma_thr=(), vdd_thr=(1, 3), kp_yx=(c["ordering"] == "yx"))
     np.testing.assert_allclose(np.asarray(got)[[1, 4]], Z[f"{name}.values"], atol=1e-7, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ padding=0 networks (cell 1)
+PAD0 = {c["name"]: c for c in META["pad0_cases"]}
+
+
+class _G:
+    """npz with the `in` / [] protocol test_oracle_golden._check_feats expects"""
+
+    def __getitem__(self, k):
+        return Z[k]
+
+    def __contains__(self, k):
+        return k in Z.files
+
+
+def pad0_inputs(c):
+    from helpers import synth
+    ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"], c["H"], c["W"])
+    img = synth.synth_image(c["iseed"], c["B"], c["H"], c["W"])
+    return ev, mask, img
+
+
+@pytest.mark.parametrize("name", list(PAD0))
+def test_padding0_networks(oracle, name):
+    """padding=0 (nine un-padded 3x3 convolutions, keypoints mapped back by +9).  As shipped the reference raises
+    TypeError on this path (mapping_positions does not recurse into the lists filter_sparse_feats returns; recorded in the
+    fixture); the expected values are its own arithmetic with the +9 applied per list element."""
+    from helpers import state_dict_for, sub_dict
+    from test_oracle_golden import _check_feats
+    c = PAD0[name]
+    assert Z[f"{name}.reference_raises_typeerror"].tolist() == [1, 1] and int(Z[f"{name}.mask_raises"][0]) == 1
+    sd = state_dict_for(c)
+    ev, mask, img = pad0_inputs(c)
+    oe = oracle.extractor_forward("vgg_np", sub_dict(sd, "event_extractor.extractor."), ev.copy(), None, top_k=c["k"], scale=1.41, padding=0)
+    oi = oracle.extractor_forward("silk", sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=c["k"], scale=1.41, padding=0)
+    assert oe["score"].shape == (c["B"], 1, c["H"] - 18, c["W"] - 18) and oe["backbone_feats"].shape[-2:] == (c["H"] - 16, c["W"] - 16)
+    _check_feats(f"{name}.ev", oe, _G())
+    _check_feats(f"{name}.im", oi, _G())
+    with pytest.raises(RuntimeError, match="shape of the mask"):
+        oracle.extractor_forward("vgg_np", sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=c["k"], padding=0)

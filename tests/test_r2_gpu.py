@@ -460,3 +460,51 @@ def test_bench_one_rank_through_the_launcher_uses_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["rccl"]["world"] == 1 and d["rccl"]["backend"] == "nccl"
     assert d["value"] > 0 and d["config"]["pairs_per_gpu_per_step"] == 4 and d["roofline"]["frac"] > 0
+
+
+# ------------------------------------------------------------------ padding=0 networks (cell 1)
+PAD0 = {c["name"]: c for c in _META["pad0_cases"]}
+
+
+@pytest.mark.parametrize("name", list(PAD0))
+def test_padding0_networks_vs_oracle_and_reference(oracle, name):
+    """SiLKModel(padding=0) / VGGExtractorNP(padding=0): un-padded convolutions + `mapping_positions` (+9)
+    (silk_extractor.py:142-152, EventExtractors.py:319-329): bit-equal to the oracle, 1e-4 to the reference's arithmetic."""
+    from helpers import state_dict_for
+    from test_oracle_golden import _check_feats
+    from test_r2_golden_cpu import _G
+    c = PAD0[name]
+    cfg = pkg.configs.to_attr(c["cfg"])
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = state_dict_for(c)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"], c["H"], c["W"])
+    img = synth.synth_image(c["iseed"], c["B"], c["H"], c["W"])
+    ef = model.event_extractor(_t(ev), None)
+    img_t = _t(img)
+    imf = model.image_extractor(img_t)
+    assert np.array_equal(_np(img_t), img)  # SiLK leaves the caller's image untouched
+    oe = oracle.extractor_forward("vgg_np", sub_dict(sd, "event_extractor.extractor."), ev.copy(), None, top_k=c["k"], scale=1.41,
+                                  padding=0, dense=True)
+    oi = oracle.extractor_forward("silk", sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=c["k"], scale=1.41,
+                                  padding=0, dense=True)
+    for got, exp in ((ef, oe), (imf, oi)):
+        for k in ("backbone_feats", "logits", "raw_descriptors", "probability", "score", "nms", "normalized_descriptors"):
+            assert np.array_equal(_np(got[k]), exp[k]), k
+        for b in range(c["B"]):
+            assert np.array_equal(_np(got["sparse_positions"][b]), exp["sparse_positions"][b])
+            assert np.array_equal(_np(got["sparse_descriptors"][b]), exp["sparse_descriptors"][b])
+        assert tuple(got["score"].shape) == (c["B"], 1, c["H"] - 18, c["W"] - 18)
+        assert [tuple(_np(s)) for s in got["image_size"]] == [(c["H"], c["W"])] * c["B"]
+    as_np = lambda f: {k: (_np(v) if torch.is_tensor(v) else [_np(t) for t in v]) for k, v in f.items()}  # noqa: E731
+    _check_feats(f"{name}.ev", as_np(ef), _G())
+    _check_feats(f"{name}.im", as_np(imf), _G())
+    np.testing.assert_allclose(_np(ef["dense_positions"][0])[::97], _Z[f"{name}.ev.dense_positions_probe"], atol=1e-6)
+    np.testing.assert_allclose(_np(imf["dense_positions"][0])[::97], _Z[f"{name}.im.dense_positions_probe"], atol=1e-6)
+    assert float(ef["sparse_positions"][0][:, :2].min()) >= 9.0 + 4.0  # +9 mapping on top of the 4-pixel border
+    with pytest.raises(RuntimeError, match="shape of the mask"):
+        model.event_extractor(_t(ev), _t(mask))
+    # the matcher consumes the mapped keypoints like any others
+    m = model.matcher(ef, imf)
+    exp = oracle.mnn(oe["sparse_descriptors"][0], oi["sparse_descriptors"][0], want_la=False)
+    assert np.array_equal(_np(m["matches0"][0])[0], exp["matches0"])
