@@ -362,8 +362,8 @@ def dominant_kernel_roofline(wl, value_per_gpu, kernel_only=False):
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         traffic_src = (f"replayed from profiles/{os.path.basename(pmc)} (FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over this "
                        "kernel, tools/collect_profiles.sh; PMC counters cannot be read from inside this process, so this run did not re-measure them)")
-    tile = "8,32,2,4,1,2,8"
-    kname = f"conv_block_kernel<3,{tile},{'true' if l1.pool else 'false'},true> ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"
+    l1(x1)
+    kname = pkg.native.lib().einx_conv_last_kernel().decode() + f" ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"  # what the dispatcher launched
     return {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": round(dur * 1e3, 4), "launches_timed": reps, "flop_per_launch": flops,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "einx_extract_shapes": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(ExtractShapes)]),
     "einx_extract_ws_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "einx_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(ExtractOut), c_void_p]),
+    "einx_conv_last_kernel": (c_char_p, []),
     "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "einx_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

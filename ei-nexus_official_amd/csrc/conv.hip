@@ -16,6 +16,7 @@
 // net/detector_head.py:42-48, net/descriptor_head.py:40-43,
 // image_extractors/superpoint_extractor.py:388-406, silk/backbones/superpoint/vgg.py:284-290,
 // utils/util.py:17-32 (replicate pad folded into the first layer's addressing).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "einx_common.h"
@@ -380,6 +381,8 @@ int conv_exp() {
   return v;
 }
 
+thread_local const char* g_last_conv_kernel = "";
+
 struct TileCfg {
   int th, tw, slots;  // slots = pixel slots a workgroup launches for this tile
 };
@@ -390,6 +393,15 @@ void launch(const ConvArgs& a, int B, hipStream_t s) {
   // 3x3 tile except 11x22, whose 768-workgroup launches on the 256-channel heads ran 20 % slower with it
   const bool exact = (a.Cin % CK) == 0 && KS == 3 && (!(TH == 11 && TW == 22) || ((conv_exp() & 8) && a.Cin <= 64));
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
+  {
+    // name of the instantiation this call launches (einx_conv_last_kernel: measurement provenance)
+    static char names[2][96] = {{0}, {0}};
+    char* nm = names[exact ? 1 : 0];
+    if (!nm[0])
+      snprintf(nm, sizeof(names[0]), "conv_block_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%s,%s>", KS, TH, TW, WM, WN, MT, NT, CK, POOL ? "true" : "false",
+               exact ? "true" : "false");
+    g_last_conv_kernel = nm;
+  }
   EINX_PROF(KS == 1 ? "conv_block_kernel 1x1" : (CK < 8 ? "conv_block_kernel 3x3 first layer" : "conv_block_kernel 3x3"), s);
   if (exact) hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, true>), grid, dim3(WM * WN * 64), 0, s, a);
   else hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, false>), grid, dim3(WM * WN * 64), 0, s, a);
@@ -402,6 +414,8 @@ double tile_waste(int H, int W, const TileCfg& c) {
 }
 
 }  // namespace
+
+EINX_EXPORT const char* einx_conv_last_kernel(void) { return g_last_conv_kernel; }
 
 EINX_EXPORT size_t einx_conv_weight_elems(int cin, int cout, int ks) {
   const int taps = ks * ks;

@@ -78,6 +78,11 @@ typedef struct einx_conv_desc {
 int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d, float* out,
                     void* stream);
 
+/* name of the kernel instantiation the calling thread's last einx_conv_block launched, e.g.
+ * "conv_block_kernel<3,8,32,2,4,1,2,8,true,true>" (tile shape, wave layout, chunk, pool, reload path): provenance for
+ * profiles and bench lines, so that a reported kernel name cannot go stale against the dispatcher */
+const char* einx_conv_last_kernel(void);
+
 /* x /= divisor in place (SuperPointv1.forward `image /= 255.0`, superpoint_extractor.py:372) */
 int einx_div_inplace(float* x, size_t n, float divisor, void* stream);
 
