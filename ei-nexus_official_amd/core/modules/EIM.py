@@ -128,8 +128,10 @@ class EIM(nn.Module):
                 nm_host = mr.nmatch.cpu()
                 nm_event = None
         if retries == 0:
-            self.event_extractor.extractor.engine().note_converged()
-            self.image_extractor.extractor.engine().note_converged()
+            for wrapper in (self.event_extractor, self.image_extractor):
+                eng = getattr(wrapper.extractor, "_engine", None)
+                if eng is not None:
+                    eng.note_converged()
         n, m = host[0].tolist(), host[1].tolist()
         events_feats = ev.materialize(n)
         image_feats = im.materialize(m)

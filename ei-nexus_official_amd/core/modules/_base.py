@@ -34,27 +34,33 @@ class NativeExtractor(nn.Module):
         self._engine = None
         self._scale_host = None
         self._sig = None
+        self._sig_tensors = None
         # runs for THIS module also when a parent's load_state_dict recurses into it (EIM, the
         # Extractor wrappers, ImageImageMatcher), which never calls the child's own load_state_dict
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh())
 
     # -- cache invalidation: anything that moves or replaces parameters drops the native images
     def _apply(self, fn, *a, **k):
-        self._engine = self._scale_host = None
+        self._engine = self._scale_host = self._sig_tensors = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._engine = self._scale_host = None
+        self._engine = self._scale_host = self._sig_tensors = None
         return super().load_state_dict(*a, **k)
 
     def _signature(self):
         """(storage, version) of every parameter and buffer: in-place edits (`p.data.copy_`, optimiser
-        steps, `load_state_dict`) bump `_version`, `.to()` / re-assignment change the storage."""
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        steps, `load_state_dict`) bump `_version`, `.to()` changes the storage.  The flat tensor list is cached (walking the
+        module tree costs 50-450 us per call); `_apply`, `load_state_dict` and `refresh()` drop it -- call `refresh()` after
+        REPLACING a Parameter object."""
+        ts = self._sig_tensors
+        if ts is None:
+            ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
 
     def refresh(self):
-        """Call after editing parameters in place (weights or descriptor_scale_factor)."""
-        self._engine = self._scale_host = None
+        """Call after editing parameters in place (weights or descriptor_scale_factor) or replacing Parameter objects."""
+        self._engine = self._scale_host = self._sig_tensors = None
 
     def _layer(self, block, pool=False):
         conv, bn, relu, pool = block_spec(block, pool)

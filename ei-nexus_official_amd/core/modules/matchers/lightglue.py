@@ -114,23 +114,26 @@ class LightGlue(nn.Module):
         self.fold_message_projection = True  # inference-time weight folding (see _pack); False = layer by layer as written
         self._packed = None
         self._sig = None
+        self._sig_tensors = None
         # also reached when a parent module's load_state_dict recurses into this one
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh())
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self._packed = self._sig_tensors = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._packed = None
+        self._packed = self._sig_tensors = None
         return super().load_state_dict(*a, **k)
 
     def refresh(self):
-        self._packed = None
+        self._packed = self._sig_tensors = None
 
     def _pack(self):
         """ctypes image of the parameter pointers (weights stay in their nn.Parameter storage)."""
-        sig = tuple((t.data_ptr(), t._version) for t in self.parameters())
+        if self._sig_tensors is None:
+            self._sig_tensors = list(self.parameters())
+        sig = tuple((t.data_ptr(), t._version) for t in self._sig_tensors)
         if sig != self._sig:  # in-place parameter edits and moves drop the folded weight images too
             self._packed, self._sig = None, sig
         if self._packed is not None:
