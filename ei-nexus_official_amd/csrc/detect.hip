@@ -257,29 +257,25 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass_kernel(const float* src,
 //   ismax = v > 0 && inside && max(left 4) < v && max(right 4) <= v && max(4 rows above of R9) < v
 //           && max(4 rows below of R9) <= v;   suppressed = (some ismax in the 9x9 window) && !ismax
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
-                                                                int32_t* flags, int it, int nIt) {
-  constexpr int R = 4;
-  constexpr int VH = NMS_TH + 4 * R, VW = NMS_TW + 4 * R;  // 48 x 80 values: tile + halo 2R
-  constexpr int MH = NMS_TH + 2 * R, MW = NMS_TW + 2 * R;  // 40 x 72 is-max grid: tile + halo R
-  constexpr int G = MW / 8, TG = NMS_TW / 8;               // 9 column groups of the is-max grid, 8 of the tile
-  __shared__ __attribute__((aligned(16))) float vals[VH * VW];
-  __shared__ __attribute__((aligned(16))) float r9[VH * MW];
-  __shared__ uint8_t rowok8[VH * G];   // bit k of [vy][g]: centre > 0 and row-wise conditions hold at column g*8+k
-  __shared__ uint8_t ismax8[MH * (G + 1)];
-  __shared__ uint8_t rowor8[MH * TG];
-  __shared__ int changed;
-  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);  // neighbouring tiles (shared halo) on one XCD
-  const int txi = bid % tilesX;
-  bid /= tilesX;
-  const int tyi = bid % tilesY;
-  const int b = bid / tilesY;
-  if (it >= 2 && flags[b * nIt + it - 1] == 0) return;
-  const float* s = src + (size_t)b * Hp * Wp;
-  float* d = dst + (size_t)b * Hp * Wp;
-  const int y0 = tyi * NMS_TH, x0 = txi * NMS_TW;
+struct __attribute__((aligned(16))) Nms4Smem {
+  static constexpr int R = 4;
+  static constexpr int VH = NMS_TH + 4 * R, VW = NMS_TW + 4 * R;  // 48 x 80 values: tile + halo 2R
+  static constexpr int MH = NMS_TH + 2 * R, MW = NMS_TW + 2 * R;  // 40 x 72 is-max grid: tile + halo R
+  static constexpr int G = MW / 8, TG = NMS_TW / 8;               // 9 column groups of the is-max grid, 8 of the tile
+  float vals[VH * VW];
+  float r9[VH * MW];
+  uint8_t rowok8[VH * G];  // bit k of [vy][g]: centre > 0 and row-wise conditions hold at column g*8+k
+  uint8_t ismax8[MH * (G + 1)];
+  uint8_t rowor8[MH * TG];
+  int changed;
+};
+
+// one tile of one pass: s -> d for the 32x64 tile at (y0, x0); raises sm.changed if it zeroes a non-zero pixel.  The caller
+// clears sm.changed beforehand (followed by a barrier) and synchronises before reading it.
+template <bool COHERENT>
+__device__ __forceinline__ void nms4_tile(Nms4Smem& sm, const float* s, float* d, int Hp, int Wp, int y0, int x0) {
+  constexpr int R = Nms4Smem::R, VH = Nms4Smem::VH, VW = Nms4Smem::VW, MH = Nms4Smem::MH, MW = Nms4Smem::MW, G = Nms4Smem::G, TG = Nms4Smem::TG;
   const int tid = threadIdx.x;
-  if (tid == 0) changed = 0;
   constexpr int NLOAD = (VH * VW + NMS_THREADS - 1) / NMS_THREADS;
   float staged[NLOAD];
 #pragma unroll
@@ -288,20 +284,22 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
     const int ii = i < VH * VW ? i : 0;
     const int y = y0 - 2 * R + ii / VW, x = x0 - 2 * R + ii % VW;
     const bool in = y >= 0 && y < Hp && x >= 0 && x < Wp;
-    const float v = s[(size_t)(in ? y : 0) * Wp + (in ? x : 0)];
+    const float* src_p = s + (size_t)(in ? y : 0) * Wp + (in ? x : 0);
+    // COHERENT: the previous pass of the SAME launch wrote these values (finisher): read them from L2, never from a stale L1 line
+    const float v = COHERENT ? __hip_atomic_load(const_cast<float*>(src_p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src_p;
     staged[k] = in ? v : 0.0f;
   }
 #pragma unroll
   for (int k = 0; k < NLOAD; ++k) {
     const int i = tid + k * NMS_THREADS;
-    if (i < VH * VW) vals[i] = staged[k];
+    if (i < VH * VW) sm.vals[i] = staged[k];
   }
   __syncthreads();
   // A: per row and column group: R9 (9-wide row maximum) and the row-wise part of the is-max test
   if (tid < VH * G) {
     const int vy = tid / G, g = tid % G;
     float v[16];
-    const float* row = vals + vy * VW + g * 8;
+    const float* row = sm.vals + vy * VW + g * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q);
@@ -324,10 +322,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
       m9[k] = fmaxf(fmaxf(left, right), c);
       ok |= (c > 0.0f && left < c && right <= c) ? (1u << k) : 0u;
     }
-    float* o = r9 + vy * MW + g * 8;
+    float* o = sm.r9 + vy * MW + g * 8;
     *reinterpret_cast<f32x4*>(o) = f32x4{m9[0], m9[1], m9[2], m9[3]};
     *reinterpret_cast<f32x4*>(o + 4) = f32x4{m9[4], m9[5], m9[6], m9[7]};
-    rowok8[tid] = (uint8_t)ok;
+    sm.rowok8[tid] = (uint8_t)ok;
   }
   __syncthreads();
   // B: column-wise part on the is-max grid (rows my = 0..39 <-> vy = my + 4)
@@ -339,8 +337,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
     for (int k = 0; k < 8; ++k) above[k] = below[k] = 0.0f;
 #pragma unroll
     for (int dy = 1; dy <= R; ++dy) {
-      const float* ra = r9 + (vy - dy) * MW + g * 8;
-      const float* rb = r9 + (vy + dy) * MW + g * 8;
+      const float* ra = sm.r9 + (vy - dy) * MW + g * 8;
+      const float* rb = sm.r9 + (vy + dy) * MW + g * 8;
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(ra), a1 = *reinterpret_cast<const f32x4*>(ra + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(rb), b1 = *reinterpret_cast<const f32x4*>(rb + 4);
 #pragma unroll
@@ -351,9 +349,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
         below[k + 4] = dy == 1 ? b1[k] : fmaxf(below[k + 4], b1[k]);
       }
     }
-    const float* crow = vals + vy * VW + g * 8 + R;
+    const float* crow = sm.vals + vy * VW + g * 8 + R;
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow), c1 = *reinterpret_cast<const f32x4*>(crow + 4);
-    const unsigned rok = rowok8[vy * G + g];
+    const unsigned rok = sm.rowok8[vy * G + g];
     const int y = y0 - R + my;
     unsigned bits = 0;
 #pragma unroll
@@ -363,19 +361,19 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
       const bool okk = ((rok >> k) & 1u) && y >= 0 && y < Hp && x >= 0 && x < Wp && above[k] < c && below[k] <= c;
       bits |= okk ? (1u << k) : 0u;
     }
-    ismax8[my * (G + 1) + g] = (uint8_t)bits;
-    if (g == 0) ismax8[my * (G + 1) + G] = 0;  // pad byte read by the last tile group
+    sm.ismax8[my * (G + 1) + g] = (uint8_t)bits;
+    if (g == 0) sm.ismax8[my * (G + 1) + G] = 0;  // pad byte read by the last tile group
   }
   __syncthreads();
   // C: row-wise OR over the 9-wide window, for the tile's 64 columns (bit k of group t8: is-max columns t8*8+k .. +8)
   if (tid < MH * TG) {
     const int my = tid / TG, t8 = tid % TG;
-    const unsigned w = (unsigned)ismax8[my * (G + 1) + t8] | ((unsigned)ismax8[my * (G + 1) + t8 + 1] << 8) |
-                       ((unsigned)ismax8[my * (G + 1) + t8 + 2] << 16);
+    const unsigned w = (unsigned)sm.ismax8[my * (G + 1) + t8] | ((unsigned)sm.ismax8[my * (G + 1) + t8 + 1] << 8) |
+                       ((unsigned)sm.ismax8[my * (G + 1) + t8 + 2] << 16);
     unsigned r = 0;
 #pragma unroll
     for (int dx = 0; dx <= 2 * R; ++dx) r |= w >> dx;
-    rowor8[tid] = (uint8_t)(r & 0xFFu);
+    sm.rowor8[tid] = (uint8_t)(r & 0xFFu);
   }
   __syncthreads();
   // D: column-wise OR and suppression for 8 pixels of one tile row
@@ -384,12 +382,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
     const int ty = tid / TG, t8 = tid % TG;
     unsigned o8 = 0;
 #pragma unroll
-    for (int dy = 0; dy <= 2 * R; ++dy) o8 |= rowor8[(ty + dy) * TG + t8];
+    for (int dy = 0; dy <= 2 * R; ++dy) o8 |= sm.rowor8[(ty + dy) * TG + t8];
     // is-max bits of the pixels themselves: grid row ty+R, columns t8*8 + k + R
-    const unsigned iw = (unsigned)ismax8[(ty + R) * (G + 1) + t8] | ((unsigned)ismax8[(ty + R) * (G + 1) + t8 + 1] << 8);
+    const unsigned iw = (unsigned)sm.ismax8[(ty + R) * (G + 1) + t8] | ((unsigned)sm.ismax8[(ty + R) * (G + 1) + t8 + 1] << 8);
     const unsigned is8 = (iw >> R) & 0xFFu;
     const unsigned sup = o8 & ~is8;
-    const float* crow = vals + (ty + 2 * R) * VW + t8 * 8 + 2 * R;
+    const float* crow = sm.vals + (ty + 2 * R) * VW + t8 * 8 + 2 * R;
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow), c1 = *reinterpret_cast<const f32x4*>(crow + 4);
     const int y = y0 + ty;
     if (y < Hp) {
@@ -412,9 +410,92 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
       }
     }
   }
-  if (my_changed) changed = 1;
+  if (my_changed) sm.changed = 1;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,
+                                                                int32_t* flags, int it, int nIt) {
+  __shared__ Nms4Smem sm;
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);  // neighbouring tiles (shared halo) on one XCD
+  const int txi = bid % tilesX;
+  bid /= tilesX;
+  const int tyi = bid % tilesY;
+  const int b = bid / tilesY;
+  if (it >= 2 && flags[b * nIt + it - 1] == 0) return;
+  if (threadIdx.x == 0) sm.changed = 0;  // ordered before the tile's writes by the barriers inside nms4_tile
+  nms4_tile<false>(sm, src + (size_t)b * Hp * Wp, dst + (size_t)b * Hp * Wp, Hp, Wp, tyi * NMS_TH, txi * NMS_TW);
   __syncthreads();
-  if (tid == 0 && changed) atomicOr(&flags[b * nIt + it], 1);
+  if (threadIdx.x == 0 && sm.changed) atomicOr(&flags[b * nIt + it], 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Finisher: images whose fix-point needs more passes than the enqueued wide ones (tie-heavy maps: 14-17 passes on
+// quantised scores) are completed HERE, on the device, by one workgroup per such image that keeps ping-ponging between
+// the two map buffers until a pass changes nothing -- no host round trip, no sticky pass budget.  Converged images
+// (the normal case) cost one flag load.  A tile is revisited only while it or one of its 8 neighbours changed in the
+// previous pass: an untouched tile is already identical in both buffers (its last change is at least two passes old),
+// so later passes touch only the few contested tiles.  Loads of map values bypass L1 (the same CU wrote them a pass
+// earlier in this launch); stores are complete (vmcnt(0) + barrier) before the next pass reads them.
+// ------------------------------------------------------------------------------------------
+constexpr int NMS_FIN_MAXT = 2048;  // tiles tracked individually; larger maps revisit every tile
+__global__ __launch_bounds__(NMS_THREADS) void nms4_finish_kernel(float* bufA, float* bufB, int Hp, int Wp, int tilesX, int tilesY,
+                                                                  int32_t* flags, int nIt, int max_passes) {
+  __shared__ Nms4Smem sm;
+  __shared__ uint8_t dirty[2][NMS_FIN_MAXT];
+  __shared__ int any_changed;
+  const int b = blockIdx.x;
+  if (flags[b * nIt + nIt - 1] == 0) return;  // fix-point reached within the wide passes
+  const int tid = threadIdx.x;
+  const int ntiles = tilesX * tilesY;
+  const bool track = ntiles <= NMS_FIN_MAXT;
+  float* src = bufA + (size_t)b * Hp * Wp;  // the last wide pass wrote bufA
+  float* dst = bufB + (size_t)b * Hp * Wp;
+  if (track)
+    for (int i = tid; i < ntiles; i += NMS_THREADS) {
+      dirty[0][i] = 1;
+      dirty[1][i] = 0;
+    }
+  __syncthreads();
+  int cur = 0;
+  int left = 1;
+  for (int pass = 0; pass < max_passes; ++pass) {
+    if (tid == 0) any_changed = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const int txi = t % tilesX, tyi = t / tilesX;
+      bool need = !track;
+      if (track) {
+        for (int dy = -1; dy <= 1 && !need; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = tyi + dy, xx = txi + dx;
+            if (yy >= 0 && yy < tilesY && xx >= 0 && xx < tilesX && dirty[cur][yy * tilesX + xx]) need = true;
+          }
+      }
+      if (!need) continue;  // workgroup-uniform: every thread reads the same LDS bytes
+      if (tid == 0) sm.changed = 0;
+      __syncthreads();
+      nms4_tile<true>(sm, src, dst, Hp, Wp, tyi * NMS_TH, txi * NMS_TW);
+      __syncthreads();
+      if (tid == 0 && sm.changed) {
+        any_changed = 1;
+        if (track) dirty[cur ^ 1][t] = 1;
+      }
+      __syncthreads();
+    }
+    // this pass's stores have reached L2 before any thread starts the next pass
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    left = any_changed;
+    if (track)
+      for (int i = tid; i < ntiles; i += NMS_THREADS) dirty[cur][i] = 0;
+    cur ^= 1;
+    float* tmp = src;
+    src = dst;
+    dst = tmp;
+    __syncthreads();
+    if (!left) break;
+  }
+  // a pass that changes nothing leaves both buffers holding the fix-point, so whichever one the selection kernel reads is final
+  if (tid == 0) flags[b * nIt + nIt - 1] = left ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -884,6 +965,16 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
       }
       EINX_CHECK_LAUNCH();
       cur = dst;
+    }
+    if (p->radius == 4) {
+      // images that are still changing after the wide passes are finished on the device (see nms4_finish_kernel); for the
+      // other radii the caller re-runs with a larger budget when not_converged is raised
+      float* last = const_cast<float*>(cur);
+      float* other = last == buf0 ? buf1 : buf0;
+      EINX_PROF("nms4_finish_kernel", s);
+      hipLaunchKernelGGL(nms4_finish_kernel, dim3((unsigned)p->B), dim3(NMS_THREADS), 0, s, last, other, p->Hp, p->Wp, tilesX, tilesY, flags, nIt,
+                         1 << 20);
+      EINX_CHECK_LAUNCH();
     }
   }
   SelArgs a;
