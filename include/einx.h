@@ -130,8 +130,10 @@ size_t einx_detect_ws_bytes(const einx_detect_params* p);
  * indices   [B,cap]    int32 flat index y*Wp+x in the padded map
  * counts    [B]        int32 number of keypoints (may exceed cap: only cap rows are written)
  * thr       [B]        threshold used
- * not_converged [B]    int32, nonzero if the fix-point needed more than nms_iters passes
- *                      (caller re-runs with more passes; never observed above 4 at 264x352) */
+ * not_converged [B]    int32, nonzero if the fix-point needed more than nms_iters passes (caller re-runs with more
+ *                      passes).  Radius 4 (every shipped configuration) never raises it: images that are still changing
+ *                      after the nms_iters wide passes are completed on the device by a per-image finisher
+ *                      (nms4_finish_kernel), e.g. quantised maps that need 14-25 passes */
 int einx_detect(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
                 int32_t* counts, float* thr, int32_t* not_converged, void* stream);
 
