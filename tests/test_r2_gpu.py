@@ -508,3 +508,17 @@ def test_padding0_networks_vs_oracle_and_reference(oracle, name):
     m = model.matcher(ef, imf)
     exp = oracle.mnn(oe["sparse_descriptors"][0], oi["sparse_descriptors"][0], want_la=False)
     assert np.array_equal(_np(m["matches0"][0])[0], exp["matches0"])
+
+
+def test_torch_free_c_abi_host():
+    """examples/c_abi_host: a C++/HIP program that links libeinx_hip.so and runs two extractors + MNN with hipMalloc'ed
+    buffers only (no Python, no torch below or above the boundary)."""
+    import subprocess
+    from helpers import ROOT
+    exe = os.path.join(ROOT, "examples", "c_abi_host")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "C ABI host: OK" in r.stdout
+    assert r.stdout.count("event keypoints") == 3
