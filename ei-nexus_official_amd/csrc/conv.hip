@@ -515,6 +515,53 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   // an 8-wave 11x22 tile beats the 4-wave 192-slot tiles even at ~6 % more pixel slots (132x176: 3072 workgroups
   // = six full rounds of two per CU; measured +3 % on that layer)
   if (!d->pool && (best == 1 || best == 2) && tile_waste(H, W, cfgs[3]) <= bw * 1.06 + 1e-9) best = 3;
+  {
+    // Small grids (single images: the reference's own call pattern): the launch does not fill the chip, so what counts is the
+    // LATENCY of one workgroup = (waves it puts on a SIMD) x (accumulator tiles per wave) x K-steps x 64 cycles -- the k-ordered
+    // accumulation forbids splitting K -- times the rounds the grid needs on 256 CUs.  Finer tiles with one single-tile wave
+    // per SIMD cut it up to 4x; bit-identical results (same kernel, other template arguments).  Thin first layers stay on the
+    // generic path (they are store-bound).
+    const long blocks_best = (long)einx_cdiv(H, cfgs[best].th) * einx_cdiv(W, cfgs[best].tw) * B * (a.CoutPad / kCoutTile);
+    if (blocks_best < 512 && d->cin > 6 && !(conv_exp() & 32)) {
+      struct Lat {
+        int th, tw, unit;  // unit = waves per SIMD x accumulator tiles per wave
+      };
+      static const Lat pooled[4] = {{8, 32, 4}, {12, 16, 3}, {8, 16, 2}, {4, 16, 1}};
+      static const Lat plain[5] = {{8, 32, 4}, {11, 22, 4}, {12, 16, 3}, {11, 11, 2}, {11, 5, 1}};
+      const Lat* cand = d->pool ? pooled : plain;
+      const int nc = d->pool ? 4 : 5;
+      int pick = -1;
+      double best_est = 1e30;
+      for (int i = 0; i < nc; ++i) {
+        const long blocks = (long)einx_cdiv(H, cand[i].th) * einx_cdiv(W, cand[i].tw) * B * (a.CoutPad / kCoutTile);
+        const double est = (double)((blocks + 255) / 256) * cand[i].unit;
+        if (est < best_est - 1e-9) {
+          best_est = est;
+          pick = i;
+        }
+      }
+      a.tilesX = einx_cdiv(W, cand[pick].tw);
+      a.tilesY = einx_cdiv(H, cand[pick].th);
+      if (d->pool) {
+        switch (pick) {
+          case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s); break;
+          case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
+          case 2: launch<3, 8, 16, 2, 2, 1, 2, 8, true>(a, B, s); break;
+          default: launch<3, 4, 16, 2, 2, 1, 1, 8, true>(a, B, s); break;
+        }
+      } else {
+        switch (pick) {
+          case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, false>(a, B, s); break;
+          case 1: launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s); break;
+          case 2: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
+          case 3: launch<3, 11, 11, 2, 2, 1, 2, 8, false>(a, B, s); break;
+          default: launch<3, 11, 5, 2, 2, 1, 1, 8, false>(a, B, s); break;
+        }
+      }
+      EINX_CHECK_LAUNCH();
+      return EINX_OK;
+    }
+  }
   a.tilesX = einx_cdiv(W, cfgs[best].tw);
   a.tilesY = einx_cdiv(H, cfgs[best].th);
   // Wave layouts (measured per layer, bench.py --layer-table): 8 waves (2 channel groups x 4 pixel
