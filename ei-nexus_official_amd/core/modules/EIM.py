@@ -36,11 +36,16 @@ class EIM(nn.Module):
 
     overlap_extractors = os.environ.get("EINX_OVERLAP", "1") != "0"  # two (independent) extractors on two HIP streams
 
+    _side_streams = {}  # one side stream per device for the whole process
+
     def _side_stream(self, device):
-        st = getattr(self, "_einx_side_stream", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device, priority=int(os.environ.get("EINX_SIDE_PRIO", "0")))
-            self._einx_side_stream = st
+        """HIP maps streams onto a small pool of hardware queues in creation order: a side stream per model instance means that
+        the third or fourth model of a process gets one that shares a queue with the main stream, and its two extractors
+        serialise (measured in bench.py's extra legs: B=1 1.23 ms instead of 0.92).  So all instances share one."""
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        st = EIM._side_streams.get(key)
+        if st is None:
+            st = EIM._side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("EINX_SIDE_PRIO", "0")))
         return st
 
     def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False, before_match=None):
