@@ -39,6 +39,34 @@ struct ConvArgs {
   int relu;
 };
 
+// Smallest LDS row pitch >= tw + 2 for which every 32-aligned run of a th x tw tile's pixel slots (slot q = row q / tw,
+// column q % tw: what one half-wave reads with one ds_read_b32 per K-step, at any tap shift) lands on 32 distinct banks.
+// tw == 32: any pitch (a run is one row).  Otherwise the rows of a run must tile the 32 banks: pitch == tw (mod 32) always
+// works, smaller pitches exist when 32 % tw == 0 (tw 8: 24).  With the plain pitch tw + 2 the rows of a run overlap by two
+// banks: a 2-way conflict on every B-operand read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.29-0.38 on the 12x16, 11x22,
+// 22x8 and 11x11 tiles in round 2, 0 on 8x32).
+constexpr bool pitch_conflict_free(int th, int tw, int pitch) {
+  const int npix = th * tw;
+  for (int q0 = 0; q0 < npix; q0 += 32) {
+    unsigned used = 0;
+    for (int q = q0; q < q0 + 32 && q < npix; ++q) {
+      const unsigned bit = 1u << (((q / tw) * pitch + q % tw) & 31);
+      if (used & bit) return false;
+      used |= bit;
+    }
+  }
+  return true;
+}
+constexpr int conv_lds_pitch(int th, int tw) {
+#ifdef EINX_CONV_PLAIN_PITCH
+  return tw + 2;
+#else
+  for (int p = tw + 2; p < tw + 2 + 32; ++p)
+    if (pitch_conflict_free(th, tw, p)) return p;
+  return tw + 2;
+#endif
+}
+
 // KS: 1|3.  TH x TW: spatial tile (KS==1: flat run of TH*TW pixels).  Waves are arranged
 // WM (output-channel groups) x WN (pixel groups); each wave owns MT x NT MFMA tiles of 32x32, with
 // WM*MT == 2 (64 output channels per workgroup).  CK: input channels staged per LDS round.
@@ -57,24 +85,30 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
   constexpr int HALO = KS / 2;
   constexpr int PW = TW + 2 * HALO;
   constexpr int PH = TH + 2 * HALO;
-  constexpr int PLANE = PH * PW;
+  constexpr int PITCH = KS == 1 ? PW : conv_lds_pitch(TH, TW);  // LDS row pitch (bank-conflict-free B reads)
+  constexpr int PLANE = PH * PITCH;                             // LDS floats per staged channel
+  constexpr int PLANE_E = PH * PW;                              // elements staged per channel
+  constexpr bool PADDED = PITCH != PW;
   constexpr int NTHR = NW * 64;
   constexpr int NPIX = TH * TW;
   static_assert(WM * MT * 32 == kCoutTile, "a workgroup covers 64 output channels");
   static_assert(WN * NT * 32 >= NPIX, "tile does not fit the workgroup's pixel slots");
+  static_assert(KS == 1 || NPIX >= 32, "unused slots alias the slot one run earlier");
   static_assert(CK % 2 == 0, "channels are consumed in pairs");
-  constexpr int IN_ELEMS = CK * PLANE;
+  constexpr int IN_ELEMS = CK * PLANE_E;
+  constexpr int IN_LDS = CK * PLANE;
+  static_assert(IN_LDS % 4 == 0, "the weight tile behind the input tile is float4 aligned");
   constexpr int IN_PER_THR = (IN_ELEMS + NTHR - 1) / NTHR;
   constexpr int W_ROWS = CK * TAPS;
   constexpr int W_F4 = W_ROWS * kCoutTile / 4;
   constexpr int W_PER_THR = (W_F4 + NTHR - 1) / NTHR;
   constexpr int POOL_ELEMS = 0;  // pooling is done in registers
-  constexpr int LDS_FLOATS = (IN_ELEMS + W_ROWS * kCoutTile) > POOL_ELEMS ? (IN_ELEMS + W_ROWS * kCoutTile) : POOL_ELEMS;
+  constexpr int LDS_FLOATS = (IN_LDS + W_ROWS * kCoutTile) > POOL_ELEMS ? (IN_LDS + W_ROWS * kCoutTile) : POOL_ELEMS;
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   __shared__ float s_bias[kCoutTile], s_scale[kCoutTile], s_shift[kCoutTile];  // epilogue constants
   float* in_tile = lds;
-  float* w_tile = lds + IN_ELEMS;  // IN_ELEMS is a multiple of 4 for every instantiation
+  float* w_tile = lds + IN_LDS;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
@@ -126,8 +160,11 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
       const int p = p0 + q;
       opix[nt] = (vq && p < HW) ? p : -1;
     } else {
-      const int ty = vq ? q / TW : 0, tx = vq ? q % TW : 0;
-      bBase[nt] = half * PLANE + ty * PW + tx;
+      // an unused slot reads the address of the valid slot one or more whole runs before it: same bank as its own
+      // position would have, so it never collides with the valid lanes of its run
+      const int qa = vq ? q : q - 32 * ((q - NPIX) / 32 + 1);
+      const int ty = qa / TW, tx = qa % TW;
+      bBase[nt] = half * PLANE + ty * PITCH + tx;
       const int y = y0 + ty, x = x0 + tx;
       opix[nt] = (vq && y < a.H && x < a.W) ? y * a.W + x : -1;
     }
@@ -141,13 +178,15 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
   int g_ci[IN_PER_THR];   // (generic path) channel inside the chunk
   unsigned goff[IN_PER_THR];  // (EXACT path) element offset from the chunk's first channel plane
   unsigned okmask = 0;        // (EXACT path) bit i: element i is a real pixel (not padding / tail)
+  int lds_off[PADDED ? IN_PER_THR : 1];  // (padded pitch) where element i goes in the LDS tile
 #pragma unroll
   for (int i = 0; i < IN_PER_THR; ++i) {
     const int e = tid + i * NTHR;
     int off = -1, cil = 0;
     if (e < IN_ELEMS) {
-      cil = e / PLANE;
-      const int r = e % PLANE;
+      cil = e / PLANE_E;
+      const int r = e % PLANE_E;
+      if (PADDED) lds_off[i] = cil * PLANE + (r / PW) * PITCH + r % PW;
       if (KS == 1) {
         const int p = p0 + r;
         if (p < HW) off = p;  // 1x1 layers never carry the replicate fold
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
 #pragma unroll
     for (int i = 0; i < IN_PER_THR; ++i) {
       const int e = tid + i * NTHR;
-      if (e < IN_ELEMS) in_tile[e] = ((m >> i) & 1u) ? r_in[i] : 0.0f;
+      if (e < IN_ELEMS) in_tile[PADDED ? lds_off[i] : e] = ((m >> i) & 1u) ? r_in[i] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < W_PER_THR; ++i) {
@@ -258,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt) av[buf][mt] = w_tile[aBase + (kp * TAPS + tap) * 2 * kCoutTile + mt * 32];
 #pragma unroll
-      for (int nt = 0; nt < kNT; ++nt) bv[buf][nt] = in_tile[bBase[nt] + kp * 2 * PLANE + ky * PW + kx];
+      for (int nt = 0; nt < kNT; ++nt) bv[buf][nt] = in_tile[bBase[nt] + kp * 2 * PLANE + ky * PITCH + kx];
     };
 #pragma unroll
     for (int st = 0; st < PF && st < STEPS; ++st) load_frag(st, st % (PF + 1));
