@@ -19,7 +19,10 @@ Rank 0 prints ONE JSON line with the driver contract plus
   roofline_stages  conv stage, descriptor-correlation GEMM, LightGlue GEMM / attention kernels
   cpu_baseline     the oracle (a port) on the host cores, bounded sample; `verified_pairs` = pairs of
                    that sample whose GPU outputs (keypoints, descriptors, matches) equal the oracle's
-  extra_configs    short legs for BASELINE configs[2], configs[3], B=1 latency and the round-1 weights
+  scale_legs       all-rank legs run after the headline at EVERY N: BASELINE configs[4] = SP+LightGlue, 64 pairs per GPU
+                   (whole-job pairs/s over the slowest rank, per-rank min/max, RCCL world)
+  extra_configs    legs for BASELINE configs[2], configs[3], the reference-complete dict, B=1 latency and the round-1 weights
+  cpu_baseline_torch  plain PyTorch on the host cores (oracle/torch_cpu.py), bounded to a few seconds
   rccl             world size seen by the process group + latency of the metric all-reduce (N > 1 or --spawn)
 """
 import argparse
@@ -66,11 +69,14 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs and roofline_stages (they run at N=1 only)")
     ap.add_argument("--extras", action="store_true", help="run extra_configs / roofline_stages on rank 0 even when N > 1")
-    ap.add_argument("--cpu-torch", action="store_true", help="also time oracle/torch_cpu.py (plain PyTorch on the host cores; SP+MNN only)")
+    ap.add_argument("--no-cpu-torch", action="store_true", help="skip the plain-PyTorch CPU leg (oracle/torch_cpu.py, ~5 s; SP+MNN at N=1 only)")
+    ap.add_argument("--cpu-torch", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--cpu-pairs", type=int, default=None, help="pairs of the CPU baseline sample (default: ~10-20 s of host work)")
     ap.add_argument("--with-metrics", action="store_true", help="also compute MR/MMA/VDD on the device each step (metrics.hip) and all-reduce their sums")
     ap.add_argument("--layer-table", action="store_true", help="tuning aid: time every conv layer of both extractors standalone and exit")
     ap.add_argument("--kernel-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
+    ap.add_argument("--no-scale-legs", action="store_true",
+                    help="skip the all-rank BASELINE configs[4] leg (SP+LightGlue, 64 pairs per GPU) that follows the headline at every N")
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (one-rank RCCL group)")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launcher / collective rehearsal on CPU: ranks form a gloo group, all-reduce the metric accumulators, run no kernels")
@@ -119,6 +125,71 @@ def launch_ranks(args, argv):
     return rc
 
 
+# ------------------------------------------------------------------------------------ all-rank legs
+SCALE_LEG_STEPS = 10
+
+
+def scale_leg_plan(args):
+    """Workloads every rank runs after the headline, at every N (so that the N = 1, 2, 4, 8 lines of a scaling run each carry
+    them): BASELINE configs[4] = SP + LightGlue, 64 pairs per GPU (512 over 8 GPUs), rank-sharded like the headline."""
+    if args.no_scale_legs or args.kernel_only or args.layer_table or args.config == "sp_lg":
+        return []
+    return [("sp_lg", WORKLOADS["sp_lg"][1], SCALE_LEG_STEPS)]
+
+
+def leg_record(config, batch, steps, world, elapsed_max, pairs_total, per_rank_pairs_s, mean_matches=None, calibrated=None):
+    """one entry of `scale_legs` (rank 0): whole-job pairs/s over the slowest rank's time, plus the per-rank spread"""
+    e = {"config": config, "workload": f"B{batch} " + WORKLOADS[config][2], "pairs_per_gpu_per_step": batch, "global_batch": batch * world,
+         "n_gpus": world, "steps": steps, "value": round(pairs_total / elapsed_max, 2) if elapsed_max > 0 else 0.0, "unit": "pairs/s",
+         "ms_per_step": round(elapsed_max / max(steps, 1) * 1e3, 3),
+         "per_rank_pairs_per_s": {"min": round(min(per_rank_pairs_s), 2), "max": round(max(per_rank_pairs_s), 2)},
+         "timing": "barrier + synchronize on both sides, max over ranks (as the headline)", "scaling": "weak"}
+    if config == "sp_lg":
+        e["note"] = "BASELINE configs[4] (Batch=512 SP+LightGlue over 8 GPUs = 64 per GPU); at N=1 this is configs[3]"
+    if mean_matches is not None:
+        e["mean_matches"] = round(mean_matches, 1)
+    if calibrated is not None:
+        e["calibrated_descriptors"] = bool(calibrated)
+    return e
+
+
+def all_rank_leg(pkg, dev, config, batch, steps, rank, world, dist=None, local=0, warmup=3):
+    """Every rank builds the workload on its own shard of the pair index space and times `steps` forwards; returns
+    (record on rank 0 | None, workload).  No data-path collective: a barrier on both sides, MAX of the elapsed time, SUM of pairs."""
+    import torch
+    w = Workload(pkg, dev, config, batch, rank=rank)
+    for _ in range(2 + warmup):
+        w.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(device_ids=[local])
+    t0 = time.perf_counter()
+    nm = 0
+    for _ in range(steps):
+        _, _, m = w.step()
+        nm += sum(int(t.shape[0]) for t in m["matched_kpts0"])
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier(device_ids=[local])
+    elapsed = time.perf_counter() - t0
+    v = torch.tensor([elapsed, mine, float(steps * batch), float(nm)], dtype=torch.float64, device=dev)
+    per_rank = [steps * batch / mine]
+    if dist is not None:
+        tmax = v[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(gathered, v)
+        elapsed = float(tmax.item())
+        per_rank = [float(g[2].item() / g[1].item()) for g in gathered]
+        pairs = sum(float(g[2].item()) for g in gathered)
+        nm = sum(float(g[3].item()) for g in gathered)
+    else:
+        pairs = float(steps * batch)
+    rec = leg_record(config, batch, steps, world, elapsed, pairs, per_rank, mean_matches=nm / max(pairs, 1.0), calibrated=w.calibrated) if rank == 0 else None
+    return rec, w
+
+
 # ------------------------------------------------------------------------------------ CPU rehearsal
 def dry_run_gloo(args):
     """The N>1 control flow without kernels: same env:// rendezvous, same accumulator all-reduce,
@@ -139,10 +210,26 @@ def dry_run_gloo(args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     acc.all_reduce()
     stats = acc.as_dict()
+    legs = []
+    for cfg_, b_, steps_ in scale_leg_plan(args):  # the same all-rank control flow as all_rank_leg, without kernels
+        dist.barrier()
+        t1 = time.perf_counter()
+        time.sleep(0.001 * (rank + 1))
+        mine = time.perf_counter() - t1
+        dist.barrier()
+        v = torch.tensor([time.perf_counter() - t1, mine, float(steps_ * b_), 0.0], dtype=torch.float64)
+        tmax = v[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(gathered, v)
+        if rank == 0:
+            legs.append(leg_record(cfg_, b_, steps_, world, float(tmax.item()), sum(float(g[2]) for g in gathered),
+                                   [float(g[2] / g[1]) for g in gathered]))
     if rank == 0:
         print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "steps": args.steps,
                           "pairs": stats["pairs"], "keypoints0": stats["keypoints0"], "matches": stats["matches"],
-                          "config": {"workload": WORKLOADS[args.config][2], "pairs_per_gpu_per_step": B, "global_batch": B * world}}))
+                          "config": {"workload": WORKLOADS[args.config][2], "pairs_per_gpu_per_step": B, "global_batch": B * world},
+                          "scale_legs": legs}))
     dist.destroy_process_group()
 
 
@@ -443,6 +530,22 @@ def stage_rooflines(wl, lg_wl=None):
     return out
 
 
+def dense_stage_roofline(w):
+    """The dense-output stage: upsample + L2-normalise of both sides' raw descriptor maps, a pure HBM stream."""
+    torch, pkg = w.torch, w.pkg
+    w.step()
+    torch.cuda.synchronize()
+    prof = library_profile(pkg, lambda: (w.step(), torch.cuda.synchronize()))
+    keys = [k for k in prof if k.startswith("upsample")]
+    ms = sum(prof[k][1] for k in keys)
+    calls = sum(prof[k][0] for k in keys)
+    by = 2.0 * w.B * 256 * 260 * 346 * 4  # both sides' [B,256,260,346] fp32 outputs; the 33x44 sources are L2-resident
+    return {"stage": "dense descriptor maps (upsample + normalise, both sides, %d launches)" % calls, "ms": round(ms, 3), "bound": "hbm",
+            "achieved": round(by / ms / 1e9, 3) if ms > 0 else None, "peak": PEAK_HBM_BYTES / 1e12, "unit": "TB/s",
+            "frac": round(by / (ms * 1e-3) / PEAK_HBM_BYTES, 4) if ms > 0 else None, "algorithmic_bytes": by,
+            "kernels_ms": {k: round(prof[k][1], 4) for k in keys}}
+
+
 def cpu_baseline_and_verify(wl, args, gpu_out):
     """The oracle (C port, OpenMP) on the host cores over the first pairs of the resident batch.  Its outputs
     double as the checker of the GPU outputs of the same pairs (`verified_pairs`): same weights, same inputs."""
@@ -590,6 +693,20 @@ def run_rank(args):
     pairs_total = max(stats["pairs"], 1.0)
     value = stats["pairs"] / elapsed if elapsed > 0 else 0.0
 
+    # ---- all-rank legs (every N): BASELINE configs[4], SP + LightGlue at 64 pairs per GPU, sharded like the headline ----
+    scale_legs, leg_wls = [], {}
+    for cfg_, b_, steps_ in scale_leg_plan(args):
+        rec, w_ = all_rank_leg(pkg, dev, cfg_, b_, steps_, rank, world, dist if distributed else None, local)
+        if rec is not None:
+            if rccl is not None:
+                rec["rccl_world"] = rccl["world"]
+            scale_legs.append(rec)
+        if rank == 0 and world == 1:
+            leg_wls[(cfg_, b_)] = w_  # reused by the per-stage rooflines below
+        else:
+            del w_
+            torch.cuda.empty_cache()
+
     roofline = stages = cpu_baseline = cpu_torch = None
     extras = []
     do_extras = rank == 0 and not args.no_extras and (world == 1 or args.extras)
@@ -601,9 +718,9 @@ def run_rank(args):
         if last is None:
             last = step()
         cpu_baseline = cpu_baseline_and_verify(wl, args, last)
-    if rank == 0 and world == 1 and args.cpu_torch and args.config == "sp_mnn":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_torch and args.config == "sp_mnn":
         from oracle import torch_cpu
-        nb = min(16, B)
+        nb = min(8, B)  # ~5 s of host work on the GPU box's cores
         a_ = (wl.sub("event_extractor.extractor."), wl.sub("image_extractor.extractor."))
         torch_cpu.sp_mnn_pairs(*a_, wl.ev_np[:2], wl.mask_np[:2], wl.img_np[:2].copy())
         tc = time.perf_counter()
@@ -626,11 +743,29 @@ def run_rank(args):
 
         lg_wl = None
         if args.config == "sp_mnn":
-            lg_wl = leg("sp_lg", 64, note="BASELINE configs[3]")
+            lg_wl = leg_wls.pop(("sp_lg", 64), None)
+            if lg_wl is not None:  # the all-rank leg above IS the configs[3] measurement at N=1 (same timing rules)
+                r_ = scale_legs[0]
+                extras.append({"config": "sp_lg", "workload": r_["workload"], "pairs_per_step": 64, "calibrated_descriptors": r_.get("calibrated_descriptors"),
+                               "value": r_["value"], "unit": "pairs/s", "ms_per_step": r_["ms_per_step"], "steps": r_["steps"],
+                               "mean_matches": r_.get("mean_matches"), "note": "BASELINE configs[3] (= scale_legs[0])"})
+            else:
+                lg_wl = leg("sp_lg", 64, steps=SCALE_LEG_STEPS, note="BASELINE configs[3]")
             stages = stage_rooflines(wl, lg_wl)
             del lg_wl
             torch.cuda.empty_cache()
-            w = leg("silk_mnn", 32, steps=2, note="BASELINE configs[2]")
+            w = leg("silk_mnn", 32, steps=10, note="BASELINE configs[2]")
+            del w
+            torch.cuda.empty_cache()
+            # the dict an unmodified reference caller gets: dense descriptor maps + dense positions + log_assignment
+            w = Workload(pkg, dev, "sp_mnn", 32, dense=True, log_assignment=True)
+            sec, mm = w.timed(10)
+            extras.append({"config": "sp_mnn", "workload": "B32 " + WORKLOADS["sp_mnn"][2], "pairs_per_step": 32, "calibrated_descriptors": True,
+                           "value": round(32 / sec, 2), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10, "mean_matches": round(mm, 1),
+                           "note": "reference-complete dict: dense_outputs=True (normalized_descriptors [B,256,260,346] = 2.95 GB per side, "
+                                   "dense_descriptors / dense_positions) and log_assignment -- the defaults of core.modules (the headline "
+                                   "materialises the sparse set only, SURVEY 8d)"})
+            stages.append(dense_stage_roofline(w))
             del w
             torch.cuda.empty_cache()
             w = leg("sp_mnn", 1, steps=50, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
@@ -666,6 +801,8 @@ def run_rank(args):
                        "harness_metrics_mean": ([round(v, 5) for v in (metric_sums / pairs_total).tolist()] if args.with_metrics else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if scale_legs:
+            out["scale_legs"] = scale_legs
         if stages:
             out["roofline_stages"] = stages
         if extras:

@@ -30,6 +30,21 @@ def test_launcher_spawns_two_gloo_ranks():
     assert d["keypoints0"] == steps * (B * 1000 + 0) + steps * (B * 1000 + 1)
     assert d["matches"] == steps * 10 + steps * 20
     assert d["config"]["global_batch"] == 2 * B
+    # the scaling run must carry BASELINE configs[4] next to the headline at every N: SP+LightGlue, 64 pairs per GPU, all ranks
+    assert "MNN" in d["config"]["workload"]
+    legs = d["scale_legs"]
+    assert len(legs) == 1 and legs[0]["config"] == "sp_lg" and "LightGlue" in legs[0]["workload"]
+    assert legs[0]["pairs_per_gpu_per_step"] == 64 and legs[0]["global_batch"] == 128 and legs[0]["n_gpus"] == 2
+    assert legs[0]["steps"] >= 10 and legs[0]["value"] > 0
+    pr = legs[0]["per_rank_pairs_per_s"]
+    assert 0 < pr["min"] <= pr["max"]  # one entry per rank went into the spread (rank 1 sleeps longer in the rehearsal)
+    assert pr["min"] < pr["max"]
+
+
+def test_scale_legs_can_be_switched_off_and_are_not_doubled_for_sp_lg():
+    r = _run("--gpus", "2", "--dry-run-gloo", "--steps", "1", "--no-scale-legs")
+    assert r.returncode == 0, r.stderr
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["scale_legs"] == []
 
 
 def test_launcher_passes_config_and_batch():
@@ -38,6 +53,7 @@ def test_launcher_passes_config_and_batch():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["pairs_per_gpu_per_step"] == 64 and d["config"]["global_batch"] == 128
     assert "LightGlue" in d["config"]["workload"]
+    assert d["scale_legs"] == []  # the headline already is the configs[4] workload
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box without a GPU")
