@@ -87,8 +87,9 @@ SIGNATURES = {
     "einx_desc_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
                                  c_void_p, c_void_p]),
     "einx_normalize_map": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "einx_upsample_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "einx_upsample_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                        c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "einx_mnn_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "einx_mnn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_void_p]),

@@ -224,7 +224,9 @@ def upsample_normalize(raw, padded_size, pads, scale):
     w0, w1, h0, h1 = pads
     H, W = Hp - h0 - h1, Wp - w0 - w1
     out = torch.empty((B, D, H, W), dtype=F32, device=raw.device)
-    check(lib().einx_upsample_normalize(_ptr(raw), B, D, hc, wc, Hp, Wp, h0, w0, H, W, float(scale), _ptr(out), _stream(raw)),
+    nws = int(lib().einx_upsample_ws_bytes(B, H, W))
+    ws = torch.empty((nws + 3) // 4, dtype=F32, device=raw.device)  # per-pixel norms handed from the first kernel to the second
+    check(lib().einx_upsample_normalize(_ptr(raw), B, D, hc, wc, Hp, Wp, h0, w0, H, W, float(scale), _ptr(out), _ptr(ws), nws, _stream(raw)),
           "einx_upsample_normalize")
     return out
 

@@ -311,6 +311,334 @@ __global__ __launch_bounds__(UP_COLS) void upsample_band_kernel(const float* raw
   }
 }
 
+
+// ---- dense descriptor maps, round 3: two kernels instead of the band kernel above for W <= 384, wc <= 63 ---------------
+// The output [B,D,H,W] is a pure 2.95 GB stream at the shipped size (B=32); tools/store_pattern2.hip measured what the
+// store schedule alone is worth on MI355X: 2.3-2.7 TB/s for per-row dword stores at the 346-float pitch (every 256-byte
+// segment straddles cache lines), 5.4 TB/s for "one wave writes the whole ROWS x W run of one (channel, band) with 16-byte
+// stores, 16-32 channels per workgroup, channel group fastest in the grid", 6.9 for a plain sequential fill.
+//   upsample_den_kernel    per output pixel: den = max(sqrt(sum_c v_c^2), 1e-12) with the sequential fmaf chain c = 0..D-1
+//                          (the only part that needs all channels of a pixel), and 1/den; [2,B,H,W] floats of workspace
+//   upsample_store_kernel  (channel group, sweep, image) per workgroup, channels in parallel over its four waves: each wave
+//                          recomputes v for one channel of the sweep (horizontal lerps shared by the rows, as above), divides
+//                          by den, stages the run in its private LDS slab and writes it linearly; no workgroup barrier
+//                          after the coarse rows are staged, stores drain under the next channel's arithmetic.
+// A sweep = up to UP_ROWS consecutive output rows that interpolate between the same two coarse rows (j, y1): unit
+// (j, s) = rows [first row of band j + s UP_ROWS, + UP_ROWS) of band j; units 0..hc-1 are the first sweeps, the few further
+// sweeps of taller bands are listed by the host (UpGeom::extra_*), so every workgroup has work.  Both kernels keep the per-element operation order of orc_upsample_normalize (bit-equal).
+#ifndef EINX_UPS_CC
+#define EINX_UPS_CC 32
+#endif
+constexpr int UPS_CC = EINX_UPS_CC;  // channels per workgroup of the store kernel: 64 (channel, row) pairs = 16 per wave
+constexpr int UPS_WAVES = 4;
+#ifndef EINX_UPS_EXP
+#define EINX_UPS_EXP 0
+#endif
+constexpr int UP_PAIRS = 16;  // (channel, coarse row) pairs a wave of the store kernel stages (once)
+#ifndef EINX_UPD_PAIRS
+#define EINX_UPD_PAIRS 8
+#endif
+#ifndef EINX_UPD_UNROLL
+#define EINX_UPD_UNROLL 1
+#endif
+#ifndef EINX_UPD_WAVES
+#define EINX_UPD_WAVES 8
+#endif
+constexpr int UPD_PAIRS = EINX_UPD_PAIRS;  // ... and a wave of the den kernel per round (registers: five of its workgroups per CU)
+
+constexpr int UP_MAX_EXTRA = 8;
+struct UpGeom {
+  int D, hc, wc, Hp, Wp, h0, w0, H, W;
+  int units;  // hc first sweeps + n_extra further sweeps of bands taller than UP_ROWS (band 0 at the shipped size)
+  int n_extra;
+  short extra_j[UP_MAX_EXTRA], extra_s[UP_MAX_EXTRA];
+};
+
+__host__ __device__ inline int up_coarse_row(const UpGeom& g, int Y, float& ly) {  // y0 and the vertical weight of padded row Y
+  const float sy = (float)g.hc / (float)g.Hp;
+  float fy = ((float)Y + 0.5f) * sy - 0.5f;
+  if (fy < 0.0f) fy = 0.0f;
+  const int y0 = (int)fy;
+  ly = fy - (float)y0;
+  return y0;
+}
+// first padded row (>= h0) whose source row is j; rows are monotone in y0, band 0 also owns the rows clamped to source row 0
+__device__ __forceinline__ int up_band_start(const UpGeom& g, int j) {
+  const float sy = (float)g.hc / (float)g.Hp;
+  int Y = j == 0 ? g.h0 : (int)(((float)j + 0.5f) / sy - 0.5f) - 2;
+  if (Y < g.h0) Y = g.h0;
+  float t;
+  while (Y < g.h0 + g.H && up_coarse_row(g, Y, t) < j) ++Y;
+  return Y;
+}
+// rows of sweep s of band j: first row Y, count nrow (0: nothing to do), vertical weights
+__device__ __forceinline__ int up_sweep(const UpGeom& g, int j, int s, int& Y, float* ly, float* hy) {
+  Y = up_band_start(g, j) + s * UP_ROWS;
+  int nrow = 0;
+#pragma unroll
+  for (int r = 0; r < UP_ROWS; ++r) {
+    float l = 0.0f;
+    const bool in = Y + r < g.h0 + g.H && up_coarse_row(g, Y + r, l) == j && nrow == r;
+    if (in) nrow = r + 1;
+    ly[r] = l;
+    hy[r] = 1.0f - l;
+  }
+  return nrow;
+}
+__device__ __forceinline__ void up_unit(const UpGeom& g, int unit, int& j, int& s) {
+  j = unit;
+  s = 0;
+  if (unit >= g.hc) {
+#pragma unroll
+    for (int e = 0; e < UP_MAX_EXTRA; ++e)  // constant indices: the arrays stay in SGPRs
+      if (e == unit - g.hc) {
+        j = g.extra_j[e];
+        s = g.extra_s[e];
+      }
+  }
+}
+__device__ __forceinline__ void up_column(const UpGeom& g, int x, int& x0, float& lx, float& hx) {
+  const float sx = (float)g.wc / (float)g.Wp;
+  float fx = ((float)(x + g.w0) + 0.5f) * sx - 0.5f;
+  if (fx < 0.0f) fx = 0.0f;
+  x0 = (int)fx;
+  lx = fx - (float)x0;
+  hx = 1.0f - lx;
+}
+// Coarse rows j and y1 of channels [c0, c0 + n) -> LDS [n][2][wc + 1] (wc + 1 <= 64); element wc repeats element wc - 1, so
+// that the right neighbour x1 = min(x0 + 1, wc - 1) is always the word after x0.  (channel, row) pairs are dealt to the
+// waves (at most UP_PAIRS each), lane = x: coalesced row reads, no index divisions, all of a wave's loads in flight at once;
+// split in issue / commit so that a round's loads can fly under the previous round's arithmetic.
+template <int PAIRS>
+struct UpStage {
+  float v[PAIRS];
+};
+template <int PAIRS>
+__device__ __forceinline__ void up_stage_issue(UpStage<PAIRS>& st, const float* rb, const UpGeom& g, int j, int y1, int c0, int n, int lane, int wv, int nw) {
+  const unsigned plane = (unsigned)(g.hc * g.wc);
+  const int np = 2 * n;
+  // 32-bit element offsets from one uniform base: the loads address as scalar base + vector offset
+  const float* base = rb + (size_t)c0 * plane + (size_t)j * g.wc;
+  const unsigned lo = (unsigned)(lane < g.wc ? lane : g.wc - 1);
+  const unsigned d1 = (unsigned)((y1 - j) * g.wc);
+#pragma unroll
+  for (int u = 0; u < PAIRS; ++u) {
+    const int q = wv + u * nw;
+    const int qc = q < np ? q : np - 1;
+    st.v[u] = base[(unsigned)(qc >> 1) * plane + ((qc & 1) ? d1 : 0u) + lo];
+  }
+}
+template <int PAIRS>
+__device__ __forceinline__ void up_stage_commit(const UpStage<PAIRS>& st, const UpGeom& g, int n, float* rows, int lane, int wv, int nw) {
+  const int pw = g.wc + 1;
+  if (lane < pw) {
+#pragma unroll
+    for (int u = 0; u < PAIRS; ++u) {
+      const int q = wv + u * nw;
+      if (q < 2 * n) rows[q * pw + lane] = st.v[u];
+    }
+  }
+}
+
+// ws layout: den [B,H,W] then 1/den [B,H,W] (the reciprocal correctly rounded: IEEE division)
+template <int NIT>
+__global__ __launch_bounds__(64 * NIT, EINX_UPD_WAVES) void upsample_den_kernel(const float* raw, UpGeom g, float* den, float* rden) {
+  constexpr int CHR = UPD_PAIRS * NIT / 2;  // channels per LDS round: every wave stages UPD_PAIRS (channel, row) pairs
+  extern __shared__ float rows[];          // [CHR][2][wc + 1]
+  const int b = blockIdx.y;
+  int j, s;
+  up_unit(g, blockIdx.x, j, s);
+  float ly[UP_ROWS], hy[UP_ROWS], ssq[UP_ROWS];
+  int Y;
+  const int nrow = up_sweep(g, j, s, Y, ly, hy);
+  if (nrow == 0) return;  // uniform (a band without rows in the crop window)
+  const int tid = threadIdx.x, x = tid, lane = tid & 63, wv = tid >> 6;
+  const bool xv = x < g.W;
+  const int pw = g.wc + 1;
+  int x0;
+  float lx, hx;
+  up_column(g, xv ? x : g.W - 1, x0, lx, hx);
+  const int y1 = j + (j < g.hc - 1 ? 1 : 0);
+  const float* rb = raw + (size_t)b * g.D * g.hc * g.wc;
+#pragma unroll
+  for (int r = 0; r < UP_ROWS; ++r) ssq[r] = 0.0f;
+  for (int c0 = 0; c0 < g.D; c0 += CHR) {
+    const int n = g.D - c0 < CHR ? g.D - c0 : CHR;
+    // the staging registers are not kept across the arithmetic: with <= 64 registers five of these workgroups share a CU and
+    // hide each other's load latency (a register prefetch across the loop cost two of them: 217 -> 307 us at B=32)
+    UpStage<UPD_PAIRS> st;
+    up_stage_issue(st, rb, g, j, y1, c0, n, lane, wv, NIT);
+    __syncthreads();  // the previous round's reads are done
+    up_stage_commit(st, g, n, rows, lane, wv, NIT);
+    __syncthreads();
+    const float* rp = rows + x0;
+#pragma unroll EINX_UPD_UNROLL
+    for (int cl = 0; cl < n; ++cl, rp += 2 * pw) {
+      const float t0 = hx * rp[0] + lx * rp[1];
+      const float t1 = hx * rp[pw] + lx * rp[pw + 1];
+#pragma unroll
+      for (int r = 0; r < UP_ROWS; ++r) {
+        const float v = hy[r] * t0 + ly[r] * t1;
+        ssq[r] = fmaf(v, v, ssq[r]);
+      }
+    }
+  }
+  if (xv) {
+    const size_t o = ((size_t)b * g.H + (Y - g.h0)) * g.W + x;
+#pragma unroll
+    for (int r = 0; r < UP_ROWS; ++r)
+      if (r < nrow) {
+        const float d = fmaxf(sqrtf(ssq[r]), 1e-12f);
+        den[o + (size_t)r * g.W] = d;
+        rden[o + (size_t)r * g.W] = 1.0f / d;
+      }
+  }
+}
+
+// v / d for the store kernel.  d >= 1e-12 and y = RN(1 / d) come from the den kernel.  Two Newton corrections of
+// q = v * y with exact fma remainders give the correctly rounded quotient (after the first step q is faithful, then
+// Markstein's theorem applies) as long as nothing under- or overflows: 2^-80 <= |v| <= 2^60 (|v| <= d always holds
+// here).  Checked against IEEE division on 2.5e9 random and boundary-mantissa operands (tools/div_check.c).  Elements
+// outside that range (exact zeros among them) make the wave redo the channel with IEEE divisions.
+__device__ __forceinline__ float up_div(float v, float d, float y) {
+  const float q0 = v * y;
+  const float r0 = fmaf(-d, q0, v);
+  const float q1 = fmaf(r0, y, q0);
+  const float r1 = fmaf(-d, q1, v);
+  return fmaf(r1, y, q1);
+}
+
+template <int NIT>
+__global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const float* raw, const float* den, const float* rden, UpGeom g,
+                                                                         float scale, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pw = g.wc + 1;
+  const int ng = (g.D + UPS_CC - 1) / UPS_CC;
+  int id = (int)blockIdx.x;
+  const int cg = id % ng;  // channel group fastest: neighbouring workgroups write the same rows of neighbouring channel groups
+  id /= ng;
+  const int unit = id % g.units, b = id / g.units;
+  int j, s;
+  up_unit(g, unit, j, s);
+  float ly[UP_ROWS], hy[UP_ROWS];
+  int Y;
+  const int nrow = up_sweep(g, j, s, Y, ly, hy);
+  if (nrow == 0) return;  // uniform (a band without rows in the crop window)
+  const int c0 = cg * UPS_CC;
+  const int nc = g.D - c0 < UPS_CC ? g.D - c0 : UPS_CC;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int run_cap = UP_ROWS * 64 * NIT + 4;  // slab per wave: UP_ROWS rows of W floats (row-major like the output) + slack
+  float* rows = smem + UPS_WAVES * run_cap;        // [UPS_CC][2][wc + 1]
+  float* slab = smem + wave * run_cap;
+  const int y1 = j + (j < g.hc - 1 ? 1 : 0);
+  const float* rb = raw + (size_t)b * g.D * g.hc * g.wc;
+  UpStage<UP_PAIRS> st;
+  up_stage_issue(st, rb, g, j, y1, c0, nc, lane, wave, UPS_WAVES);
+
+  int x0[NIT];
+  float lx[NIT], hx[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int x = it * 64 + lane;
+    up_column(g, x < g.W ? x : g.W - 1, x0[it], lx[it], hx[it]);
+  }
+  const bool xvl = (NIT - 1) * 64 + lane < g.W;  // only the last column sweep has lanes outside the row
+  const size_t HW = (size_t)g.H * g.W;
+  // per-pixel norms of this sweep; rows past nrow / columns past W re-read a valid pixel's norm (clamped address, no
+  // branches) and are never copied out
+  float dn[NIT][UP_ROWS], yr[NIT][UP_ROWS];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int r = 0; r < UP_ROWS; ++r) {
+      const int xc = (it < NIT - 1 || xvl) ? it * 64 + lane : g.W - 1;
+      const size_t o = ((size_t)b * g.H + (Y - g.h0 + (r < nrow ? r : nrow - 1))) * g.W + xc;
+      dn[it][r] = den[o];
+      yr[it][r] = rden[o];
+    }
+  bool big = false;  // a norm beyond the fast division's range (|v| <= den < 2^60 otherwise): IEEE divisions for the whole sweep
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int r = 0; r < UP_ROWS; ++r) big |= !(dn[it][r] < 0x1p60f);
+  big = __any(big);
+  up_stage_commit(st, g, nc, rows, lane, wave, UPS_WAVES);
+  __syncthreads();  // the only workgroup barrier: from here on every wave works on its own channels and its own LDS slab
+
+  const int len = nrow * g.W;
+  for (int cl = wave; cl < nc; cl += UPS_WAVES) {
+    float* oc = out + ((size_t)b * g.D + c0 + cl) * HW + (size_t)(Y - g.h0) * g.W;
+    const int head = (int)(((16 - ((size_t)oc & 15)) & 15) >> 2);  // floats up to the first 16-byte boundary of the run
+#ifdef EINX_UPS_NOSHIFT
+    float* buf = slab;
+#else
+    float* buf = slab + ((4 - head) & 3);                           // ... which then sits on a 16-byte boundary of the slab too
+#endif
+    const float* rp = rows + cl * 2 * pw;
+    bool odd = big;  // some element outside the fast division's range
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const float t0 = hx[it] * rp[x0[it]] + lx[it] * rp[x0[it] + 1];
+      const float t1 = hx[it] * rp[pw + x0[it]] + lx[it] * rp[pw + x0[it] + 1];
+      float q[UP_ROWS];
+#pragma unroll
+      for (int r = 0; r < UP_ROWS; ++r) {
+        const float v = hy[r] * t0 + ly[r] * t1;
+#if EINX_UPS_EXP == 1  // timing experiment (wrong results): no division
+        q[r] = v;
+#elif EINX_UPS_EXP == 2  // timing experiment: one correction step, no range check
+        { const float q0 = v * yr[it][r]; q[r] = scale * fmaf(fmaf(-dn[it][r], q0, v), yr[it][r], q0); }
+#elif EINX_UPS_EXP == 3  // timing experiment: no range check
+        q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
+#else
+        odd |= !(fabsf(v) >= 0x1p-80f);  // also true for NaN; the upper end is checked once per sweep on the norms (|v| <= den)
+        q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
+#endif
+      }
+      if (it < NIT - 1 || xvl) {
+#pragma unroll
+        for (int r = 0; r < UP_ROWS; ++r) buf[r * g.W + it * 64 + lane] = q[r];  // rows past nrow land in the slab's slack
+      }
+    }
+    if (__builtin_expect(__any(odd), 0)) {  // the same values with IEEE divisions
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {  // unrolled: a rolled loop would index the per-sweep register arrays dynamically (scratch)
+        const float t0 = hx[it] * rp[x0[it]] + lx[it] * rp[x0[it] + 1];
+        const float t1 = hx[it] * rp[pw + x0[it]] + lx[it] * rp[pw + x0[it] + 1];
+        if (it < NIT - 1 || xvl) {
+#pragma unroll
+          for (int r = 0; r < UP_ROWS; ++r) buf[r * g.W + it * 64 + lane] = scale * ((hy[r] * t0 + ly[r] * t1) / dn[it][r]);
+        }
+      }
+    }
+    // the wave's own LDS writes -> its own LDS reads: the LDS executes one wave's instructions in order; the fences only
+    // keep the compiler from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < head && lane < len) oc[lane] = buf[lane];
+    const int n4 = len > head ? (len - head) >> 2 : 0;
+    f32x4* o4 = reinterpret_cast<f32x4*>(oc + head);
+    f32x4 w4[2 * NIT];
+#pragma unroll
+    for (int k = 0; k < 2 * NIT; ++k) {  // UP_ROWS x 64 NIT floats = 2 NIT float4 per lane at most
+      const int i = lane + 64 * k;
+      const float* sb = buf + head + 4 * (i < n4 ? i : 0);
+      w4[k] = f32x4{sb[0], sb[1], sb[2], sb[3]};  // one ds_read_b128: buf + head is 16-byte aligned
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NIT; ++k) {
+      const int i = lane + 64 * k;
+      if (i < n4) o4[i] = w4[k];
+    }
+    const int tail0 = head + 4 * n4;
+    if (tail0 + lane < len) oc[tail0 + lane] = buf[tail0 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 }  // namespace
 
 EINX_EXPORT int einx_desc_sample(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last,
@@ -368,13 +696,74 @@ EINX_EXPORT int einx_random_positions(const float* u, int R, float size0, float 
   return EINX_OK;
 }
 
+// lists the sweeps beyond the first of every band (the same float arithmetic as the kernels: IEEE, no contraction);
+// false if there are more than UP_MAX_EXTRA of them (unusual scales: the band kernel handles those)
+static bool up_plan_units(UpGeom& g) {
+  g.n_extra = 0;
+  for (int e = 0; e < UP_MAX_EXTRA; ++e) g.extra_j[e] = g.extra_s[e] = 0;
+  int run = 0, prev = -1;
+  for (int Y = g.h0; Y < g.h0 + g.H; ++Y) {
+    float l;
+    const int y0 = up_coarse_row(g, Y, l);
+    run = y0 == prev ? run + 1 : 1;
+    prev = y0;
+    if (run > UP_ROWS && (run - 1) % UP_ROWS == 0) {  // row number UP_ROWS k + 1 of this band opens sweep k
+      if (g.n_extra == UP_MAX_EXTRA) return false;
+      g.extra_j[g.n_extra] = (short)y0;
+      g.extra_s[g.n_extra] = (short)((run - 1) / UP_ROWS);
+      ++g.n_extra;
+    }
+  }
+  g.units = g.hc + g.n_extra;
+  return true;
+}
+
+EINX_EXPORT size_t einx_upsample_ws_bytes(int B, int H, int W) { return (size_t)2 * B * H * W * sizeof(float); }
+
+template <int NIT>
+static void launch_upsample(const float* raw, int B, const UpGeom& g, float scale, float* out, float* den, hipStream_t s) {
+  float* rden = den + (size_t)B * g.H * g.W;
+  const int pw = g.wc + 1;
+  const int units = g.units;
+  {
+    EINX_PROF("upsample_den_kernel", s);
+    hipLaunchKernelGGL(upsample_den_kernel<NIT>, dim3((unsigned)units, (unsigned)B), dim3(64 * NIT), (size_t)(UPD_PAIRS * NIT / 2) * 2 * pw * sizeof(float),
+                       s, raw, g, den, rden);
+  }
+  {
+    EINX_PROF("upsample_store_kernel", s);
+    const int ng = einx_cdiv(g.D, UPS_CC);
+    const size_t lds = ((size_t)UPS_WAVES * (UP_ROWS * 64 * NIT + 4) + (size_t)UPS_CC * 2 * pw) * sizeof(float);
+    hipLaunchKernelGGL(upsample_store_kernel<NIT>, dim3((unsigned)(ng * units * B)), dim3(64 * UPS_WAVES), lds, s, raw, den, rden, g, scale, out);
+  }
+}
+
 EINX_EXPORT int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int h0, int w0, int H, int W,
-                                        float scale, float* out, void* stream) {
+                                        float scale, float* out, void* ws, size_t ws_bytes, void* stream) {
   EINX_CHECK_ARG(raw && out, "null pointer");
   EINX_CHECK_ARG(B > 0 && D > 0 && hc > 0 && wc > 0 && H > 0 && W > 0, "bad shape");
   EINX_CHECK_ARG(h0 >= 0 && w0 >= 0 && h0 + H <= Hp && w0 + W <= Wp, "crop window outside the padded map");
+  EINX_CHECK_ARG(B < 65536, "batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  UpGeom g{D, hc, wc, Hp, Wp, h0, w0, H, W, 0, 0, {0}, {0}};
+  if (W <= 384 && wc <= 63 && hc < 32768 && up_plan_units(g)) {  // the two-kernel path (the shipped geometries); others take the band kernel
+    EINX_CHECK_ARG(ws && ws_bytes >= einx_upsample_ws_bytes(B, H, W), "workspace missing or smaller than einx_upsample_ws_bytes");
+    EINX_CHECK_ARG((long)einx_cdiv(D, UPS_CC) * g.units * B < (1L << 31), "grid too large");
+    float* den = (float*)ws;
+    switch (einx_cdiv(W, 64)) {
+      case 1: launch_upsample<1>(raw, B, g, scale, out, den, s); break;
+      case 2: launch_upsample<2>(raw, B, g, scale, out, den, s); break;
+      case 3: launch_upsample<3>(raw, B, g, scale, out, den, s); break;
+      case 4: launch_upsample<4>(raw, B, g, scale, out, den, s); break;
+      case 5: launch_upsample<5>(raw, B, g, scale, out, den, s); break;
+      default: launch_upsample<6>(raw, B, g, scale, out, den, s); break;
+    }
+    EINX_CHECK_LAUNCH();
+    return EINX_OK;
+  }
+  EINX_PROF("upsample_band_kernel", s);
   const size_t lds = W <= UP_COLS ? (size_t)2 * UP_ROWS * W * sizeof(float) : 0;
-  hipLaunchKernelGGL(upsample_band_kernel, dim3((unsigned)einx_cdiv(W, UP_COLS), (unsigned)hc, (unsigned)B), dim3(UP_COLS), lds, (hipStream_t)stream, raw, D,
+  hipLaunchKernelGGL(upsample_band_kernel, dim3((unsigned)einx_cdiv(W, UP_COLS), (unsigned)hc, (unsigned)B), dim3(UP_COLS), lds, s, raw, D,
                      hc, wc, Hp, Wp, h0, w0, H, W, scale, out);
   EINX_CHECK_LAUNCH();
   return EINX_OK;

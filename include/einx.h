@@ -161,9 +161,12 @@ int einx_normalize_rows(const float* x, int R, int C, float scale, float* out, v
 int einx_random_positions(const float* u, int R, float size0, float size1, float* out, void* stream);
 
 /* upsample_descriptors: bilinear resize to (Hp,Wp) + normalize, written cropped to the
- * unpadded window [B,D,H,W] (descriptor_util.py:131-138 + Padder.unpad util.py:34-50) */
+ * unpadded window [B,D,H,W] (descriptor_util.py:131-138 + Padder.unpad util.py:34-50).
+ * ws: device scratch of at least einx_upsample_ws_bytes(B,H,W) bytes (the per-pixel norms between the two
+ * kernels); required when W <= 384 and wc <= 63 (every shipped geometry), unused (may be NULL) otherwise. */
+size_t einx_upsample_ws_bytes(int B, int H, int W);
 int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int h0, int w0, int H, int W,
-                            float scale, float* out, void* stream);
+                            float scale, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Mutual-nearest-neighbour matcher  (K7)   core/modules/matchers/MNN.py:43-140

@@ -10,7 +10,8 @@ OUT=/tmp/einx_var_$NAME
 mkdir -p "$OUT" "$ROOT/ab_libs"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall -Wno-unused-function $*"
 for f in common conv detect desc mnn lightglue events metrics extract; do
-  /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$OUT/$f.o" &
+  X=""; if [ $f = desc ]; then X="-fno-slp-vectorize"; fi  # as the Makefile
+  /opt/rocm/bin/hipcc $FLAGS $X -c "$SRC/$f.hip" -o "$OUT/$f.o" &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$OUT"/*.o -o "$ROOT/ab_libs/libeinx_$NAME.so"

@@ -17,6 +17,30 @@ __device__ __forceinline__ void write_run(float* o, int len, int lane, int nl, f
   if (lane < len - t0) o[t0 + lane] = v;
 }
 
+// as write_run, but the float4 body starts on a 128-byte boundary (head of up to 31 floats as dword stores): every
+// wave-instruction of the body then covers 8 whole cache lines
+__device__ __forceinline__ void write_run128(float* o, int len, int lane, float v) {
+  int head = (int)((128 - ((size_t)o & 127)) & 127) / 4;
+  if (head > len) head = len;
+  if (lane < head) o[lane] = v;
+  const int n4 = (len - head) / 4;
+  float4* o4 = reinterpret_cast<float4*>(o + head);
+  for (int i = lane; i < n4; i += 64) o4[i] = make_float4(v, v, v, v);
+  const int t0 = head + n4 * 4;
+  if (lane < len - t0) o[t0 + lane] = v;
+}
+template <int NWAVES>
+__global__ void k_wave_run128(float* out, int cc) {
+  const int ng = D / cc;
+  int id = blockIdx.x;
+  const int g = id % ng; id /= ng; const int j = id % NB; const int b = id / NB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int y0 = j * ROWS;
+  const int rows = y0 + ROWS <= H ? ROWS : H - y0;
+  for (int c = g * cc + wave; c < (g + 1) * cc; c += NWAVES)
+    write_run128(out + (((size_t)b * D + c) * H + y0) * W, rows * W, lane, (float)c);
+}
+
 // wave per run; workgroup of NWAVES waves = (image, band, group of CC channels), waves stride the channels.
 // ORDER 0: linear block id -> (band fastest, channel group, image); 1: (channel group fastest, band, image)
 template <int NWAVES, int ORDER>
@@ -133,6 +157,14 @@ int main() {
     run(nm, [&] { hipLaunchKernelGGL((k_rows<1>), dim3(grid), dim3(384), 0, 0, out, cc); });
     snprintf(nm, sizeof nm, "wave rows (dword, no staging), 4 waves, %3d ch/WG, band fastest", cc);
     run(nm, [&] { hipLaunchKernelGGL((k_wave_rows<4, 0>), dim3(grid), dim3(256), 0, 0, out, cc); });
+  }
+  for (int cc : {32, 16}) {
+    char nm[96];
+    const unsigned grid = (unsigned)(NB * (D / cc) * B);
+    snprintf(nm, sizeof nm, "wave per run, 128-byte aligned body, 4 waves, %3d ch/WG, cg fastest", cc);
+    run(nm, [&] { hipLaunchKernelGGL((k_wave_run128<4>), dim3(grid), dim3(256), 0, 0, out, cc); });
+    snprintf(nm, sizeof nm, "wave per run, 16-byte aligned body,  4 waves, %3d ch/WG, cg fastest", cc);
+    run(nm, [&] { hipLaunchKernelGGL((k_wave_run<4, 1>), dim3(grid), dim3(256), 0, 0, out, cc); });
   }
   run("workgroup per channel plane, 4 waves", [&] { hipLaunchKernelGGL((k_plane<4>), dim3(B * D), dim3(256), 0, 0, out); });
   run("workgroup per channel plane, 8 waves", [&] { hipLaunchKernelGGL((k_plane<8>), dim3(B * D), dim3(512), 0, 0, out); });
