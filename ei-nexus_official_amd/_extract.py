@@ -213,12 +213,13 @@ class ExtractorEngine:
         det.cap, det.padded, det.pads = cap, (Hp, Wp), pads
         bf.det = det
         bf.sparse_desc = e(B, cap, D)
-        ws = e(L.einx_extract_ws_bytes(h, B, H, W, cap, nms_iters), dt=torch.uint8)
+        nws = int(L.einx_extract_ws_bytes(h, B, H, W, cap, int(nms_iters)))
+        ws = e(nws, dt=torch.uint8)
         m8 = _mask_u8(mask, H, W)
         P = N._ptr
         out = _lib.ExtractOut(P(bf.feats), P(bf.logits), P(bf.raw), P(bf.prob), P(bf.score), P(bf.coarse), P(bf.raw_cl), P(det.nms),
                               P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap)
-        _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), ctypes.byref(out), N._stream(x)), "einx_extract")
+        _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), nws, ctypes.byref(out), N._stream(x)), "einx_extract")
         if dense:
             w0, w1, h0, h1 = pads
             if self.cell == 8:

@@ -44,7 +44,7 @@ class ExtractOut(ctypes.Structure):
 
 class MetricParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("B", "cap0", "cap1", "D", "cols", "H0", "W0", "H1", "W1", "kp_yx", "n_mma", "n_vdd")] + \
-               [("mma_thr", c_float * 4), ("vdd_thr", c_float * 4)]
+               [("mma_thr", c_float * 4), ("vdd_thr", c_float * 4), ("rep_nan_if_empty", ctypes.c_int32)]
 
 
 class LgLayer(ctypes.Structure):
@@ -71,7 +71,7 @@ SIGNATURES = {
     "einx_extractor_destroy": (None, [c_void_p]),
     "einx_extract_shapes": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(ExtractShapes)]),
     "einx_extract_ws_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
-    "einx_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(ExtractOut), c_void_p]),
+    "einx_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, ctypes.POINTER(ExtractOut), c_void_p]),
     "einx_conv_last_kernel": (c_char_p, []),
     "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

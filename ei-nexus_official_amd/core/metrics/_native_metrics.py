@@ -15,7 +15,7 @@ def metric_names(mma_thr=(1, 3), vdd_thr=(1, 3), prefix_vdd="VDD"):
 
 
 def pair_metrics(kpts0, desc0, n, kpts1, desc1, m, mk0, mk1, nmatch, size0, size1, homography=None, mma_thr=(1, 3), vdd_thr=(1, 3),
-                 ordering="yx"):
+                 ordering="yx", rep_nan_if_empty=False):
     """All tensors on the device: kpts [B,cap,3], desc [B,cap,D], counts int32 [B], matched keypoints
     [B,cap0,cols] + nmatch.  Returns float64 [B, 1+len(mma_thr)+3*len(vdd_thr)] (see metric_names)."""
     B, cap0, _ = kpts0.shape
@@ -25,6 +25,7 @@ def pair_metrics(kpts0, desc0, n, kpts1, desc1, m, mk0, mk1, nmatch, size0, size
     p.H0, p.W0, p.H1, p.W1 = int(size0[0]), int(size0[1]), int(size1[0]), int(size1[1])
     p.kp_yx = int(ordering == "yx")
     p.n_mma, p.n_vdd = len(mma_thr), len(vdd_thr)
+    p.rep_nan_if_empty = int(bool(rep_nan_if_empty))
     for i, t in enumerate(mma_thr):
         p.mma_thr[i] = float(t)
     for i, t in enumerate(vdd_thr):
@@ -55,7 +56,8 @@ def _pad3(k):
     return torch.cat([k, k.new_zeros(k.shape[0], 3 - k.shape[-1])], 1)
 
 
-def single_pair(points1, points2, desc1, desc2, matched1, matched2, size0, size1, homography, mma_thr, vdd_thr, ordering="yx"):
+def single_pair(points1, points2, desc1, desc2, matched1, matched2, size0, size1, homography, mma_thr, vdd_thr, ordering="yx",
+                rep_nan_if_empty=False):
     """update_one-style entry: per-pair tensors of any length -> dict of python floats."""
     dev = points1.device
     k0, k1 = _pad3(points1.float())[None].contiguous(), _pad3(points2.float())[None].contiguous()
@@ -75,5 +77,5 @@ def single_pair(points1, points2, desc1, desc2, matched1, matched2, size0, size1
     cnt = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)  # noqa: E731
     hom = None if homography is None else homography.reshape(1, 3, 3)
     out = pair_metrics(k0, d0, cnt(points1.shape[0]), k1, d1, cnt(points2.shape[0]), mk0, mk1, cnt(M), size0, size1, hom, mma_thr, vdd_thr,
-                       ordering)
+                       ordering, rep_nan_if_empty=rep_nan_if_empty)
     return dict(zip(metric_names(mma_thr, vdd_thr), out[0].tolist()))

@@ -8,7 +8,8 @@ from ._native_metrics import single_pair
 class Repeatability:
     """(count1 + count2) / (N + M) of mutual nearest warped keypoints within `distance_thresh`
     (keypoints_metrics.py:54-157).  The same neighbour pass as ValidDescriptorsDistance's repeatability
-    (identical whenever either image has keypoints; with none on both sides the reference emits no entry).
+    (identical whenever either image keeps a keypoint after the visibility filter; with none on both sides the reference
+    emits no entry -- the kernel marks that case with NaN (`rep_nan_if_empty`) and the entry is dropped here).
     ordering "xy": rows are (x, y); "yx": rows are (y, x) -- note the opposite convention of
     ValidDescriptorsDistance (keypoints_metrics.py:86-91 vs :193-198)."""
 
@@ -24,8 +25,9 @@ class Repeatability:
         if points1.shape[0] + points2.shape[0] == 0:
             return {}
         r = single_pair(points1, points2, None, None, None, None, img1_shape, img2_shape, homography, (), (self.distance_thresh,),
-                        ordering=self.ordering)
-        return {self.metric_name: r[f"VDD_Repeatability@{self.distance_thresh}"]}
+                        ordering=self.ordering, rep_nan_if_empty=True)
+        v = r[f"VDD_Repeatability@{self.distance_thresh}"]
+        return {} if v != v else {self.metric_name: v}  # NaN: original_num + warped_num == 0 (keypoints_metrics.py:126)
 
     @torch.no_grad()
     def update_batch(self, points1, points2, img1_shape, img2_shape, homography):

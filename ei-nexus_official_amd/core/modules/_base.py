@@ -49,17 +49,20 @@ class NativeExtractor(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _signature(self):
-        """(storage, version) of every parameter and buffer: in-place edits (`p.data.copy_`, optimiser
-        steps, `load_state_dict`) bump `_version`, `.to()` changes the storage.  The flat tensor list is cached (walking the
-        module tree costs 50-450 us per call); `_apply`, `load_state_dict` and `refresh()` drop it -- call `refresh()` after
-        REPLACING a Parameter object."""
+        """(storage, version) of every parameter and buffer: in-place edits made THROUGH the parameter (`with no_grad():
+        p.add_(..)` / `p.copy_(..)`, optimiser steps, `load_state_dict`) bump `p._version`, `.to()` changes the storage.
+        NOT detected: edits through `p.data` (`p.data.copy_(w)`, `p.data.mul_(..)`): `.data` is an alias with its OWN version
+        counter, so `p._version` stays put -- call `refresh()` after those, and after REPLACING a Parameter object
+        (tests/test_host_cpu.py::test_data_alias_edits_need_refresh).  The flat tensor list is cached (walking the module
+        tree costs 50-450 us per call); `_apply`, `load_state_dict` and `refresh()` drop it."""
         ts = self._sig_tensors
         if ts is None:
             ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
         return tuple((t.data_ptr(), t._version) for t in ts)
 
     def refresh(self):
-        """Call after editing parameters in place (weights or descriptor_scale_factor) or replacing Parameter objects."""
+        """Drop the kernel-native weight images.  REQUIRED after editing parameters through `.data` or replacing Parameter
+        objects; harmless otherwise (everything else is detected by `_signature`)."""
         self._engine = self._scale_host = self._sig_tensors = None
 
     def _layer(self, block, pool=False):

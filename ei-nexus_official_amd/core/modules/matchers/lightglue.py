@@ -127,6 +127,8 @@ class LightGlue(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def refresh(self):
+        """Drop the packed / folded weight images.  REQUIRED after edits through `p.data` (an alias with its own version
+        counter: `p._version`, which `_pack` keys on, does not move) or after replacing Parameter objects."""
         self._packed = self._sig_tensors = None
 
     def _pack(self):

@@ -32,15 +32,21 @@ struct ProfRec {
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
 volatile int g_prof_on = 0;
+int g_prof_gen = 0;  // bumped whenever g_prof_recs is cleared: a scope that straddles einx_profile_enable must not touch a stranger's record
 }  // namespace
 
 EinxProfScope::EinxProfScope(const char* name, hipStream_t s) : stream_(s), idx_(-1) {
   if (!g_prof_on) return;
   ProfRec r;
   r.name = name;
-  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  if (hipEventCreate(&r.e0) != hipSuccess) return;
+  if (hipEventCreate(&r.e1) != hipSuccess) {
+    (void)hipEventDestroy(r.e0);
+    return;
+  }
   (void)hipEventRecord(r.e0, s);
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  gen_ = g_prof_gen;
   idx_ = (int)g_prof_recs.size();
   g_prof_recs.push_back(r);
 }
@@ -48,7 +54,7 @@ EinxProfScope::EinxProfScope(const char* name, hipStream_t s) : stream_(s), idx_
 EinxProfScope::~EinxProfScope() {
   if (idx_ < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (idx_ < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx_].e1, stream_);
+  if (gen_ == g_prof_gen && idx_ < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx_].e1, stream_);
 }
 
 EINX_EXPORT int einx_profile_enable(int on) {
@@ -58,6 +64,7 @@ EINX_EXPORT int einx_profile_enable(int on) {
     (void)hipEventDestroy(r.e1);
   }
   g_prof_recs.clear();
+  ++g_prof_gen;
   g_prof_on = on ? 1 : 0;
   return EINX_OK;
 }

@@ -438,6 +438,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_pass4_kernel(const float* src
 // earlier in this launch); stores are complete (vmcnt(0) + barrier) before the next pass reads them.
 // ------------------------------------------------------------------------------------------
 constexpr int NMS_FIN_MAXT = 2048;  // tiles tracked individually; larger maps revisit every tile
+// One workgroup finishes one image, so its time is passes x (tiles it revisits): bounded here (a 264x352 map of 8 score
+// levels needs 25 passes).  Beyond the bound `not_converged` stays raised and the caller's retry (a larger wide-pass budget,
+// then this finisher again) takes over, as for the other radii -- the stream never stalls on one pathological image.
+constexpr int kNmsFinishMaxPasses = 256;
 __global__ __launch_bounds__(NMS_THREADS) void nms4_finish_kernel(float* bufA, float* bufB, int Hp, int Wp, int tilesX, int tilesY,
                                                                   int32_t* flags, int nIt, int max_passes) {
   __shared__ Nms4Smem sm;
@@ -973,7 +977,7 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
       float* other = last == buf0 ? buf1 : buf0;
       EINX_PROF("nms4_finish_kernel", s);
       hipLaunchKernelGGL(nms4_finish_kernel, dim3((unsigned)p->B), dim3(NMS_THREADS), 0, s, last, other, p->Hp, p->Wp, tilesX, tilesY, flags, nIt,
-                         1 << 20);
+                         kNmsFinishMaxPasses);
       EINX_CHECK_LAUNCH();
     }
   }

@@ -37,6 +37,7 @@ class EinxProfScope {
  private:
   hipStream_t stream_;
   int idx_;
+  int gen_ = 0;
 };
 
 #define EINX_PROF(name, stream) EinxProfScope einx_prof_scope_(name, (hipStream_t)(stream))

@@ -239,7 +239,9 @@ struct PinnedOffsets {
     if (done) (void)hipEventDestroy(done);
   }
 };
-thread_local PinnedOffsets g_offs;
+// one staging state per (host thread, device): an event can only be recorded on a stream of the device it was created on
+constexpr int kMaxDev = 64;
+thread_local PinnedOffsets g_offs[kMaxDev];
 
 // copies the host offsets to the workspace and returns the largest per-sample event count (-1 on bad input)
 long long stage_offsets(const int64_t* offsets_host, int B, int H, int W, void* ws, hipStream_t s, int64_t** dev) {
@@ -252,14 +254,16 @@ long long stage_offsets(const int64_t* offsets_host, int B, int H, int W, void* 
   char* p = (char*)ws + (size_t)B * 32 + (size_t)B * H * W * sizeof(int32_t) + (size_t)B * 8;
   p = (char*)(((size_t)p + 7) & ~(size_t)7);
   *dev = (int64_t*)p;
-  PinnedOffsets& st = g_offs;
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= kMaxDev) return -2;
+  PinnedOffsets& st = g_offs[devid];
   const size_t need = (size_t)B + 1;
   if (st.done && hipEventSynchronize(st.done) != hipSuccess) return -2;  // the previous call's copy has left the buffer
   if (need > st.cap) {
     if (st.p) (void)hipHostFree(st.p);
     st.p = nullptr;
     st.cap = 0;
-    if (hipHostMalloc((void**)&st.p, need * 2 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) return -2;
+    if (hipHostMalloc((void**)&st.p, need * 2 * sizeof(int64_t), hipHostMallocPortable) != hipSuccess) return -2;
     st.cap = need * 2;
   }
   if (!st.done && hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return -2;

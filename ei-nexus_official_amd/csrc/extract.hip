@@ -148,11 +148,15 @@ EINX_EXPORT int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_
   return EINX_OK;
 }
 
+// nms_iters <= 0 means "the default pass budget" in BOTH the size query and the call (the detector's per-image flag array
+// is B x nms_iters words of the workspace)
+static inline int nms_budget(int nms_iters) { return nms_iters > 0 ? nms_iters : 8; }
+
 EINX_EXPORT size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int cap, int nms_iters) {
   Plan pl;
   if (!e || B <= 0 || !make_plan(e, H, W, &pl)) return 0;
   einx_detect_params p;
-  detect_params(e, pl, B, H, W, cap > 0 ? cap : 1, nms_iters > 0 ? nms_iters : 1, &p);
+  detect_params(e, pl, B, H, W, cap > 0 ? cap : 1, nms_budget(nms_iters), &p);
   size_t bytes = 0;
   bytes += align256(pl.buf_elems[0] * B * sizeof(float)) + align256(pl.buf_elems[1] * B * sizeof(float));
   bytes += align256(pl.head_elems * B * sizeof(float));
@@ -161,7 +165,7 @@ EINX_EXPORT size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, 
 }
 
 EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
-                             const einx_extract_out* o, void* stream) {
+                             size_t ws_bytes, const einx_extract_out* o, void* stream) {
   EINX_CHECK_ARG(e && in && ws && o, "null pointer");
   EINX_CHECK_ARG(o->feats && o->logits && o->raw && o->prob && o->score && o->positions && o->indices && o->counts && o->thr &&
                      o->not_converged && o->sparse_desc,
@@ -170,6 +174,7 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
   Plan pl;
   EINX_CHECK_ARG(make_plan(e, H, W, &pl), "image size does not fit the network's pooling / cell size");
   EINX_CHECK_ARG(e->d.cell == 1 || (o->coarse && o->raw_cl), "cell-8 networks need the coarse / raw_cl outputs");
+  EINX_CHECK_ARG(ws_bytes >= einx_extract_ws_bytes(e, B, H, W, o->cap, nms_iters), "workspace smaller than einx_extract_ws_bytes for these arguments");
   char* p = (char*)ws;
   float* buf[2];
   buf[0] = (float*)p;
@@ -223,7 +228,7 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
                       stream);
   if (rc) return rc;
   einx_detect_params dp;
-  detect_params(e, pl, B, H, W, o->cap, nms_iters > 0 ? nms_iters : 8, &dp);
+  detect_params(e, pl, B, H, W, o->cap, nms_budget(nms_iters), &dp);
   rc = einx_detect(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, stream);
   if (rc) return rc;
   const bool bilinear = e->d.cell == 8;

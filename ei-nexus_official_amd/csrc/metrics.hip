@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void metric_finalize_kernel(const MetArgs a) {
         vd = sd / c;  // 0/0 -> NaN exactly like the reference when nothing is within t
         ang = sa / c;
       }
+      if (a.p.rep_nan_if_empty && N1 + N2 == 0) rep = __longlong_as_double(0x7ff8000000000000LL);
       o[1 + a.p.n_mma + 3 * t + 0] = rep;
       o[1 + a.p.n_mma + 3 * t + 1] = vd;
       o[1 + a.p.n_mma + 3 * t + 2] = ang;

@@ -139,6 +139,7 @@ struct Outs {
   einx_extract_out o{};
   einx_extract_shapes_t sh{};
   void* ws = nullptr;
+  size_t ws_bytes = 0;
 };
 
 static Outs make_outs(const Net& n, int B, int H, int W) {
@@ -161,8 +162,8 @@ static Outs make_outs(const Net& n, int B, int H, int W) {
   r.o.not_converged = dalloc<int32_t>(B);
   r.o.sparse_desc = dalloc<float>((size_t)B * s.cap * s.desc_dim);
   r.o.cap = s.cap;
-  const size_t wsb = einx_extract_ws_bytes(n.h, B, H, W, s.cap, 8);
-  HIPCHK(hipMalloc(&r.ws, wsb));
+  r.ws_bytes = einx_extract_ws_bytes(n.h, B, H, W, s.cap, 8);
+  HIPCHK(hipMalloc(&r.ws, r.ws_bytes));
   return r;
 }
 
@@ -195,8 +196,8 @@ int main(int argc, char** argv) {
   HIPCHK(hipMemcpy(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
   Outs eo = make_outs(ev_net, B, H, W), io = make_outs(im_net, B, H, W);
   // ---- the hot path: two einx_extract calls + the matcher, all enqueued on one stream, no host synchronisation in between
-  EINXCHK(einx_extract(ev_net.h, d_ev, d_mask, B, H, W, 8, eo.ws, &eo.o, st));
-  EINXCHK(einx_extract(im_net.h, d_img, nullptr, B, H, W, 8, io.ws, &io.o, st));
+  EINXCHK(einx_extract(ev_net.h, d_ev, d_mask, B, H, W, 8, eo.ws, eo.ws_bytes, &eo.o, st));
+  EINXCHK(einx_extract(im_net.h, d_img, nullptr, B, H, W, 8, io.ws, io.ws_bytes, &io.o, st));
   const int cap0 = eo.sh.cap, cap1 = io.sh.cap, D = eo.sh.desc_dim;
   void* mws = nullptr;
   HIPCHK(hipMalloc(&mws, einx_mnn_ws_bytes(B, cap0, cap1)));

@@ -323,10 +323,13 @@ typedef struct einx_extract_out {
 einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
 void einx_extractor_destroy(einx_extractor* e);
 int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* shapes);
+/* nms_iters: NMS pass budget per call (see einx_detect); <= 0 selects the default (8) in BOTH functions below.  The
+ * workspace size depends on it (B x nms_iters convergence flags), so query and call must pass the same value. */
 size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int cap, int nms_iters);
-/* in [B,cin,H,W] (modified in place only when input_div is set); mask [B,1,H,W] uint8 or NULL */
+/* in [B,cin,H,W] (modified in place only when input_div is set); mask [B,1,H,W] uint8 or NULL;
+ * ws: device scratch, ws_bytes >= einx_extract_ws_bytes(e, B, H, W, out->cap, nms_iters) (checked) */
 int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
-                 const einx_extract_out* out, void* stream);
+                 size_t ws_bytes, const einx_extract_out* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics of the reference's test harness (the step after the path)
@@ -345,6 +348,8 @@ typedef struct einx_metric_params {
   int32_t n_mma, n_vdd;
   float mma_thr[4];
   float vdd_thr[4];
+  int32_t rep_nan_if_empty; /* 1: Repeatability@t = NaN when NEITHER image keeps a keypoint after the visibility filter
+                               (class Repeatability emits no entry then, keypoints_metrics.py:126-128; VDD reports 0) */
 } einx_metric_params;
 size_t einx_metrics_ws_bytes(const einx_metric_params* p);
 int einx_pair_metrics(const einx_metric_params* p, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,

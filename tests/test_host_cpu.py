@@ -104,11 +104,32 @@ def test_parent_load_state_dict_invalidates_native_weight_images():
     ext._engine, ext._scale_host, lg._packed = sentinel, 1.0, sentinel
     model.load_state_dict(model.state_dict())
     assert ext._engine is None and ext._scale_host is None and lg._packed is None
-    # in-place parameter edits (optimiser steps, p.data.copy_) change the signature the caches are keyed on
+    # in-place edits made through the parameter (optimiser steps, `with no_grad(): p.add_()`) change the signature
     ev = model.event_extractor.extractor
     s0 = ev._signature()
     with torch.no_grad():
         next(ev.parameters()).add_(1.0)
+    assert ev._signature() != s0
+
+
+def test_data_alias_edits_need_refresh():
+    """`p.data` is an alias with its own version counter, so `p.data.copy_()` / `p.data.mul_()` leave `p._version`
+    (what the weight-image caches key on) unchanged.  Documented contract: call refresh() after such edits; refresh() (and a
+    parent's load_state_dict) drops every native image."""
+    model = pkg.EIM(pkg.default_config("SP_LG"), device="cpu").eval()
+    ev, lg = model.event_extractor.extractor, model.matcher.matcher
+    p = next(ev.parameters())
+    s0, v0 = ev._signature(), p._version
+    p.data.mul_(2.0)
+    p.data.copy_(torch.zeros_like(p))
+    assert p._version == v0 and ev._signature() == s0  # torch semantics the contract rests on (if this ever changes, auto-detect)
+    sentinel = object()
+    ev._engine, ev._scale_host, lg._packed = sentinel, 1.0, sentinel
+    ev.refresh()
+    lg.refresh()
+    assert ev._engine is None and ev._scale_host is None and lg._packed is None and lg._sig_tensors is None
+    with torch.no_grad():
+        p.add_(1.0)  # the supported in-place form IS detected
     assert ev._signature() != s0
 
 

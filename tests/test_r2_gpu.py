@@ -243,6 +243,13 @@ def test_repeatability_class_vs_reference(name):
     both = R.update_batch([_t(p0), _t(p0)], [_t(p1), _t(p1)], (260, 346), (260, 346), torch.stack([Hm, Hm]).to(DEV))
     assert abs(both["r"] - float(_Z[f"{name}.values"][1])) < 1e-6
     assert km.Repeatability("r", 3).update_one(_t(p0[:0]), _t(p1[:0]), (260, 346), (260, 346), Hm.to(DEV)) == {}
+    # the reference omits the entry when no keypoint of EITHER image survives keep_true_points
+    # (original_num + warped_num == 0, keypoints_metrics.py:126-128), not only when the inputs are empty: a translation by
+    # 1000 px moves every point out of both frames; update_batch then averages the other pairs only
+    far = torch.tensor([[1.0, 0.0, 1000.0], [0.0, 1.0, 1000.0], [0.0, 0.0, 1.0]])
+    assert km.Repeatability("r", 3, ordering=c["ordering"]).update_one(_t(p0), _t(p1), (260, 346), (260, 346), far.to(DEV)) == {}
+    mixed = R.update_batch([_t(p0), _t(p0)], [_t(p1), _t(p1)], (260, 346), (260, 346), torch.stack([Hm, far]).to(DEV))
+    assert abs(mixed["r"] - float(_Z[f"{name}.values"][1])) < 1e-6
 
 
 # ------------------------------------------------------------------ the documented drop-in: install_as_core()
