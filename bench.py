@@ -52,6 +52,7 @@ WORKLOADS = {
     "sp_mnn": ("SP_MNN", 32, "346x260 5-bin event voxel + gray image, VGG(event)+SuperPoint(image) extractors, MNN matcher, k=1024"),
     "silk_mnn": ("SiLK_MNN", 32, "346x260, VGG_NP(event)+SiLK(image) extractors, MNN matcher, k=1024"),
     "sp_lg": ("SP_LG", 64, "346x260, VGG(event)+SuperPoint(image) extractors, LightGlue matcher, k=1024"),
+    "silk_lg": ("SiLK_LG", 32, "346x260, VGG_NP(event)+SiLK(image) extractors, LightGlue matcher (128-d input_proj), k=1024"),
 }
 
 
@@ -479,7 +480,7 @@ def stage_rooflines(wl, lg_wl=None):
         wl.step()
     single_stream_forward(wl)
     prof = library_profile(pkg, lambda: single_stream_forward(wl))
-    if wl.config != "silk_mnn":
+    if not wl.config.startswith("silk"):
         conv_ms = sum(ms for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel"))
         conv_calls = sum(c for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel"))
         fl = sp_pair_flops(wl.ce) * B
@@ -492,7 +493,7 @@ def stage_rooflines(wl, lg_wl=None):
                         "note": "169 FLOP/B: compute-bound, the HBM fraction is reported because the north_star names it"})
     if "mnn_tile_kernel<0>" in prof:
         c, ms = prof["mnn_tile_kernel<0>"]
-        D = 128 if wl.config == "silk_mnn" else 256
+        D = 128 if wl.config.startswith("silk") else 256
         fl = 2.0 * 1024 * 1024 * D * B * c
         out.append({"stage": "descriptor-correlation GEMM + fused arg-max (mnn_tile_kernel<0>)", "ms": round(ms / c, 4), "bound": "mfma",
                     "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -562,7 +563,7 @@ def cpu_baseline_and_verify(wl, args, gpu_out):
     import numpy as np
     from oracle import oracle as orc
     cfg, B = wl.cfg, wl.B
-    nb = args.cpu_pairs if args.cpu_pairs else {"sp_mnn": 32, "sp_lg": 4, "silk_mnn": 4}.get(wl.config, 4)
+    nb = args.cpu_pairs if args.cpu_pairs else {"sp_mnn": 32, "sp_lg": 4, "silk_mnn": 4, "silk_lg": 2}.get(wl.config, 4)
     nb = max(1, min(nb, B))
     et, it = cfg.event_extractor.type, cfg.image_extractor.type
     escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
@@ -767,6 +768,9 @@ def run_rank(args):
             w = leg("silk_mnn", 32, steps=10, note="BASELINE configs[2]")
             del w
             torch.cuda.empty_cache()
+            w = leg("silk_lg", 32, steps=5, note="configs/model/test/EI_SiLK_LG.yaml (SiLK family + LightGlue, 128-d descriptors through input_proj)")
+            del w
+            torch.cuda.empty_cache()
             # the dict an unmodified reference caller gets: dense descriptor maps + dense positions + log_assignment
             w = Workload(pkg, dev, "sp_mnn", 32, dense=True, log_assignment=True)
             sec, mm = w.timed(10)
@@ -792,7 +796,7 @@ def run_rank(args):
             del w
             torch.cuda.empty_cache()
         else:
-            stages = stage_rooflines(wl, wl if args.config == "sp_lg" else None)
+            stages = stage_rooflines(wl, wl if args.config in ("sp_lg", "silk_lg") else None)
 
     if rank == 0:
         wl_desc = f"B{B} " + WORKLOADS[args.config][2]

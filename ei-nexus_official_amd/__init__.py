@@ -29,7 +29,7 @@ from .core.modules.Extractors import EventKeypointsExtractor, ImageKeypointsExtr
 from .core.modules.Matchers import Matcher  # noqa: E402
 from .core.modules.matchers.MNN import NearestNeighborMatcher  # noqa: E402
 from .core.modules.matchers.lightglue import LightGlue  # noqa: E402
-from .harness import SameTimeEvaluator  # noqa: E402
+from .harness import DifferentTimeEvaluator, SameTimeEvaluator  # noqa: E402
 
 
 
@@ -49,5 +49,5 @@ def install_as_core():
     return _core
 
 
-__all__ = ["install_as_core", "SameTimeEvaluator", "EIM", "ImageImageMatcher", "build_model", "EventKeypointsExtractor", "ImageKeypointsExtractor", "Matcher",
+__all__ = ["install_as_core", "SameTimeEvaluator", "DifferentTimeEvaluator", "EIM", "ImageImageMatcher", "build_model", "EventKeypointsExtractor", "ImageKeypointsExtractor", "Matcher",
            "NearestNeighborMatcher", "LightGlue", "default_config", "AttrDict", "native"]

@@ -1,11 +1,12 @@
-"""Evaluation harness with the call pattern of the reference's test_events-image_same-time.py:130-283
-(SURVEY.md section 8a row H), entirely on the device:
+"""Evaluation harnesses with the call patterns of the reference's test_events-image_same-time.py:130-283
+ and test_events-image_different_time.py:187-264, entirely on the device:
 
     raw events --(events.hip)--> voxel grid + events mask
                --(EIM: conv/detect/desc/mnn|lightglue kernels)--> keypoints, descriptors, matches
                --(metrics.hip)--> MR, MMA@1/3, VDD@1/3 per pair  --> means (all-reduced across ranks)
 
-HomographyEstimation / RelativePoseEstimation (cv2 RANSAC on the CPU in the reference) are out of scope.
+HomographyEstimation / RelativePoseEstimation (cv2 RANSAC on the CPU in the reference) are out of scope;
+DifferentTimeEvaluator hands over exactly what the reference passes to them.
 """
 import torch
 
@@ -51,3 +52,24 @@ class SameTimeEvaluator:
             torch.distributed.all_reduce(c)
         mean = (s / c.clamp_min(1)).tolist()
         return dict(zip(self.names, mean))
+
+
+class DifferentTimeEvaluator(SameTimeEvaluator):
+    """Call pattern of test_events-image_different_time.py:187-264: the events come from frame i, the image from a LATER
+    frame j of the sequence, and the two views are related by a known motion instead of the identity.
+
+    * `step(events_list, images, homography)`: as SameTimeEvaluator.step, with the image-0 -> image-1 homography [B,3,3]
+      of the pair (planar scenes / pure rotations; None = identity) going into MMA@t and VDD@t (metrics.hip warps the
+      keypoints exactly like core/metrics/util.py:warp_points).
+    * `pose_inputs(matches, b)`: what the reference feeds RelativePoseEstimation.update_one for pair b
+      (`matches["matched_kpts0"][b]`, `matches["matched_kpts1"][b]`, :251-257), plus the (x, y) views of
+      test_events-image_different_time.py:217-224 (`[..., :2]`, flipped when the extractor's ordering is "yx").  The pose
+      solver itself (cv2.findEssentialMat / recoverPose on the CPU) is outside this build.
+    """
+
+    def pose_inputs(self, matches, b=0):
+        mk0, mk1 = matches["matched_kpts0"][b], matches["matched_kpts1"][b]
+        xy0, xy1 = mk0[..., :2], mk1[..., :2]
+        if self.model.event_extractor.extractor.ordering == "yx":
+            xy0, xy1 = torch.flip(xy0, dims=[-1]), torch.flip(xy1, dims=[-1])
+        return {"matched_kpts0": mk0, "matched_kpts1": mk1, "matched_xy0": xy0, "matched_xy1": xy1}

@@ -18,3 +18,27 @@ def oracle():
     from oracle import oracle as orc
     orc.lib()
     return orc
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured float errors of the tolerance-based comparisons (helpers.close_and_record): printed and kept as
+    gpurun_out/parity_errors.json (the GPU box merges gpurun_out/ back)."""
+    import json
+    from helpers import recorded_errors
+    errs = recorded_errors()
+    if not errs:
+        return
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_errors.json"), "w") as f:
+            json.dump(errs, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    tr = session.config.pluginmanager.get_plugin("terminalreporter")
+    if tr is not None:
+        tr.write_line("")
+        tr.write_line("measured max |error| of the tolerance-based comparisons (tag: measured / atol, largest reference magnitude):")
+        for k in sorted(errs):
+            e = errs[k]
+            tr.write_line(f"  {k}: {e['max_abs_err']:.3e} / {e['atol']:.1e}   (|ref| <= {e['max_abs_ref']:.3g}, {e['n']} values)")

@@ -369,6 +369,8 @@ E2E_CASES = [
     dict(name="sp_mnn16", event_type="vgg", image_type="superpointv1", matcher="MNN", ce=16, B=1, wseed=12, iseed=22),
     dict(name="sp_lg", event_type="vgg", image_type="superpointv1", matcher="LightGlue", ce=5, B=1, wseed=13, iseed=23),
     dict(name="silk_mnn", event_type="vgg_np", image_type="silk", matcher="MNN", ce=5, B=1, wseed=14, iseed=24),
+    # configs/model/test/EI_SiLK_LG.yaml: 128-d SiLK descriptors through LightGlue's input_proj (lightglue.py:451-454)
+    dict(name="silk_lg", event_type="vgg_np", image_type="silk", matcher="LightGlue", ce=5, B=1, wseed=15, iseed=25),
 ]
 
 

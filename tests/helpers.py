@@ -198,3 +198,28 @@ def rep_inputs(c):
     if c["ordering"] == "xy":
         k0, k1 = k0[:, [1, 0, 2]].copy(), k1[:, [1, 0, 2]].copy()
     return k0[:, :2].copy(), k1[:, :2].copy()
+
+
+# ------------------------------------------------------------------ measured float errors
+_ERRORS = {}
+
+
+def close_and_record(tag, got, exp, atol, rtol=0.0):
+    """np.testing.assert_allclose that also RECORDS the measured max |got - exp| (and the largest |exp| it was measured
+    against) under `tag`.  tests/conftest.py prints the table at the end of the session and writes it to
+    gpurun_out/parity_errors.json, so the tolerances in the tests can be read next to what was actually measured."""
+    got = np.asarray(got, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (tag, got.shape, exp.shape)
+    fin = np.isfinite(exp) & np.isfinite(got)
+    err = float(np.abs(got - exp)[fin].max()) if fin.any() else 0.0
+    rec = _ERRORS.setdefault(tag, {"max_abs_err": 0.0, "max_abs_ref": 0.0, "atol": atol, "rtol": rtol, "n": 0})
+    rec["max_abs_err"] = max(rec["max_abs_err"], err)
+    rec["max_abs_ref"] = max(rec["max_abs_ref"], float(np.abs(exp[fin]).max()) if fin.any() else 0.0)
+    rec["n"] += int(got.size)
+    np.testing.assert_allclose(got, exp, atol=atol, rtol=rtol, err_msg=tag)
+    return err
+
+
+def recorded_errors():
+    return _ERRORS

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, load_pkg, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth
+from helpers import close_and_record, Golden, load_pkg, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth
 
 pytestmark = pytest.mark.gpu
 pkg = load_pkg()
@@ -450,6 +450,14 @@ def test_properties_at_bench_batch():
 
 # ------------------------------------------------------------------ LightGlue
 LG = Golden("lg")
+# Float tolerances of the LightGlue path, next to what is MEASURED (helpers.close_and_record prints the maxima at the end
+# of the session; profiles/r03_parity_errors.json keeps the round's table):
+#   matching_scores, ref_descriptors, matched keypoints: the north_star's 1e-4 absolute (measured <= 2.1e-5 / 1.1e-5)
+#   log_assignment: does NOT meet 1e-4.  Measured maximum 3.8e-4 absolute (on entries of magnitude 5..74, not proportional to
+#   the magnitude: 1.7e-4 at |la| = 5.3, 3.8e-4 at 50.7) after nine transformer layers summed in another order (flash-style
+#   attention, fused projections) than the reference's BLAS; the CPU oracle differs from the reference by as much
+#   (tests/test_oracle_golden.py).  Bound used: 5e-4 absolute, no relative term.  Match ASSIGNMENTS are compared exactly.
+LA_ATOL, LA_RTOL = 5e-4, 0.0
 
 
 def _lg_model(c):
@@ -475,31 +483,32 @@ def test_lightglue_vs_golden(oracle, name):
     # bit-exact match assignments against the reference
     assert np.array_equal(_np(r["matches0"]), LG[f"{name}.matches0"])
     assert np.array_equal(_np(r["matches1"]), LG[f"{name}.matches1"])
-    np.testing.assert_allclose(_np(r["matching_scores0"]), LG[f"{name}.mscores0"], atol=FTOL)
-    np.testing.assert_allclose(_np(r["matching_scores1"]), LG[f"{name}.mscores1"], atol=FTOL)
+    close_and_record(f"lg.{name}.matching_scores0 vs reference", _np(r["matching_scores0"]), LG[f"{name}.mscores0"], atol=FTOL)
+    close_and_record(f"lg.{name}.matching_scores1 vs reference", _np(r["matching_scores1"]), LG[f"{name}.mscores1"], atol=FTOL)
     assert np.array_equal(_np(r["matched_kpts0"]), LG[f"{name}.matched_kpts0"])
     assert np.array_equal(_np(r["matched_kpts1"]), LG[f"{name}.matched_kpts1"])
     la = _np(r["log_assignment"])
     assert la.shape == (1, c["n"] + 1, c["m"] + 1)
     if f"{name}.la" in LG:
-        np.testing.assert_allclose(la, LG[f"{name}.la"], atol=2e-4, rtol=1e-4)
+        close_and_record(f"lg.{name}.log_assignment vs reference", la, LG[f"{name}.la"], atol=LA_ATOL, rtol=LA_RTOL)
     else:
-        np.testing.assert_allclose(la[0, ::37, ::41], LG[f"{name}.la_probe"], atol=2e-4, rtol=1e-4)
+        close_and_record(f"lg.{name}.log_assignment vs reference", la[0, ::37, ::41], LG[f"{name}.la_probe"], atol=LA_ATOL, rtol=LA_RTOL)
     sn = max(1, c["n"] // 16)
     ref = _np(r["ref_descriptors0"])
     assert ref.shape == (1, 1, c["n"], 256)
-    np.testing.assert_allclose(ref[0, 0, ::sn, ::16], LG[f"{name}.ref_desc0_probe"], atol=FTOL, rtol=FTOL)
+    close_and_record(f"lg.{name}.ref_descriptors0 vs reference", ref[0, 0, ::sn, ::16], LG[f"{name}.ref_desc0_probe"], atol=FTOL)
     assert tuple(r["prune0"].shape) == (1, c["n"]) and float(r["prune0"][0, 0]) == 9.0
     if name != "full":
         exp = oracle.lightglue(sd, k0, d0, k1, d1)
         assert np.array_equal(_np(r["matches0"])[0], exp["matches0"])
-        np.testing.assert_allclose(la[0], exp["log_assignment"], atol=2e-4, rtol=1e-4)
-        np.testing.assert_allclose(ref[0, 0], exp["ref_descriptors0"], atol=FTOL, rtol=FTOL)
+        close_and_record(f"lg.{name}.log_assignment vs oracle", la[0], exp["log_assignment"], atol=LA_ATOL, rtol=LA_RTOL)
+        close_and_record(f"lg.{name}.ref_descriptors0 vs oracle", ref[0, 0], exp["ref_descriptors0"], atol=FTOL)
 
 
-def test_e2e_sp_lightglue(oracle):
-    from test_oracle_golden import _check_feats
-    name = "sp_lg"
+@pytest.mark.parametrize("name", ["sp_lg", "silk_lg"])
+def test_e2e_lightglue(oracle, name):
+    """EIM.forward with the LightGlue matcher at 346x260: SuperPoint-shaped 256-d descriptors, and the SiLK family's 128-d
+    descriptors through LightGlue's input_proj (configs/model/test/EI_SiLK_LG.yaml, lightglue.py:451-454)."""
     c = E2E.cases[name]
     model, sd = _build(c, E2E)
     for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
@@ -518,10 +527,14 @@ def test_e2e_sp_lightglue(oracle):
         for b in range(c["B"]):
             assert tuple(m[key][b].shape) == exp[b].shape  # [M,2] for LightGlue
             np.testing.assert_allclose(_np(m[key][b]), exp[b], atol=FTOL)
+    for key in ("matching_scores0", "matching_scores1"):
+        exp = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
+        for b in range(c["B"]):
+            close_and_record(f"e2e.{name}.{key} vs reference", _np(m[key][b])[0], exp[b], atol=FTOL)
     for b in range(c["B"]):
         la = _np(m["log_assignment"][b])
         assert list(la.shape) == E2E[f"{name}.m.la_shapes"][b].tolist()
-        np.testing.assert_allclose(la[0, ::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b], atol=5e-4, rtol=1e-4)
+        close_and_record(f"e2e.{name}.log_assignment vs reference", la[0, ::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b], atol=LA_ATOL, rtol=LA_RTOL)
 
 
 def test_detect_generic_path_dense_and_negative(oracle):
@@ -710,6 +723,53 @@ def test_same_time_harness_end_to_end(oracle):
     res = evalr.result()
     assert set(res) == {"MR", "MMA@1", "MMA@3", "VDD_Repeatability@1", "VDD_ValidDistance@1", "VDD_Angle@1", "VDD_Repeatability@3",
                         "VDD_ValidDistance@3", "VDD_Angle@3"}
+
+
+def test_different_time_harness_end_to_end(oracle):
+    """test_events-image_different_time.py:187-264: events of frame i, image of a later frame j, related by a known
+    (non-identity) homography per pair.  The evaluator's metric rows equal the oracle chain under the same homographies
+    (the metric arithmetic itself is pinned to the reference's classes under a non-identity H by metrics.npz / r2.npz), and
+    pose_inputs() hands over what the reference gives RelativePoseEstimation: the matched keypoint rows and their (x, y) views."""
+    from helpers import synth_raw_events
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 128
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sdn = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=33)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    H, W, B = 100, 124, 2
+    evs = [synth_raw_events(dict(seed=400 + b, n=6000, H=H, W=W, bins=5, frac=False, pneg=False)) for b in range(B)]  # frames i
+    img = synth.synth_image(91, B, H, W)                                                                                # frames j > i
+    homs = np.array([[1.02, 0.015, -3.0, -0.01, 0.98, 2.5, 1e-5, -2e-5, 1.0],
+                     [0.97, -0.02, 4.0, 0.03, 1.01, -1.5, -1e-5, 1e-5, 1.0]], np.float32).reshape(B, 3, 3)
+    evalr = pkg.DifferentTimeEvaluator(model, bins=5, resolution=(W, H))
+    rows, (ef, imf, m) = evalr.step(evs, _t(img), torch.from_numpy(homs).to(DEV))
+    rows = _np(rows)
+    grid = _np(evalr.last_inputs[0])
+    mask = np.stack([oracle.events_mask(e, (W, H)) for e in evs])[:, None]
+    oe = oracle.extractor_forward("vgg", sub_dict(sdn, "event_extractor.extractor."), grid.copy(), mask, top_k=128)
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sdn, "image_extractor.extractor."), img.copy(), None, top_k=128)
+    _assert_feats_equal_oracle(ef, oe)
+    _assert_feats_equal_oracle(imf, oi)
+    ident = []
+    for b in range(B):
+        r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
+        mk0, mk1 = oracle.matched_kpts(oe["sparse_positions"][b], oi["sparse_positions"][b], r["matches0"], 3)
+        args = (oe["sparse_positions"][b], oi["sparse_positions"][b], oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], mk0, mk1,
+                (H, W), (H, W))
+        np.testing.assert_allclose(rows[b], oracle.pair_metrics(*args, hom=homs[b]), atol=1e-6, rtol=1e-6, equal_nan=True)
+        ident.append(oracle.pair_metrics(*args))
+        p = evalr.pose_inputs(m, b)
+        assert np.array_equal(_np(p["matched_kpts0"]), mk0) and np.array_equal(_np(p["matched_kpts1"]), mk1)  # [M,3] rows (y, x, score)
+        assert model.event_extractor.extractor.ordering == "yx"
+        assert np.array_equal(_np(p["matched_xy0"]), mk0[:, 1::-1]) and np.array_equal(_np(p["matched_xy1"]), mk1[:, 1::-1])
+    # the homography really takes part: MR is motion-independent, the warped-distance metrics are not
+    ident = np.array(ident)
+    assert np.array_equal(rows[:, 0], ident[:, 0])
+    assert not np.allclose(np.nan_to_num(rows[:, 1:]), np.nan_to_num(ident[:, 1:]))
+    assert set(evalr.result()) == set(evalr.names)
 
 
 def test_lightglue_weight_folding_is_equivalent():

@@ -16,12 +16,13 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, load_pkg, r2_mnn_inputs, rep_inputs, sub_dict, synth, tie_map
+from helpers import GOLDEN, close_and_record, load_pkg, r2_mnn_inputs, rep_inputs, sub_dict, synth, tie_map
 
 pytestmark = pytest.mark.gpu
 pkg = load_pkg()
 DEV = "cuda:0"
 FTOL = 1e-4
+LA_ATOL, LA_RTOL = 5e-4, 0.0  # log_assignment: see tests/test_gpu_parity.py (measured 3.8e-4 at most; 1.8e-4 at B=64)
 
 _Z = np.load(os.path.join(GOLDEN, "r2.npz"))
 _META = json.loads(bytes(_Z["meta"]).decode())
@@ -131,10 +132,11 @@ def test_baseline_batch_sampled_pairs_vs_oracle_lightglue(oracle):
             assert len(bad) <= 2, f"pair {b}: {len(bad)} assignments differ"
             for i in bad:
                 row = np.sort(la[i, :-1])[::-1]
-                assert row[0] - row[1] < 5e-4, f"pair {b}: row {i} differs with margin {row[0] - row[1]}"
+                assert row[0] - row[1] < LA_ATOL + LA_RTOL * abs(row[0]), f"pair {b}: row {i} differs with margin {row[0] - row[1]}"
         gla = _np(m["log_assignment"][b])[0] if m["log_assignment"][b] is not None else None
         if gla is not None:
-            np.testing.assert_allclose(gla[::53, ::47], r["log_assignment"][::53, ::47], atol=5e-4, rtol=1e-4)
+            close_and_record("B64 sp_lg log_assignment vs oracle", gla[::53, ::47], r["log_assignment"][::53, ::47], atol=LA_ATOL, rtol=LA_RTOL)
+        close_and_record("B64 sp_lg matching_scores0 vs oracle", _np(m["matching_scores0"][b])[0], np.asarray(r["matching_scores0"]).reshape(-1), atol=1e-4)
 
 
 # ------------------------------------------------------------------ r2 fixtures: tie maps with survivors
