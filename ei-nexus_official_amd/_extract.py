@@ -148,7 +148,10 @@ class ExtractorEngine:
         self.backbone = []  # ConvLayer list
         self.det_head = []
         self.desc_head = []
-        self.nms_iters = 8
+        # wide NMS passes enqueued per forward (EINX_NMS_PASSES: tuning).  Measured: 4 instead of 8 at radius 4 leaves real work to
+        # nms4_finish_kernel (one workgroup per image walking 54 tiles per pass): B=1 0.84 -> 1.01 ms, B=32 3440 -> 3347 pairs/s
+        self.nms_base = int(os.environ.get("EINX_NMS_PASSES", "8"))
+        self.nms_iters = self.nms_base
         self._handle = None
         self._handle_key = None
         self._shapes = {}
@@ -257,12 +260,12 @@ class ExtractorEngine:
         return self.nms_iters
 
     def note_converged(self):
-        """A grown budget decays again: after 64 consecutive forwards that converged, halve it (never below 8),
+        """A grown budget decays again: after 64 consecutive forwards that converged, halve it (never below the base),
         so one pathological image does not make every later call enqueue thousands of (skipped) passes."""
-        if self.nms_iters > 8:
+        if self.nms_iters > self.nms_base:
             self._calm = getattr(self, "_calm", 0) + 1
             if self._calm >= 64:
-                self.nms_iters = max(8, self.nms_iters // 2)
+                self.nms_iters = max(self.nms_base, self.nms_iters // 2)
                 self._calm = 0
 
     def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None, input_div=0.0):

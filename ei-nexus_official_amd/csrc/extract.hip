@@ -13,6 +13,10 @@
 // workspace); every tensor of the reference's output dict is written to caller-provided outputs.
 // The op-level entry points (einx_conv_block, einx_score_map, ...) stay exported for the unit tests; this file
 // only sequences them, so a handle-level forward is bit-identical to the op-by-op forward.
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -33,6 +37,44 @@ struct Plan {
   size_t buf_elems[2];      // ping-pong activation buffers (floats per image)
   size_t head_elems;        // scratch for the 3x3 head layers' outputs (floats per image)
 };
+
+// Small batches (the reference's own call pattern is one pair per forward): every launch after the backbone leaves most of
+// the 256 CUs idle and the call is a chain of ~25 dependent kernels.  The descriptor branch (head convs, coarse
+// normalisation) does not depend on the detector branch (head convs, score map, NMS passes, selection) until the sparse
+// sampling, so it is enqueued on a second, library-owned stream between a fork and a join event: at B=1 ~90 us of ~540 per
+// network leave the critical path.  The rule depends only on the arguments that size the workspace (a second head scratch).
+#ifndef EINX_FORK_MAX_CELLS
+#define EINX_FORK_MAX_CELLS 8192  // B x head pixels up to which the two head branches run concurrently (B <= 5 at 33x44)
+#endif
+bool fork_heads(const einx_extractor* e, const Plan& pl, int B) {
+  static const int off = getenv("EINX_NO_FORK") ? 1 : 0;
+  return !off && (long)B * pl.hc * pl.wc <= EINX_FORK_MAX_CELLS;
+}
+
+// one side stream + fork/join events per caller stream (created on first use, kept for the life of the process)
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+Side* side_for(hipStream_t caller) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Side> sides;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  Side& sd = sides[{dev, caller}];
+  if (!sd.stream) {
+    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
+      if (sd.stream) (void)hipStreamDestroy(sd.stream);
+      if (sd.fork) (void)hipEventDestroy(sd.fork);
+      sd = Side();
+      return nullptr;
+    }
+  }
+  return &sd;
+}
 
 // Padder.__init__ arithmetic (core/modules/utils/util.py:6-15)
 void padder(int h, int w, int p, int* w0, int* w1, int* h0, int* h1) {
@@ -159,7 +201,7 @@ EINX_EXPORT size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, 
   detect_params(e, pl, B, H, W, cap > 0 ? cap : 1, nms_budget(nms_iters), &p);
   size_t bytes = 0;
   bytes += align256(pl.buf_elems[0] * B * sizeof(float)) + align256(pl.buf_elems[1] * B * sizeof(float));
-  bytes += align256(pl.head_elems * B * sizeof(float));
+  bytes += align256(pl.head_elems * B * sizeof(float)) * (fork_heads(e, pl, B) ? 2 : 1);
   bytes += align256(einx_detect_ws_bytes(&p));
   return bytes + 256;
 }
@@ -183,6 +225,12 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
   p += align256(pl.buf_elems[1] * B * sizeof(float));
   float* head = (float*)p;
   p += align256(pl.head_elems * B * sizeof(float));
+  const bool fork = fork_heads(e, pl, B);
+  float* head2 = head;  // the descriptor head's own scratch when the two branches run concurrently
+  if (fork) {
+    head2 = (float*)p;
+    p += align256(pl.head_elems * B * sizeof(float));
+  }
   void* det_ws = p;
   int rc;
   if (e->d.input_div != 0.0f && e->d.input_div != 1.0f) {  // SuperPointv1: `image /= 255.0` in place on the caller's tensor
@@ -205,31 +253,63 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
     }
     cur = out;
   }
-  // ---- heads (the hidden 3x3 layer of each head goes through the scratch buffer)
-  auto run_head = [&](const std::vector<einx_conv_desc>& L, float* final_out) -> int {
+  // ---- heads (the hidden 3x3 layer of each head goes through a scratch buffer)
+  auto run_head = [&](const std::vector<einx_conv_desc>& L, float* scratch, float* final_out, void* st) -> int {
     const float* x = o->feats;
     for (size_t i = 0; i < L.size(); ++i) {
-      float* out = (i + 1 < L.size()) ? head : final_out;
-      const int r = einx_conv_block(x, B, h, w, 0, 0, h, w, &L[i], out, stream);
+      float* out = (i + 1 < L.size()) ? scratch : final_out;
+      const int r = einx_conv_block(x, B, h, w, 0, 0, h, w, &L[i], out, st);
       if (r) return r;
       x = out;
     }
     return 0;
   };
-  if ((rc = run_head(e->det, o->logits))) return rc;
-  if ((rc = run_head(e->desc, o->raw))) return rc;
   const int D = e->desc.back().cout;
-  // ---- dense by-product first (depends on `raw` only; overlaps the other extractor's convolutions)
-  if (e->d.cell == 8) {
-    rc = einx_normalize_map(o->raw, B, D, h * w, e->d.desc_scale, o->coarse, o->raw_cl, stream);
-    if (rc) return rc;
+  // descriptor branch: head convs + the dense by-product that depends on `raw` only
+  auto desc_branch = [&](void* st) -> int {
+    int r = run_head(e->desc, head2, o->raw, st);
+    if (r) return r;
+    if (e->d.cell == 8) r = einx_normalize_map(o->raw, B, D, h * w, e->d.desc_scale, o->coarse, o->raw_cl, st);
+    return r;
+  };
+  Side* sd = fork ? side_for((hipStream_t)stream) : nullptr;
+  if (sd) {  // fork: the descriptor branch runs beside the detector branch
+    if (hipEventRecord(sd->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->stream, sd->fork, 0) != hipSuccess) {
+      einx_set_error("einx_extract: fork failed");
+      return EINX_ERR_LAUNCH;
+    }
+    rc = desc_branch(sd->stream);
+    // the join is enqueued even when a launch failed, so that the caller's stream never runs ahead of the side stream
+    const bool ok = hipEventRecord(sd->join, sd->stream) == hipSuccess;
+    if (rc) {
+      (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
+      return rc;
+    }
+    if (!ok) {
+      einx_set_error("einx_extract: join failed");
+      return EINX_ERR_LAUNCH;
+    }
+    if ((rc = run_head(e->det, head, o->logits, stream))) {
+      (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
+      return rc;
+    }
+  } else {
+    if ((rc = run_head(e->det, head, o->logits, stream))) return rc;
+    if ((rc = desc_branch(stream))) return rc;
   }
   rc = einx_score_map(o->logits, B, e->det.back().cout, h, w, mask, H, W, pl.h0, pl.w0, e->d.dilate_mask, e->d.border, o->prob, o->score,
                       stream);
-  if (rc) return rc;
+  if (rc) {
+    if (sd) (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
+    return rc;
+  }
   einx_detect_params dp;
   detect_params(e, pl, B, H, W, o->cap, nms_budget(nms_iters), &dp);
   rc = einx_detect(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, stream);
+  if (sd && hipStreamWaitEvent((hipStream_t)stream, sd->join, 0) != hipSuccess && !rc) {  // join before the sampler reads `raw`
+    einx_set_error("einx_extract: join failed");
+    return EINX_ERR_LAUNCH;
+  }
   if (rc) return rc;
   const bool bilinear = e->d.cell == 8;
   const bool use_cl = bilinear && D <= 512;
