@@ -15,6 +15,8 @@
 // Replaces (reference file:line): core/modules/matchers/lightglue.py:137-148 (normalize_keypoints),
 // :161-174 (posenc), :151-158 (rotary), :240-272 (SelfBlock), :275-330 (CrossBlock), :365-418
 // (assignment + filter_matches), :522-716 (forward).
+#include <stdlib.h>
+
 #include "match_tiles.h"
 
 using namespace einx_gemm;
@@ -238,6 +240,130 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
             *y = finish(f.acc[mt][nt][r], bj[nt], EPI == EPI_RESID ? *y : 0.0f);
           }
         }
+    }
+    if (!more) break;
+    cur = nxt;
+    b = nb;
+    n = nn;
+    L = Ln;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// FFN first half in ONE launch (round 3): h = GELU(LayerNorm(cat(x, msg) @ W0^T + b0)), lightglue.py:247-249 / :297-299.
+// LayerNorm needs whole 512-wide rows, which span four 128-column tiles.  Here a workgroup owns a GROUP of 128 rows: it
+// runs the group's four tiles back to back (same tile engine, the next tile's first K-slab prefetched as before), writes
+// the pre-activation rows, and then -- once its own stores are complete -- normalises and activates those 128 rows in
+// place, one wave per row, with exactly the arithmetic of lg_ln_gelu_kernel (sum -> mean -> sum of squared deviations ->
+// rstd -> gelu(fma)), so results are bit-identical to the two-launch form.  The rows it re-reads were written a few
+// microseconds earlier by this workgroup and come from L2 (loads bypass L1): the 2 x 134 MB HBM round trip and 18
+// launches of the stand-alone LayerNorm+GELU kernel per forward (B=64) are gone; the other workgroup of the CU keeps the
+// matrix cores busy during the tail.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_ffn0_ln_gelu_kernel(const GemmArgs g, const float* ln_g, const float* ln_b) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  constexpr int TN = 4;  // 512 output columns = 4 tiles
+  const int tilesM = einx_cdiv(g.cap, BM);
+  const int groups = tilesM * g.B;
+  auto locate = [&](int L, Src& s, int& bb, int& nn) {  // L = group * TN + tile
+    const int grp = L / TN;
+    if (grp >= groups) return false;
+    const int b = grp / tilesM, ti = grp % tilesM;
+    const int n = g.cnt ? min(g.cnt[b], g.cap) : g.cap;
+    if (ti * BM >= n) return false;
+    s.A = g.X + (size_t)b * g.cap * g.ldx;
+    s.A2 = g.X2 + (size_t)b * g.cap * g.ldx2;
+    s.lda = g.ldx;
+    s.lda2 = g.ldx2;
+    s.i0 = ti * BM;
+    s.Mvalid = n;
+    s.B = g.W;
+    s.ldb = g.K;
+    s.j0 = (L % TN) * BN;
+    s.Nvalid = g.N;
+    bb = b;
+    nn = n;
+    return true;
+  };
+  const int total = groups * TN, step = (int)gridDim.x * TN;
+  Src cur, nxt;
+  int b = 0, n = 0, nb = 0, nn = 0;
+  int L = (int)blockIdx.x * TN;
+  while (L < total && !locate(L, cur, b, n)) L += step;
+  if (L >= total) return;
+  Stage st;
+  issue_slab(cur, 0, g.K, g.Ksplit, st);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (;;) {
+    // next tile: the same group's next column tile, else the first tile of this workgroup's next group
+    int Ln = L + 1;
+    if (Ln % TN == 0) {
+      Ln = L - (TN - 1) + step;
+      while (Ln < total && !locate(Ln, nxt, nb, nn)) Ln += step;
+    } else {
+      locate(Ln, nxt, nb, nn);
+    }
+    const bool more = Ln < total;
+    Frag f;
+    tile_nt_run(cur, g.K, g.Ksplit, lds, f, st, nxt, more);
+    const int i0 = cur.i0, j0 = cur.j0;
+    float* Y = g.Y + (size_t)b * g.cap * g.ldy;
+    float bj[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bj[nt] = g.bias[j0 + col_of(nt)];
+    if (i0 + BM <= n) {
+      float* ytile = Y + (size_t)i0 * g.ldy + j0;
+      const unsigned lane_off = (unsigned)(row_base() * g.ldy + col_of(0));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* yrow = ytile + (size_t)row_step(mt, r) * g.ldy;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) yrow[lane_off + nt * 32] = f.acc[mt][nt][r] + bj[nt];
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + row_of(mt, r);
+          if (i >= n) continue;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) Y[(size_t)i * g.ldy + j0 + col_of(nt)] = f.acc[mt][nt][r] + bj[nt];
+        }
+    }
+    if (L % TN == TN - 1) {
+      // ---- tail: LayerNorm + GELU over this group's rows.  Every wave drains its stores, the barrier orders all of the
+      // workgroup's stores before any of its re-reads, and the re-reads bypass L1 (agent-scope relaxed loads).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int rr = wave; rr < BM; rr += WAVES) {
+        const int i = i0 + rr;
+        if (i >= n) break;
+        float* row = Y + (size_t)i * g.ldy;
+        float v[8];
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          v[t] = __hip_atomic_load(row + lane + 64 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sum += v[t];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum / 512.0f;
+        float q = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) q = fmaf(v[t] - mean, v[t] - mean, q);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int c = lane + 64 * t;
+          row[c] = einx_geluf(fmaf((v[t] - mean) * rstd, ln_g[c], ln_b[c]));
+        }
+      }
     }
     if (!more) break;
     cur = nxt;
@@ -636,12 +762,41 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
 // ffn(cat[x,msg]) + residual, in place on s.x
 int ffn(hipStream_t st, const Side& s, int B, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
         const float* w3, const float* b3) {
-  if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
-  {
-    EINX_PROF("lg_ln_gelu_kernel", st);
-    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+  // Measured (tools/r3_exp8.sh, B=64, one box): LightGlue 46.0 ms with the two launches below, 47.5 ms with the fused
+  // kernel (bit-identical outputs).  With 512 row groups on 512 resident workgroups every workgroup reaches its LayerNorm
+  // tail at the same time, so the tail does not hide under another workgroup's matrix work, and the group-per-workgroup
+  // order gives up the XCD-shared operand rows.  The fused kernel stays selectable (EINX_LG_FUSE_LN=1) as the measured record.
+  static const bool fuse = getenv("EINX_LG_FUSE_LN") != nullptr;
+  if (fuse) {
+    GemmArgs a{};
+    a.X = s.x;
+    a.X2 = msg;
+    a.W = w0;
+    a.bias = b0;
+    a.Y = s.h;
+    a.cnt = s.cnt;
+    a.cap = s.cap;
+    a.ldx = D;
+    a.ldx2 = D;
+    a.Ksplit = D;
+    a.K = 2 * D;
+    a.N = 2 * D;
+    a.ldy = 2 * D;
+    a.div = 1.0f;
+    a.B = B;
+    const int groups = einx_cdiv(s.cap, BM) * B;
+    const unsigned res = gemm_grid(groups * 4);
+    EINX_PROF("lg_ffn0_ln_gelu_kernel", st);
+    hipLaunchKernelGGL(lg_ffn0_ln_gelu_kernel, dim3((unsigned)groups < res ? (unsigned)groups : res), dim3(THREADS), 0, st, a, g, be);
+    if (hipGetLastError() != hipSuccess) return -1;
+  } else {
+    if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
+    {
+      EINX_PROF("lg_ln_gelu_kernel", st);
+      hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+    }
+    if (hipGetLastError() != hipSuccess) return -1;
   }
-  if (hipGetLastError() != hipSuccess) return -1;
   return gemm(st, EPI_RESID, s, B, s.h, 2 * D, nullptr, 0, 0x7fffffff, 2 * D, w3, b3, D, s.x, D);
 }
 
