@@ -78,7 +78,12 @@ template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool P
 #ifndef EINX_THIN_WAVES
 #define EINX_THIN_WAVES 6  // thin first layers: cap registers so three 8-wave workgroups share a CU (their load -> MFMA -> store phases only overlap across workgroups)
 #endif
-__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void conv_block_kernel(const ConvArgs a) {
+#ifndef EINX_CONV_DEPTH
+#define EINX_CONV_DEPTH 1
+#endif
+// minimum waves per SIMD the register allocation must allow: thin first layers see above; with two chunks of staging
+// registers in flight (EINX_CONV_DEPTH 2) the 8-wave kernels are held at two workgroups per CU, the 4-wave ones at three
+__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CONV_DEPTH == 2 ? (WM * WN >= 8 ? 4 : 3) : 1))) void conv_block_kernel(const ConvArgs a) {
   constexpr int kMT = MT, kNT = NT;
   constexpr int NW = WM * WN;
   constexpr int TAPS = KS * KS;
@@ -110,6 +115,15 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
   float* in_tile = lds;
   float* w_tile = lds + IN_LDS;
 
+#if defined(EINX_CONV_STAGGER) && EINX_CONV_STAGGER > 0
+  // experiment (tools/r3_exp9.sh): are the two co-resident workgroups of a CU in lockstep (same start, same length, so their
+  // prologues, epilogues and chunk boundaries coincide)?  Delay the second resident round once; later workgroups inherit it.
+  {
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (lin >= 256u && lin < 512u)
+      for (int i = 0; i < EINX_CONV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles = 3.4 us each
+  }
+#endif
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -220,8 +234,18 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
   const int pairs_total = (a.Cin + 1) / 2;
   const int nchunks = (pairs_total * 2 + CK - 1) / CK;
 
-  float r_in[IN_PER_THR];
-  f32x4 r_w[W_PER_THR];
+  // Register image of one chunk in flight (global -> registers -> LDS).  DEPTH chunks are in flight: the loads of chunk
+  // c + DEPTH are issued when chunk c has been committed to LDS, i.e. they have DEPTH chunks of MFMAs to land.
+  // Measured (tools/r3_exp10.sh, timing-only ablations): with DEPTH = 1 the per-chunk global loads cost conv1b 10 % (1653 us
+  // against 1485 us with the same commits fed from registers loaded once) although they are issued a whole chunk ahead.
+  struct StageRegs {
+    float in[IN_PER_THR];
+    f32x4 w[W_PER_THR];
+    unsigned pend;  // (generic path) validity bits
+  };
+  constexpr int DEPTH = (CK >= 8 && EINX_CONV_DEPTH == 2) ? 2 : 1;
+  StageRegs sA, sB;
+  sA.pend = sB.pend = 0;
 
   unsigned woff[W_PER_THR];  // (EXACT path) element offset of this thread's weight float4 inside a chunk's rows
   if (EXACT) {
@@ -232,15 +256,14 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
       woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4);
     }
   }
-  unsigned pend = 0;  // (generic path) validity bits of the chunk in flight
-  auto issue_loads = [&](int c) {
+  auto issue_loads = [&](int c, StageRegs& sr) {
     if (EXACT) {
       const float* ib = in_b + (size_t)c * CK * src_plane;
 #pragma unroll
-      for (int i = 0; i < IN_PER_THR; ++i) r_in[i] = ib[goff[i]];  // padding is masked at commit time
+      for (int i = 0; i < IN_PER_THR; ++i) sr.in[i] = ib[goff[i]];  // padding is masked at commit time
       const float* wb = a.w + (size_t)c * W_ROWS * a.CoutPad;
 #pragma unroll
-      for (int i = 0; i < W_PER_THR; ++i) r_w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+      for (int i = 0; i < W_PER_THR; ++i) sr.w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
       return;
     }
     const int ci0 = c * CK;
@@ -249,8 +272,8 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
       // unconditional load from a clamped (always valid) address, then select: no branches
       const int ci = ci0 + g_ci[i];
       const bool ok = g_off[i] >= 0 && ci < a.Cin;
-      r_in[i] = in_b[(size_t)(ci < a.Cin ? ci : a.Cin - 1) * src_plane + (g_off[i] >= 0 ? g_off[i] : 0)];
-      pend = (pend & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+      sr.in[i] = in_b[(size_t)(ci < a.Cin ? ci : a.Cin - 1) * src_plane + (g_off[i] >= 0 ? g_off[i] : 0)];
+      sr.pend = (sr.pend & ~(1u << i)) | ((ok ? 1u : 0u) << i);
     }
     const int krow0 = c * W_ROWS;
 #pragma unroll
@@ -260,34 +283,28 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
       // the native weight image is zero-padded to whole 16-channel row groups (einx_conv_repack),
       // so every row a chunk can name exists; only the thread-count tail is clamped
       const int rr = (f < W_F4) ? r : 0;
-      r_w[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + rr) * a.CoutPad + co0 + c4 * 4);
+      sr.w[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + rr) * a.CoutPad + co0 + c4 * 4);
     }
   };
   // The zero for padding / channel-tail elements is selected here, when the value is consumed: a select
   // right after the load would make the wave wait for the load before it starts the MFMAs the load is
   // meant to fly under.
-  auto commit_loads = [&]() {
-    const unsigned m = EXACT ? okmask : pend;
+  auto commit_loads = [&](const StageRegs& sr) {
+    const unsigned m = EXACT ? okmask : sr.pend;
 #pragma unroll
     for (int i = 0; i < IN_PER_THR; ++i) {
       const int e = tid + i * NTHR;
-      if (e < IN_ELEMS) in_tile[PADDED ? lds_off[i] : e] = ((m >> i) & 1u) ? r_in[i] : 0.0f;
+      if (e < IN_ELEMS) in_tile[PADDED ? lds_off[i] : e] = ((m >> i) & 1u) ? sr.in[i] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < W_PER_THR; ++i) {
       const int f = tid + i * NTHR;
-      if (f < W_F4) *reinterpret_cast<f32x4*>(w_tile + f * 4) = r_w[i];
+      if (f < W_F4) *reinterpret_cast<f32x4*>(w_tile + f * 4) = sr.w[i];
     }
   };
-
-  issue_loads(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();  // previous round's LDS reads are done
-    commit_loads();
-    __syncthreads();
-    if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under the MFMAs below
-    // 36 K-steps (CK/2 channel pairs x taps), software pipelined: the LDS fragments of step t+1
-    // are requested before the MFMAs of step t so that no MFMA group waits on a fresh ds_read.
+  // 36 K-steps (CK/2 channel pairs x taps), software pipelined: the LDS fragments of step t+1
+  // are requested before the MFMAs of step t so that no MFMA group waits on a fresh ds_read.
+  auto mfma_chunk = [&]() {
     constexpr int STEPS = (CK / 2) * TAPS;
     constexpr int PF = 2;  // fragment prefetch distance in K-steps (LDS latency under 8-16 waves/CU > 1 step)
     float av[PF + 1][kMT], bv[PF + 1][kNT];
@@ -312,6 +329,26 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : 1)) void 
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % (PF + 1)][mt], bv[st % (PF + 1)][nt], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  auto round = [&](int c, StageRegs& sr) {
+    __syncthreads();  // previous round's LDS reads are done
+    commit_loads(sr);
+    __syncthreads();
+#ifdef EINX_CONV_ABL_NOLOADS  // timing-only ablation (wrong results, tools/r3_exp10.sh / r3_exp11.sh): every chunk recommits chunk 0's registers
+    if (false)
+#endif
+    if (c + DEPTH < nchunks) issue_loads(c + DEPTH, sr);  // in flight under the MFMAs of the next DEPTH chunks
+    mfma_chunk();
+  };
+  issue_loads(0, sA);
+  if (DEPTH == 2) {
+    if (nchunks > 1) issue_loads(1, sB);
+    for (int c = 0; c < nchunks; c += 2) {
+      round(c, sA);
+      if (c + 1 < nchunks) round(c + 1, sB);
+    }
+  } else {
+    for (int c = 0; c < nchunks; ++c) round(c, sA);
   }
 
   // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store -------------------------

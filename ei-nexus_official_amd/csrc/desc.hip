@@ -441,8 +441,11 @@ __device__ __forceinline__ void up_stage_commit(const UpStage<PAIRS>& st, const 
 }
 
 // ws layout: den [B,H,W] then 1/den [B,H,W] (the reciprocal correctly rounded: IEEE division)
-template <int NIT>
-__global__ __launch_bounds__(64 * NIT, EINX_UPD_WAVES) void upsample_den_kernel(const float* raw, UpGeom g, float* den, float* rden) {
+// NW waves per workgroup; blockIdx.z walks the column blocks of 64 NW (two half-width workgroups per sweep at W = 346:
+// twice as many, half as long workgroups load the CUs more evenly than 34 x B whole-row ones)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, EINX_UPD_WAVES) void upsample_den_kernel(const float* raw, UpGeom g, float* den, float* rden) {
+  constexpr int NIT = NW;
   constexpr int CHR = UPD_PAIRS * NIT / 2;  // channels per LDS round: every wave stages UPD_PAIRS (channel, row) pairs
   extern __shared__ float rows[];          // [CHR][2][wc + 1]
   const int b = blockIdx.y;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(64 * NIT, EINX_UPD_WAVES) void upsample_den_kernel(
   int Y;
   const int nrow = up_sweep(g, j, s, Y, ly, hy);
   if (nrow == 0) return;  // uniform (a band without rows in the crop window)
-  const int tid = threadIdx.x, x = tid, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, x = (int)blockIdx.z * 64 * NW + tid, lane = tid & 63, wv = tid >> 6;
   const bool xv = x < g.W;
   const int pw = g.wc + 1;
   int x0;
@@ -727,8 +730,9 @@ static void launch_upsample(const float* raw, int B, const UpGeom& g, float scal
   const int units = g.units;
   {
     EINX_PROF("upsample_den_kernel", s);
-    hipLaunchKernelGGL(upsample_den_kernel<NIT>, dim3((unsigned)units, (unsigned)B), dim3(64 * NIT), (size_t)(UPD_PAIRS * NIT / 2) * 2 * pw * sizeof(float),
-                       s, raw, g, den, rden);
+    constexpr int NWD = NIT >= 4 ? (NIT + 1) / 2 : NIT;  // waves per den workgroup
+    hipLaunchKernelGGL(upsample_den_kernel<NWD>, dim3((unsigned)units, (unsigned)B, (unsigned)einx_cdiv(g.W, 64 * NWD)), dim3(64 * NWD),
+                       (size_t)(UPD_PAIRS * NWD / 2) * 2 * pw * sizeof(float), s, raw, g, den, rden);
   }
   {
     EINX_PROF("upsample_store_kernel", s);
