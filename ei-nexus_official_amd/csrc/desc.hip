@@ -500,8 +500,8 @@ __global__ __launch_bounds__(64 * NW, EINX_UPD_WAVES) void upsample_den_kernel(c
 
 // v / d for the store kernel.  d >= 1e-12 and y = RN(1 / d) come from the den kernel.  Two Newton corrections of
 // q = v * y with exact fma remainders give the correctly rounded quotient (after the first step q is faithful, then
-// Markstein's theorem applies) as long as nothing under- or overflows: 2^-80 <= |v| <= 2^60 (|v| <= d always holds
-// here).  Checked against IEEE division on 2.5e9 random and boundary-mantissa operands (tools/div_check.c).  Elements
+// Markstein's theorem applies) as long as nothing under- or overflows and the quotient is a normal number: the kernel
+// takes this path for 2^-80 <= |v| <= d < 2^20 only (|q| >= 2^-100).  Checked against IEEE division on 2.5e9 random and boundary-mantissa operands (tools/div_check.c).  Elements
 // outside that range (exact zeros among them) make the wave redo the channel with IEEE divisions.
 __device__ __forceinline__ float up_div(float v, float d, float y) {
   const float q0 = v * y;
@@ -559,11 +559,11 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
       dn[it][r] = den[o];
       yr[it][r] = rden[o];
     }
-  bool big = false;  // a norm beyond the fast division's range (|v| <= den < 2^60 otherwise): IEEE divisions for the whole sweep
+  bool big = false;  // a norm beyond the fast division's range: IEEE divisions for the whole sweep (otherwise |v| <= den < 2^20)
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
 #pragma unroll
-    for (int r = 0; r < UP_ROWS; ++r) big |= !(dn[it][r] < 0x1p60f);
+    for (int r = 0; r < UP_ROWS; ++r) big |= !(dn[it][r] < 0x1p20f);
   big = __any(big);
   up_stage_commit(st, g, nc, rows, lane, wave, UPS_WAVES);
   __syncthreads();  // the only workgroup barrier: from here on every wave works on its own channels and its own LDS slab
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
 #elif EINX_UPS_EXP == 3  // timing experiment: no range check
         q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
 #else
-        odd |= !(fabsf(v) >= 0x1p-80f);  // also true for NaN; the upper end is checked once per sweep on the norms (|v| <= den)
+        odd |= !(fabsf(v) >= 0x1p-80f);  // also true for NaN; the upper end is checked once per sweep on the norms (|v| <= den < 2^20)
         q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
 #endif
       }
