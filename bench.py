@@ -731,7 +731,7 @@ def run_rank(args):
         cpu_baseline = cpu_baseline_and_verify(wl, args, last)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_cpu_torch and args.config == "sp_mnn":
         from oracle import torch_cpu
-        nb = min(8, B)  # ~5 s of host work on the GPU box's cores
+        nb = min(4, B)  # ~5 s of host work on the GPU box's cores
         a_ = (wl.sub("event_extractor.extractor."), wl.sub("image_extractor.extractor."))
         torch_cpu.sp_mnn_pairs(*a_, wl.ev_np[:2], wl.mask_np[:2], wl.img_np[:2].copy())
         tc = time.perf_counter()

@@ -264,6 +264,25 @@ def test_upsample_normalize_bands(oracle, case):
     assert np.array_equal(got, exp)
 
 
+def test_upsample_normalize_division_edge_cases(oracle):
+    """The store kernel divides with two Newton corrections of v * (1/den) (exact for 2^-80 <= |v| <= den < 2^20) and falls
+    back to IEEE divisions otherwise, per wave and channel: exact zeros (+-0), denormal-range values, huge norms and all-zero
+    pixels (den clamps to 1e-12) must come out bit-equal to the oracle's plain `v / den` too."""
+    B, D, hc, wc = 2, 40, 5, 7
+    Hp, Wp = 40, 56
+    raw = synth.normalish(977, (B, D, hc, wc)).astype(np.float32)
+    raw[0, 3] = 0.0                 # a channel of exact zeros: v == 0 -> slow path for that channel
+    raw[0, 5] = -0.0
+    raw[0, 7] *= np.float32(1e-30)  # |v| < 2^-80
+    raw[0, 9] *= np.float32(1e-42)  # denormal inputs
+    raw[1, :, :2, :] = 0.0          # all-zero pixels: den = 1e-12, 0 / 1e-12
+    raw[1, 11, 3:, :] *= np.float32(1e24)  # norms beyond 2^20: the whole sweep divides the IEEE way
+    got = _np(pkg.native.upsample_normalize(_t(raw), (Hp, Wp), (3, 3, 2, 2), 1.41))
+    exp = oracle.upsample_normalize(raw, (Hp, Wp), 1.41)[:, :, 2:Hp - 2, 3:Wp - 3]
+    assert np.array_equal(got, exp)
+    assert np.array_equal(np.signbit(got), np.signbit(exp))  # -0 stays -0
+
+
 # ------------------------------------------------------------------ MNN
 MNN = Golden("mnn")
 

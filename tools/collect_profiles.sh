@@ -13,6 +13,7 @@ python bench.py --log-assignment --dense --no-cpu-baseline --no-extras > $O/benc
 python bench.py --with-metrics --no-cpu-baseline --no-extras > $O/bench_sp_mnn_metrics.json 2>> $O/bench.err
 python bench.py --config sp_lg --cpu-pairs 2 > $O/bench_sp_lg.json 2>> $O/bench.err
 python bench.py --config silk_mnn --cpu-pairs 2 > $O/bench_silk.json 2>> $O/bench.err
+python bench.py --config silk_lg --cpu-pairs 1 --no-extras > $O/bench_silk_lg.json 2>> $O/bench.err
 # one-rank RCCL group through bench.py's own launcher, and through torchrun (the driver's launch pattern)
 python bench.py --gpus 1 --spawn --no-cpu-baseline --no-extras > $O/bench_spawn1.json 2> $O/bench_spawn1.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-extras > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
@@ -24,6 +25,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_overlap -o p -- 
 EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_single.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lg -o p -- python3 $R/bench.py --config sp_lg --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_lg.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kernel_only -o p -- python3 $R/bench.py --kernel-only > $O/prof_kernel_only.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dense -o p -- python3 $R/tools/up_bench.py > $O/prof_dense.log 2>&1
+python3 $R/tools/up_bench.py --ref > $O/up_bench.txt 2>/dev/null
 echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --kernel-only > $O/pmc_$c.log 2>&1

@@ -12,7 +12,8 @@ def timed(f, n=5):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+nums = [a for a in sys.argv[1:] if a.isdigit()]
+B = int(nums[0]) if nums else 32
 raw = torch.randn(B, 256, 33, 44, device="cuda")
 f = lambda: N.upsample_normalize(raw, (264, 352), (3, 3, 2, 2), 1.0)
 ms = timed(f)
