@@ -416,6 +416,146 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small grids (single pairs: the reference's own call pattern): conv3x3 on v_mfma_f32_16x16x4_f32.
+// A launch that cannot fill the chip is bound by the LATENCY of one workgroup = chunks x K-steps x MFMA latency; the
+// k-ordered chain forbids splitting K.  The 16x16x4 instruction consumes four K per 32-cycle issue (40 dependent) instead
+// of two per 64, and a wave that owns ONE 16x16 accumulator (16 output channels x 16 pixels) walks a chunk of 72 K in
+// 18 x 40 = 720 cycles instead of 36 x 64 = 2304; the work spreads over 4x as many waves.  Its four products per
+// instruction accumulate as the sequential chain k, k+1, k+2, k+3 (tools/mfma16_order.hip: bit-equal to the fmaf chain, no
+// other order matches), and the K order is the one of conv_block_kernel, so results are bit-identical to it and to the oracle.
+//   workgroup = 64 output channels x one 2 x 8 pixel tile, 4 waves = 4 M-tiles of 16 channels (one wave per SIMD)
+//   lane l: A = w[k = 4g + l/16][channel l%16], B = patch[k = 4g + l/16][pixel l%16], C rows 4 (l/16) + i, column l%16
+//   k -> (channel pair k / 18, tap (k % 18) / 2, parity k % 2); 4g is even, so the parity is the lane group's
+// Cin must be a multiple of 8, no replicate-pad fold (never the first layer).  POOL: 2x2 max over lanes j^1 (x), j^8 (y).
+// ------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// CK input channels per LDS round.  Measured at B=1 on the 33x44 128->128 layer (tools/r3_exp12.sh): 27.8 us with the finest
+// 32x32x2 tile (11x5, one accumulator per wave), 14.5 us here with CK = 8 (2,170 cycles per chunk for 720 of MFMAs: every
+// workgroup streams the layer's whole weight set, 18 KB per chunk, through L2 and LDS for 16 pixels); CK = 16 (half the
+// barriers) 14.6-15.1 us, three chunks of registers in flight 14.5-15.1 us, no LDS at all (every lane loads its own
+// operands from L1 / L2) 21 us.  Forward at B=1: 0.80 -> 0.73 ms on the device.
+template <bool POOL, int CK>
+__global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
+  constexpr int TAPS = 9, KCH = CK * TAPS, G = KCH / 4;  // CK = 8: 72 K per chunk = 18 instructions
+  constexpr int TH = 2, TW = 8, PH = TH + 2, PW = TW + 2;
+  constexpr int PITCH = 16, PLANE = PH * PITCH + 8;  // rows of a pixel tile on banks 0-7 / 16-23, the odd channel of a pair 8 banks on
+  constexpr int IN_LDS = CK * PLANE;
+  constexpr int W_F4 = KCH * kCoutTile / 4;       // float4 of weights per chunk (CK = 8: 1152)
+  constexpr int W_PER_THR = (W_F4 + 255) / 256;
+  constexpr int IN_ELEMS = CK * PH * PW;
+  constexpr int IN_PER_THR = (IN_ELEMS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float in_tile[IN_LDS];
+  __shared__ __attribute__((aligned(16))) float w_tile[KCH * kCoutTile];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, j = lane & 15;
+  const int ncot = (int)gridDim.y;
+  int item = xcd_contiguous((int)(blockIdx.x + blockIdx.y * gridDim.x), (int)gridDim.x * ncot);
+  const int co0 = (item % ncot) * kCoutTile;
+  int bid = item / ncot;
+  const int tx_i = bid % a.tilesX;
+  bid /= a.tilesX;
+  const int ty_i = bid % a.tilesY;
+  const int b = bid / a.tilesY;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int HW = a.H * a.W;
+  // ---- staging plan
+  const float* in_b = a.in + (size_t)b * a.Cin * HW;
+  unsigned goff[IN_PER_THR], loff[IN_PER_THR], okmask = 0;
+#pragma unroll
+  for (int i = 0; i < IN_PER_THR; ++i) {
+    const int e = tid + i * 256;
+    int off = -1, cil = 0, r = 0;
+    if (e < IN_ELEMS) {
+      cil = e / (PH * PW);
+      r = e % (PH * PW);
+      const int y = y0 - 1 + r / PW, x = x0 - 1 + r % PW;
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W) off = y * a.W + x;
+    }
+    goff[i] = (unsigned)cil * (unsigned)HW + (unsigned)(off >= 0 ? off : 0);
+    loff[i] = (unsigned)(cil * PLANE + (r / PW) * PITCH + r % PW);
+    okmask |= (off >= 0 ? 1u : 0u) << i;
+  }
+  unsigned woff[W_PER_THR];
+#pragma unroll
+  for (int i = 0; i < W_PER_THR; ++i) {
+    const int f = tid + i * 256;
+    const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
+    woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4);
+  }
+  // ---- per-lane operand offsets: koff[g] = LDS offset of patch element k = 4g + q relative to the pixel's top-left tap
+  int koff[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k = 4 * g + q;
+    const int pair = k / 18, tap = (k % 18) >> 1;
+    koff[g] = (2 * pair + (k & 1)) * PLANE + (tap / 3) * PITCH + tap % 3;
+  }
+  const int bpix = (j >> 3) * PITCH + (j & 7);     // pixel (j / 8, j % 8) of the tile, halo origin at (0, 0)
+  const int aoff = q * kCoutTile + wave * 16 + j;  // A: k = 4g + q rows of 64 channels; this wave's M-tile
+  float r_in[IN_PER_THR];
+  f32x4 r_w[W_PER_THR];
+  auto issue_loads = [&](int c) {
+    const float* ib = in_b + (size_t)c * CK * HW;
+#pragma unroll
+    for (int i = 0; i < IN_PER_THR; ++i) r_in[i] = ib[goff[i]];
+    const float* wb = a.w + (size_t)c * KCH * a.CoutPad;
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i) r_w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+  };
+  f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int nchunks = a.Cin / CK;
+  issue_loads(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IN_PER_THR; ++i)
+      if (tid + i * 256 < IN_ELEMS) in_tile[loff[i]] = ((okmask >> i) & 1u) ? r_in[i] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i)
+      if (tid + i * 256 < W_F4) *reinterpret_cast<f32x4*>(w_tile + (tid + i * 256) * 4) = r_w[i];
+    __syncthreads();
+    if (c + 1 < nchunks) issue_loads(c + 1);
+    constexpr int PF = 3;
+    float av[PF + 1], bv[PF + 1];
+#pragma unroll
+    for (int g = 0; g < PF; ++g) {
+      av[g] = w_tile[aoff + g * 4 * kCoutTile];
+      bv[g] = in_tile[bpix + koff[g]];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g + PF < G) {
+        av[(g + PF) % (PF + 1)] = w_tile[aoff + (g + PF) * 4 * kCoutTile];
+        bv[(g + PF) % (PF + 1)] = in_tile[bpix + koff[g + PF]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g % (PF + 1)], bv[g % (PF + 1)], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store; C row 4q + i = output channel, column j = pixel
+  const int ty = j >> 3, tx = j & 7;
+  const int y = y0 + ty, x = x0 + tx;
+  const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
+  float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + wave * 16 + 4 * q + i;
+    const bool cv = co < a.Cout;
+    float v = acc[i] + ((cv && a.bias) ? a.bias[co] : 0.0f);
+    if (a.relu) v = v > 0.0f ? v : 0.0f;
+    if (a.scale) v = fmaf(v, cv ? a.scale[co] : 1.0f, cv ? a.shift[co] : 0.0f);
+    if (POOL) {
+      float m = fmaxf(v, __shfl_xor(v, 8, 64));  // rows 2k, 2k+1
+      m = fmaxf(m, __shfl_xor(m, 1, 64));        // columns 2c, 2c+1
+      if (cv && ty == 0 && !(tx & 1) && (y >> 1) < Ho && (x >> 1) < Wo) out_b[(size_t)co * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1)] = m;
+    } else {
+      if (cv && y < a.H && x < a.W) out_b[(size_t)co * HW + (size_t)y * a.W + x] = v;
+    }
+  }
+}
+
 // OIHW -> native [K][CoutPad], K = (ci>>1)*2*taps + tap*2 + (ci&1); zero padded.
 __global__ void conv_repack_kernel(const float* w, int cin, int cout, int taps, int coutPad, int krows, float* out) {
   const size_t n = (size_t)krows * coutPad;
@@ -598,6 +738,23 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     // per SIMD cut it up to 4x; bit-identical results (same kernel, other template arguments).  Thin first layers stay on the
     // generic path (they are store-bound).
     const long blocks_best = (long)einx_cdiv(H, cfgs[best].th) * einx_cdiv(W, cfgs[best].tw) * B * (a.CoutPad / kCoutTile);
+    // the finest grain: one 16x16 accumulator per wave on the 16x16x4 instruction, when even that leaves SIMDs to spare
+    // (MFMA tiles = pixels / 16 x channels / 16 <= EINX_CONV16_MAX_TILES) -- see conv16_kernel
+    {
+      static const long max_tiles = getenv("EINX_CONV16_MAX_TILES") ? atol(getenv("EINX_CONV16_MAX_TILES")) : 4096;
+      const long t16 = (long)einx_cdiv(H, 2) * einx_cdiv(W, 8) * B * (a.CoutPad / 16);
+      if (blocks_best < 512 && d->cin % 8 == 0 && Hs == H && Ws == W && h0 == 0 && w0 == 0 && t16 <= max_tiles && (!d->pool || (H % 2 == 0 && W % 2 == 0))) {
+        a.tilesX = einx_cdiv(W, 8);
+        a.tilesY = einx_cdiv(H, 2);
+        dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
+        g_last_conv_kernel = d->pool ? "conv16_kernel<true,8>" : "conv16_kernel<false,8>";
+        EINX_PROF("conv16_kernel 3x3 (small grid)", s);
+        if (d->pool) hipLaunchKernelGGL((conv16_kernel<true, 8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv16_kernel<false, 8>), grid, dim3(256), 0, s, a);
+        EINX_CHECK_LAUNCH();
+        return EINX_OK;
+      }
+    }
     if (blocks_best < 512 && d->cin > 6 && !(conv_exp() & 32)) {
       struct Lat {
         int th, tw, unit;  // unit = waves per SIMD x accumulator tiles per wave
