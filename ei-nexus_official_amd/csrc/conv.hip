@@ -434,12 +434,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // 32x32x2 tile (11x5, one accumulator per wave), 14.5 us here with CK = 8 (2,170 cycles per chunk for 720 of MFMAs: every
 // workgroup streams the layer's whole weight set, 18 KB per chunk, through L2 and LDS for 16 pixels); CK = 16 (half the
 // barriers) 14.6-15.1 us, three chunks of registers in flight 14.5-15.1 us, no LDS at all (every lane loads its own
-// operands from L1 / L2) 21 us.  Forward at B=1: 0.80 -> 0.73 ms on the device.
-template <bool POOL, int CK>
+// operands from L1 / L2) 21 us.  Forward at B=1: 0.80 -> 0.70 ms on the device (0.86 -> 0.77 ms wall).
+// NPW: 16-pixel N-tiles per wave (accumulators sharing one A fragment); the workgroup's tile is 2 x 8 NPW pixels.  More
+// pixels per workgroup = less weight traffic per pixel (the kernel is L2-bound on the larger maps) at NPW x the chain length.
+template <bool POOL, int CK, int NPW>
 __global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
   constexpr int TAPS = 9, KCH = CK * TAPS, G = KCH / 4;  // CK = 8: 72 K per chunk = 18 instructions
-  constexpr int TH = 2, TW = 8, PH = TH + 2, PW = TW + 2;
-  constexpr int PITCH = 16, PLANE = PH * PITCH + 8;  // rows of a pixel tile on banks 0-7 / 16-23, the odd channel of a pair 8 banks on
+  constexpr int TH = 2, TW = 8 * NPW, PH = TH + 2, PW = TW + 2;
+  constexpr int PITCH = TW + 8, PLANE = PH * PITCH + 8;
   constexpr int IN_LDS = CK * PLANE;
   constexpr int W_F4 = KCH * kCoutTile / 4;       // float4 of weights per chunk (CK = 8: 1152)
   constexpr int W_PER_THR = (W_F4 + 255) / 256;
@@ -503,7 +505,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < W_PER_THR; ++i) r_w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
   };
-  f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4v acc[NPW];
+#pragma unroll
+  for (int n = 0; n < NPW; ++n) acc[n] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
   const int nchunks = a.Cin / CK;
   issue_loads(0);
   for (int c = 0; c < nchunks; ++c) {
@@ -517,41 +521,48 @@ __global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
     __syncthreads();
     if (c + 1 < nchunks) issue_loads(c + 1);
     constexpr int PF = 3;
-    float av[PF + 1], bv[PF + 1];
+    float av[PF + 1], bv[PF + 1][NPW];
 #pragma unroll
     for (int g = 0; g < PF; ++g) {
       av[g] = w_tile[aoff + g * 4 * kCoutTile];
-      bv[g] = in_tile[bpix + koff[g]];
+#pragma unroll
+      for (int n = 0; n < NPW; ++n) bv[g][n] = in_tile[bpix + 8 * n + koff[g]];
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if (g + PF < G) {
         av[(g + PF) % (PF + 1)] = w_tile[aoff + (g + PF) * 4 * kCoutTile];
-        bv[(g + PF) % (PF + 1)] = in_tile[bpix + koff[g + PF]];
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) bv[(g + PF) % (PF + 1)][n] = in_tile[bpix + 8 * n + koff[g + PF]];
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g % (PF + 1)], bv[g % (PF + 1)], acc, 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NPW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g % (PF + 1)], bv[g % (PF + 1)][n], acc[n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store; C row 4q + i = output channel, column j = pixel
   const int ty = j >> 3, tx = j & 7;
-  const int y = y0 + ty, x = x0 + tx;
   const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
   float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int co = co0 + wave * 16 + 4 * q + i;
     const bool cv = co < a.Cout;
-    float v = acc[i] + ((cv && a.bias) ? a.bias[co] : 0.0f);
-    if (a.relu) v = v > 0.0f ? v : 0.0f;
-    if (a.scale) v = fmaf(v, cv ? a.scale[co] : 1.0f, cv ? a.shift[co] : 0.0f);
-    if (POOL) {
-      float m = fmaxf(v, __shfl_xor(v, 8, 64));  // rows 2k, 2k+1
-      m = fmaxf(m, __shfl_xor(m, 1, 64));        // columns 2c, 2c+1
-      if (cv && ty == 0 && !(tx & 1) && (y >> 1) < Ho && (x >> 1) < Wo) out_b[(size_t)co * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1)] = m;
-    } else {
-      if (cv && y < a.H && x < a.W) out_b[(size_t)co * HW + (size_t)y * a.W + x] = v;
+    const float bi = (cv && a.bias) ? a.bias[co] : 0.0f, sc = (cv && a.scale) ? a.scale[co] : 1.0f, sh = (cv && a.scale) ? a.shift[co] : 0.0f;
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int y = y0 + ty, x = x0 + 8 * n + tx;
+      float v = acc[n][i] + bi;
+      if (a.relu) v = v > 0.0f ? v : 0.0f;
+      if (a.scale) v = fmaf(v, sc, sh);
+      if (POOL) {
+        float m = fmaxf(v, __shfl_xor(v, 8, 64));  // rows 2k, 2k+1
+        m = fmaxf(m, __shfl_xor(m, 1, 64));        // columns 2c, 2c+1
+        if (cv && ty == 0 && !(tx & 1) && (y >> 1) < Ho && (x >> 1) < Wo) out_b[(size_t)co * Ho * Wo + (size_t)(y >> 1) * Wo + (x >> 1)] = m;
+      } else {
+        if (cv && y < a.H && x < a.W) out_b[(size_t)co * HW + (size_t)y * a.W + x] = v;
+      }
     }
   }
 }
@@ -741,16 +752,36 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     // the finest grain: one 16x16 accumulator per wave on the 16x16x4 instruction, when even that leaves SIMDs to spare
     // (MFMA tiles = pixels / 16 x channels / 16 <= EINX_CONV16_MAX_TILES) -- see conv16_kernel
     {
-      static const long max_tiles = getenv("EINX_CONV16_MAX_TILES") ? atol(getenv("EINX_CONV16_MAX_TILES")) : 4096;
+      static const long max_tiles = getenv("EINX_CONV16_MAX_TILES") ? atol(getenv("EINX_CONV16_MAX_TILES")) : 8192;
       const long t16 = (long)einx_cdiv(H, 2) * einx_cdiv(W, 8) * B * (a.CoutPad / 16);
       if (blocks_best < 512 && d->cin % 8 == 0 && Hs == H && Ws == W && h0 == 0 && w0 == 0 && t16 <= max_tiles && (!d->pool || (H % 2 == 0 && W % 2 == 0))) {
-        a.tilesX = einx_cdiv(W, 8);
+        // pixels per workgroup: the widest tile that still leaves every CU two workgroups (weights are re-streamed per
+        // workgroup; measured at B=1: 132x176 layers 28 -> 24.5 us with two N-tiles per wave, 29 with one or four)
+        static const long min_wg = getenv("EINX_CONV16_MIN_WG") ? atol(getenv("EINX_CONV16_MIN_WG")) : 512;
+        int npw = 1;
+        for (int cand = 4; cand > 1; cand >>= 1)
+          if ((long)einx_cdiv(H, 2) * einx_cdiv(W, 8 * cand) * B * (a.CoutPad / kCoutTile) >= min_wg) {
+            npw = cand;
+            break;
+          }
+        a.tilesX = einx_cdiv(W, 8 * npw);
         a.tilesY = einx_cdiv(H, 2);
         dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
-        g_last_conv_kernel = d->pool ? "conv16_kernel<true,8>" : "conv16_kernel<false,8>";
+        static char nm[64];
+        snprintf(nm, sizeof nm, "conv16_kernel<%s,8,%d>", d->pool ? "true" : "false", npw);
+        g_last_conv_kernel = nm;
         EINX_PROF("conv16_kernel 3x3 (small grid)", s);
-        if (d->pool) hipLaunchKernelGGL((conv16_kernel<true, 8>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv16_kernel<false, 8>), grid, dim3(256), 0, s, a);
+#define EINX_C16(P, N) hipLaunchKernelGGL((conv16_kernel<P, 8, N>), grid, dim3(256), 0, s, a)
+        if (d->pool) {
+          if (npw == 4) EINX_C16(true, 4);
+          else if (npw == 2) EINX_C16(true, 2);
+          else EINX_C16(true, 1);
+        } else {
+          if (npw == 4) EINX_C16(false, 4);
+          else if (npw == 2) EINX_C16(false, 2);
+          else EINX_C16(false, 1);
+        }
+#undef EINX_C16
         EINX_CHECK_LAUNCH();
         return EINX_OK;
       }
