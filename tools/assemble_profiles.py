@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 PR = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def last_json_line(path):
@@ -33,7 +33,9 @@ def main():
     os.makedirs(PR, exist_ok=True)
     for src, dst in (("bench_sp_mnn.json", "bench_sp_mnn_b32.json"), ("bench_sp_mnn_full.json", "bench_sp_mnn_b32_full_dict.json"),
                      ("bench_sp_mnn_metrics.json", "bench_sp_mnn_b32_with_metrics.json"), ("bench_sp_lg.json", "bench_sp_lg_b64.json"),
-                     ("bench_silk.json", "bench_silk_mnn_b32.json")):
+                     ("bench_silk.json", "bench_silk_mnn_b32.json"), ("bench_silk_lg.json", "bench_silk_lg_b32.json")):
+        if not os.path.exists(os.path.join(EV, src)):
+            continue
         j = last_json_line(os.path.join(EV, src))
         json.dump(j, open(os.path.join(PR, f"{R}_{dst}"), "w"), indent=1)
         print(dst, j["value"], j["unit"], "roofline", j.get("roofline", {}).get("achieved"))
@@ -49,9 +51,14 @@ def main():
         if os.path.exists(os.path.join(EV, src)):
             txt = "\n".join(ln for ln in open(os.path.join(EV, src)).read().splitlines() if "amdgpu.ids" not in ln)
             open(os.path.join(PR, f"{R}_{dst}"), "w").write(txt + "\n")
+    if os.path.exists(os.path.join(EV, "up_bench.txt")):
+        shutil.copy(os.path.join(EV, "up_bench.txt"), os.path.join(PR, f"{R}_dense_up_bench.txt"))
     for src, dst in (("prof_overlap", "sp_mnn_b32_kernel_stats.csv"), ("prof_single", "sp_mnn_b32_kernel_stats_single_stream.csv"),
-                     ("prof_lg", "sp_lg_b64_kernel_stats.csv")):
-        f = glob.glob(os.path.join(EV, src, "**", "*kernel_stats.csv"), recursive=True)[0]
+                     ("prof_lg", "sp_lg_b64_kernel_stats.csv"), ("prof_dense", "dense_kernel_stats.csv")):
+        ff = glob.glob(os.path.join(EV, src, "**", "*kernel_stats.csv"), recursive=True)
+        if not ff:
+            continue
+        f = ff[0]
         rows = list(csv.DictReader(open(f)))
         with open(os.path.join(PR, f"{R}_{dst}"), "w", newline="") as fo:
             w = csv.writer(fo)
@@ -142,8 +149,11 @@ def write_readme(pmc, busy):
             ("sp_mnn_b32_full_dict", "`bench.py --log-assignment --dense`", "reference-complete output dict (92 MB/image dense descriptors + log_assignment)"),
             ("sp_mnn_b32_with_metrics", "`bench.py --with-metrics`", "plus MR/MMA/VDD harness metrics on the device"),
             ("sp_lg_b64", "`bench.py --config sp_lg`", "LightGlue matcher, B=64"),
-            ("silk_mnn_b32", "`bench.py --config silk_mnn`", "SiLK-shaped extractors (no pooling, 365 GFLOP/pair), B=32")]
+            ("silk_mnn_b32", "`bench.py --config silk_mnn`", "SiLK-shaped extractors (no pooling, 365 GFLOP/pair), B=32"),
+            ("silk_lg_b32", "`bench.py --config silk_lg`", "SiLK-shaped extractors + LightGlue (128-d descriptors through input_proj), B=32")]
     for name, cmd, note in rows:
+        if not os.path.exists(os.path.join(PR, f"{R}_bench_{name}.json")):
+            continue
         j = bench(name)
         A(f"| `{R}_bench_{name}.json` | {cmd} | {j['value']:.0f} | {j['ms_per_step']:.2f} | {note} |")
     cb = b.get("cpu_baseline")
@@ -159,6 +169,20 @@ def write_readme(pmc, busy):
         A("|---|---|---|---|---|---|")
         for e in b["extra_configs"]:
             A(f"| {e['config']} | {e['pairs_per_step']} | {e['value']:.0f} | {e['ms_per_step']:.3f} | {e['mean_matches']} | {e.get('note', '')[:110]} |")
+    if b.get("scale_legs"):
+        A("")
+        A("`scale_legs` of the headline line (every rank runs them after the headline at EVERY N; at N=1 the SP+LightGlue leg is BASELINE configs[3], "
+          "at N=8 it is configs[4] = 512 pairs over 8 GPUs):")
+        A("")
+        A("| config | pairs per GPU per step | n_gpus | pairs/s (whole job) | ms/step | per-rank min / max pairs/s | steps |")
+        A("|---|---|---|---|---|---|---|")
+        for e in b["scale_legs"]:
+            pr = e["per_rank_pairs_per_s"]
+            A(f"| {e['config']} | {e['pairs_per_gpu_per_step']} | {e['n_gpus']} | {e['value']:.0f} | {e['ms_per_step']:.2f} | {pr['min']:.0f} / {pr['max']:.0f} | {e['steps']} |")
+    ct = b.get("cpu_baseline_torch")
+    if ct:
+        A("")
+        A(f"`cpu_baseline_torch`: {ct['value']} {ct['unit']} ({ct['kind']}, {ct['threads']} threads; {ct['sample']}).")
     if cb and "verified_pairs" in cb:
         A("")
         A(f"Post-run verification (outside the timed region): {cb['verified_pairs']} of {cb['verified_of']} pairs of the CPU sample have GPU outputs "
@@ -177,7 +201,9 @@ def write_readme(pmc, busy):
         A("| stage | ms | achieved | fraction of the fp32-MFMA peak | other |")
         A("|---|---|---|---|---|")
         for st in b["roofline_stages"]:
-            if "achieved" in st:
+            if st.get("bound") == "hbm":
+                A(f"| {st['stage']} | {st['ms']} | {st['achieved']} {st['unit']} | {st['frac'] * 100:.1f} % of 8 TB/s | {json.dumps(st.get('kernels_ms'))} |")
+            elif "achieved" in st:
                 other = ""
                 if "hbm" in st:
                     other = f"HBM view: {st['hbm']['achieved_GBps']:.0f} GB/s algorithmic = {st['hbm']['frac'] * 100:.1f} % of 8 TB/s"
@@ -200,7 +226,7 @@ def write_readme(pmc, busy):
     A(f"* `{R}_sp_mnn_b32_kernel_stats_single_stream.csv` (`EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 "
       f"--no-cpu-baseline`): {single['Calls']} launches, average {float(single['AverageNs']) / 1e6:.3f} ms = {flop / float(single['AverageNs']) * 1e9 / 1e12:.1f} TFLOP/s. "
       "The average mixes the roofline-loop launches and the image-side layer with the event-side layer of the same shape (dense, not ReLU-sparse, "
-      "inputs: ~2 % slower, see DESIGN.md, data-dependent clocks) and the first launches of the process, which run before the device reaches its working clocks.")
+      "inputs: ~2 % slower) and the first launches of the process, which run before the device reaches its working clocks.")
     A(f"* `{R}_sp_mnn_b32_kernel_stats.csv` (same command, default two-stream schedule): average {float(over['AverageNs']) / 1e6:.3f} ms -- "
       "the event and image extractors run concurrently, so per-kernel durations there include time-sharing of the CUs; use the single-stream file for kernel rates.")
     A(f"* `{R}_pmc_conv1b.json`: separate `--pmc` passes over `bench.py --kernel-only`: {pmc.get('fetch_correction', 1.0):g} x FETCH_SIZE "
@@ -229,6 +255,41 @@ def write_readme(pmc, busy):
     for r in stats("sp_lg_b64_kernel_stats")[:12]:
         A(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
     A("")
+    dk = os.path.join(PR, f"{R}_dense_kernel_stats.csv")
+    if os.path.exists(dk):
+        A(f"## Dense descriptor maps alone (`{R}_dense_kernel_stats.csv`: `rocprofv3 --kernel-trace --stats -- python3 tools/up_bench.py`, B=32, one side, 2.95 GB of output)")
+        A("")
+        A("| kernel | calls | avg us |")
+        A("|---|---|---|")
+        for r in csv.DictReader(open(dk)):
+            if "upsample" in r["Name"]:
+                A(f"| `{r['Name'][:80]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} |")
+        ub = os.path.join(PR, f"{R}_dense_up_bench.txt")
+        if os.path.exists(ub):
+            A("")
+            A("`tools/up_bench.py --ref` (HIP events): " + " / ".join(ln.strip() for ln in open(ub).read().splitlines() if ln.strip()))
+        A("")
+    tp = os.path.join(PR, f"{R}_pmc_conv_tiles.json")
+    if os.path.exists(tp):
+        A(f"## Per-variant conv counters (`{R}_pmc_conv_tiles.json`, `tools/r3_pmc_conv.sh` + `tools/pmc_tiles.py`)")
+        A("")
+        tj = json.load(open(tp))
+        A("| kernel variant | LDS conflicts / idx-active (plain pitch -> shipped) | MFMA busy (plain -> shipped) | effective MHz | mean us (profiled) |")
+        A("|---|---|---|---|---|")
+        for k, v in tj["conflict_free_pitch"].items():
+            o = tj["plain_pitch"].get(k, {})
+            A(f"| `{k}` | {o.get('lds_bank_conflict_per_idx_active')} -> {v.get('lds_bank_conflict_per_idx_active')} | {o.get('mfma_busy_frac')} -> "
+              f"{v.get('mfma_busy_frac')} | {v.get('effective_mhz'):.0f} | {o.get('mean_us_per_launch_profiled')} -> {v.get('mean_us_per_launch_profiled')} |")
+        A("")
+    pe = os.path.join(PR, f"{R}_parity_errors.json")
+    if os.path.exists(pe):
+        A(f"## Measured float errors of the tolerance-based parity tests (`{R}_parity_errors.json`, written by `pytest -m gpu`)")
+        A("")
+        A("| comparison | measured max abs error | tolerance | largest reference magnitude |")
+        A("|---|---|---|---|")
+        for k, v in sorted(json.load(open(pe)).items()):
+            A(f"| {k} | {v['max_abs_err']:.3e} | {v['atol']:.0e} | {v['max_abs_ref']:.3g} |")
+        A("")
     extra = os.path.join(PR, f"{R}_notes.md")
     if os.path.exists(extra):  # hand-written findings of the round (experiments, A/B runs), kept next to the raw logs
         A(open(extra).read())

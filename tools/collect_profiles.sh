@@ -21,8 +21,8 @@ python bench.py --layer-table > $O/layer_table.txt 2>> $O/bench.err
 python tools/latency_b1.py 1 > $O/latency_b1.txt 2>> $O/bench.err
 echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_overlap -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_overlap.log 2>&1
-EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_single.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_overlap -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-scale-legs > $O/prof_overlap.log 2>&1
+EINX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-scale-legs > $O/prof_single.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lg -o p -- python3 $R/bench.py --config sp_lg --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_lg.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kernel_only -o p -- python3 $R/bench.py --kernel-only > $O/prof_kernel_only.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dense -o p -- python3 $R/tools/up_bench.py > $O/prof_dense.log 2>&1
@@ -31,7 +31,7 @@ echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --kernel-only > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_busy.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-scale-legs > $O/pmc_busy.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_busy_lg -o p -- python3 $R/tools/lg_bench.py --skip-linear --reps 1 > $O/pmc_busy_lg.log 2>&1
 echo "pmc done"
 ls $O
