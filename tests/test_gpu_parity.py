@@ -84,6 +84,43 @@ def test_conv_block_bit_exact(oracle, shape):
     assert np.array_equal(_np(got), exp)
 
 
+CONV16_SHAPES = [
+    # B, cin, cout, H, W, relu, bn, pool, expected N-tiles per wave
+    (1, 128, 128, 33, 44, True, True, False, 1),   # the single-pair 33x44 layers
+    (1, 128, 256, 33, 44, True, False, False, 1),  # head hidden layer, four output-channel tiles
+    (1, 128, 128, 66, 88, True, True, True, 1),    # pooled, 726 workgroups
+    (1, 64, 64, 132, 176, True, True, True, 2),    # two N-tiles per wave, pooled across lanes j^1 / j^8
+    (1, 64, 64, 132, 176, True, False, False, 2),
+    (2, 8, 20, 5, 13, False, True, False, 1),      # one chunk, ragged channels, odd size (masked halo and stores)
+    (3, 16, 70, 10, 18, True, True, True, 1),      # ragged output channels across two channel tiles, pooled
+    (1, 8, 64, 128, 256, True, False, True, 4),    # four N-tiles per wave (exactly 8192 MFMA tiles, 512 workgroups)
+]
+
+
+@pytest.mark.parametrize("shape", CONV16_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_conv16_small_grid_kernel_bit_exact(oracle, shape):
+    """conv16_kernel (v_mfma_f32_16x16x4_f32, one accumulator chain per output in the same K order as conv_block_kernel):
+    bit-equal to the oracle, and actually the kernel the dispatcher launches for these small grids."""
+    B, cin, cout, H, W, relu, bn, pool, npw = shape
+    seed = 4000 + cin * 3 + cout + H
+    x = synth.normalish(seed, (B, cin, H, W))
+    w = synth.synth_param("c.weight", (cout, cin, 3, 3), seed)
+    b = synth.uniform(seed + 1, (cout,), -0.5, 0.5)
+    bnp = scale = shift = None
+    if bn:
+        g, be = synth.uniform(seed + 2, (cout,), 0.5, 1.5), synth.uniform(seed + 3, (cout,), -0.3, 0.3)
+        mu, var = synth.uniform(seed + 4, (cout,), -0.3, 0.3), synth.uniform(seed + 5, (cout,), 0.5, 1.5)
+        g[0] = -g[0]
+        scale, shift = oracle.bn_fold(g, be, mu, var)
+        bnp = (_t(g), _t(be), _t(mu), _t(var), 1e-5)
+    exp = oracle.conv_block(x, w, b, scale, shift, relu=relu, pool=pool)
+    layer = pkg.native.ConvLayer(_t(w), _t(b), bnp, relu=relu, pool=pool)
+    got = layer(_t(x))
+    name = pkg.native.lib().einx_conv_last_kernel().decode()
+    assert name == f"conv16_kernel<{'true' if pool else 'false'},8,{npw}>", name
+    assert np.array_equal(_np(got), exp)
+
+
 # ------------------------------------------------------------------ detector post-processing
 POST = Golden("post")
 
