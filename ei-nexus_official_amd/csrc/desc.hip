@@ -750,7 +750,10 @@ EINX_EXPORT int einx_upsample_normalize(const float* raw, int B, int D, int hc, 
   EINX_CHECK_ARG(B < 65536, "batch too large");
   hipStream_t s = (hipStream_t)stream;
   UpGeom g{D, hc, wc, Hp, Wp, h0, w0, H, W, 0, 0, {0}, {0}};
-  if (W <= 384 && wc <= 63 && hc < 32768 && up_plan_units(g)) {  // the two-kernel path (the shipped geometries); others take the band kernel
+  // dynamic LDS of the store kernel (four wave slabs + the staged coarse rows) must stay within the 64 KB a launch gets
+  // without hipFuncSetAttribute
+  const size_t store_lds = ((size_t)UPS_WAVES * (UP_ROWS * 64 * einx_cdiv(W, 64) + 4) + (size_t)UPS_CC * 2 * (wc + 1)) * sizeof(float);
+  if (W <= 384 && wc <= 63 && hc < 32768 && store_lds <= 65536 && up_plan_units(g)) {  // the two-kernel path (the shipped geometries); others take the band kernel
     EINX_CHECK_ARG(ws && ws_bytes >= einx_upsample_ws_bytes(B, H, W), "workspace missing or smaller than einx_upsample_ws_bytes");
     EINX_CHECK_ARG((long)einx_cdiv(D, UPS_CC) * g.units * B < (1L << 31), "grid too large");
     float* den = (float*)ws;

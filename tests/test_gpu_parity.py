@@ -290,6 +290,9 @@ def test_normalize_map_tiles_and_channels_last_sampler(oracle, shape):
     (1, 9, 5, 7, 10, 14, (1, 2, 8, 11)),        # x2
     (1, 5, 6, 70, 120, 140, (3, 1, 110, 139)),  # 1/20 vertically: bands taller than one sweep; several column blocks
     (1, 4, 8, 9, 8, 9, (0, 0, 8, 9)),           # identity size
+    (1, 6, 4, 60, 16, 360, (0, 0, 16, 360)),    # six column sweeps + 61-word coarse rows: 64.8 KB of dynamic LDS, still the two-kernel path
+    (1, 6, 4, 63, 16, 378, (0, 0, 16, 378)),    # one word more than a launch may ask for: falls back to the band kernel
+    (2, 33, 3, 5, 70, 40, (1, 0, 68, 40)),      # bands of 23 rows: three sweeps per band (extra units), 33 channels = a ragged channel group
 ], ids=lambda c: "x".join(map(str, c[:6])))
 def test_upsample_normalize_bands(oracle, case):
     """upsample_descriptors + normalize + crop (dense outputs): band-wise kernel == per-pixel oracle, bit for bit."""
