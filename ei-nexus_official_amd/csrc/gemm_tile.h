@@ -17,7 +17,14 @@ namespace einx_gemm {
 #ifndef EINX_GEMM_BK
 #define EINX_GEMM_BK 32
 #endif
-constexpr int BM = 128, BN = 128, BK = EINX_GEMM_BK, PITCH = BK + 1;
+#ifndef EINX_GEMM_B64
+#define EINX_GEMM_B64 0
+#endif
+// EINX_GEMM_B64: fragments of TWO K-steps per ds_read_b64.  Each group of four k is stored as (k, k+2, k+1, k+3), so the lane
+// half that feeds k = 2 kk + half finds its operands of steps 2j and 2j+1 side by side; the K order of the MFMAs (hence every
+// result bit) is unchanged.  Row pitch 34: 8-byte aligned rows, and 34 r mod 64 is a permutation of the even banks, so the
+// 32 rows of a lane group hit 64 distinct banks.
+constexpr int BM = 128, BN = 128, BK = EINX_GEMM_BK, PITCH = EINX_GEMM_B64 ? BK + 2 : BK + 1;
 constexpr int LDS_FLOATS = (BM + BN) * PITCH;
 constexpr int WAVES = EINX_GEMM_WAVES;   // waves are arranged (WAVES/2) along M x 2 along N
 constexpr int THREADS = WAVES * 64;
@@ -88,10 +95,20 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
     for (int i = 0; i < STAGE; ++i) {
       const int fidx = tid + i * THREADS;
       const int r = fidx / C4, c4 = fidx % C4;
+      if (EINX_GEMM_B64) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2* pa = reinterpret_cast<f32x2*>(As + r * PITCH + c4 * 4);
+        f32x2* pb = reinterpret_cast<f32x2*>(Bs + r * PITCH + c4 * 4);
+        pa[0] = f32x2{st.ra[i][0], st.ra[i][2]};
+        pa[1] = f32x2{st.ra[i][1], st.ra[i][3]};
+        pb[0] = f32x2{st.rb[i][0], st.rb[i][2]};
+        pb[1] = f32x2{st.rb[i][1], st.rb[i][3]};
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        As[r * PITCH + c4 * 4 + t] = st.ra[i][t];
-        Bs[r * PITCH + c4 * 4 + t] = st.rb[i][t];
+        for (int t = 0; t < 4; ++t) {
+          As[r * PITCH + c4 * 4 + t] = st.ra[i][t];
+          Bs[r * PITCH + c4 * 4 + t] = st.rb[i][t];
+        }
       }
     }
   };
@@ -141,26 +158,54 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
 #ifndef EINX_GEMM_PF
 #define EINX_GEMM_PF 1
 #endif
-    constexpr int PF = EINX_GEMM_PF;  // fragment prefetch distance in K-steps
-    float av[PF + 1][MT], bv[PF + 1][NT];
-    auto load_frag = [&](int kk, int buf) {
+    if (EINX_GEMM_B64) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const int aoff2 = (wm * WROWS + l31) * PITCH + 2 * half;
+      const int boff2 = (wn * 64 + l31) * PITCH + 2 * half;
+      constexpr int NP = BK / 4;  // pairs of K-steps per slab
+      f32x2 av2[2][MT], bv2[2][NT];
+      auto load_pair = [&](int j, int buf) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
+        for (int mt = 0; mt < MT; ++mt) av2[buf][mt] = *reinterpret_cast<const f32x2*>(As + aoff2 + mt * 32 * PITCH + j * 4);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
-    };
+        for (int nt = 0; nt < NT; ++nt) bv2[buf][nt] = *reinterpret_cast<const f32x2*>(Bs + boff2 + nt * 32 * PITCH + j * 4);
+      };
+      load_pair(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < PF; ++kk) load_frag(kk, kk % (PF + 1));
+      for (int j = 0; j < NP; ++j) {
+        if (j + 1 < NP) load_pair(j + 1, (j + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      if (kk + PF < BK / 2) load_frag(kk + PF, (kk + PF) % (PF + 1));
-      __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
+        for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % (PF + 1)][mt], bv[kk % (PF + 1)][nt], f.acc[mt][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+            for (int nt = 0; nt < NT; ++nt)
+              f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j & 1][mt][h2], bv2[j & 1][nt][h2], f.acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      constexpr int PF = EINX_GEMM_PF;  // fragment prefetch distance in K-steps
+      float av[PF + 1][MT], bv[PF + 1][NT];
+      auto load_frag = [&](int kk, int buf) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
+      };
+#pragma unroll
+      for (int kk = 0; kk < PF; ++kk) load_frag(kk, kk % (PF + 1));
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        if (kk + PF < BK / 2) load_frag(kk + PF, (kk + PF) % (PF + 1));
+        __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % (PF + 1)][mt], bv[kk % (PF + 1)][nt], f.acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 }
