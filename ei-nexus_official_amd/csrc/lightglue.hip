@@ -479,11 +479,19 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       float mx = NEG;
+      if (kbase + 32 <= nk) {  // whole block (uniform): no key mask
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kbase + crow(r, half);
-        s[r] = key < nk ? s[r] * sl2 : NEG;
-        mx = fmaxf(mx, s[r]);
+        for (int r = 0; r < 16; ++r) {
+          s[r] = s[r] * sl2;
+          mx = fmaxf(mx, s[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + crow(r, half);
+          s[r] = key < nk ? s[r] * sl2 : NEG;
+          mx = fmaxf(mx, s[r]);
+        }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
@@ -498,10 +506,14 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
+      // once the running maxima have settled alpha is exactly 1 in every lane: skip the 32 multiplications by one
+      // (wave-uniform branch; bit-identical, x * 1.0f == x)
+      if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+      }
       const float* vbase = Vs + (size_t)(sub * 32 + 4 * half) * DH + l31;
       float vf[2][2];
       vf[0][0] = vbase[crow(0, 0) * DH];
