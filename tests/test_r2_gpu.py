@@ -107,6 +107,30 @@ def test_baseline_batch_sampled_pairs_vs_oracle_mnn(oracle, cfg_name, B):
     assert min(nmatch) >= 5, f"calibrated descriptors should give real matches, got {nmatch}"
 
 
+def test_other_geometry_vga_16_bins_vs_oracle(oracle):
+    """Nothing is specialised to 346x260 / 5 bins: one 640x480 pair with the reference's shipped 16 event bins (N = 307,200 score
+    pixels: the generic selection path, 60x80 heads, other conv tile choices) bit-equal to the oracle end to end."""
+    cfg = pkg.default_config("SP_MNN", event_channels=16)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=17)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    H, W = 480, 640
+    ev, mask = synth.synth_events(4321, 1, 16, H, W)
+    img = synth.synth_image(4321, 1, H, W)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oe = oracle.extractor_forward("vgg", sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=1024)
+    oi = oracle.extractor_forward("superpointv1", sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=1024)
+    for got, exp in ((ef, oe), (imf, oi)):
+        assert np.array_equal(_np(got["sparse_positions"][0]), exp["sparse_positions"][0])
+        assert np.array_equal(_np(got["sparse_descriptors"][0]), exp["sparse_descriptors"][0])
+        assert np.array_equal(_np(got["score"]), exp["score"])
+    r = oracle.mnn(oe["sparse_descriptors"][0], oi["sparse_descriptors"][0], want_la=False)
+    assert np.array_equal(_np(m["matches0"][0])[0], r["matches0"])
+    assert 0 < ef["sparse_positions"][0].shape[0] <= 1024 and tuple(ef["score"].shape) == (1, 1, H, W)
+
+
 def test_baseline_batch_sampled_pairs_vs_oracle_lightglue(oracle):
     """configs[3]: B=64 SP+LightGlue; extractor outputs bit-equal, match assignments equal, floats to 1e-4."""
     B = 64
