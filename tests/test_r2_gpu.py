@@ -107,6 +107,34 @@ def test_baseline_batch_sampled_pairs_vs_oracle_mnn(oracle, cfg_name, B):
     assert min(nmatch) >= 5, f"calibrated descriptors should give real matches, got {nmatch}"
 
 
+@pytest.mark.parametrize("cfg_name", ["SP_MNN", "SP_LG"])
+def test_pair_without_events_gives_the_reference_empty_dict_and_leaves_the_batch_alone(cfg_name):
+    """A pair whose events mask is empty has no event keypoints (score[~mask] = 0, EventExtractors.py:561-562): the matcher
+    returns the reference's empty-input dict for THAT pair (MNN.py:63-86 / lightglue.py:572-591: matches of length 0 / m, no
+    matched keypoints, zero log_assignment [1,1,m+1]) and the other pairs of the batch are exactly what they are alone."""
+    cfg, model, sd = _bench_like_model(cfg_name)
+    B = 3
+    ev, mask = synth.synth_events(777, B, 5)
+    img = synth.synth_image(777, B)
+    ev[1] = 0.0
+    mask[1] = False
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    assert ef["sparse_positions"][1].shape == (0, 3) and ef["sparse_descriptors"][1].shape == (0, 256)
+    mi = imf["sparse_positions"][1].shape[0]
+    assert mi > 0
+    assert tuple(m["matches0"][1].shape) == (1, 0) and tuple(m["matches1"][1].shape) == (1, mi)
+    assert bool((m["matches1"][1] == -1).all()) and float(m["matching_scores1"][1].abs().max()) == 0.0
+    assert tuple(m["matched_kpts0"][1].shape) == (0, 3) and tuple(m["matched_kpts1"][1].shape) == (0, 3)
+    la = m["log_assignment"][1]
+    assert tuple(la.shape) == (1, 1, mi + 1) and float(la.abs().max()) == 0.0
+    for b in (0, 2):
+        ef1, imf1, m1 = model(_t(ev[b:b + 1]), _t(img[b:b + 1]), _t(mask[b:b + 1]))
+        assert torch.equal(ef1["sparse_positions"][0], ef["sparse_positions"][b])
+        assert torch.equal(imf1["sparse_descriptors"][0], imf["sparse_descriptors"][b])
+        assert torch.equal(m1["matches0"][0], m["matches0"][b])
+        assert torch.equal(m1["matched_kpts0"][0], m["matched_kpts0"][b])
+
+
 def test_other_geometry_vga_16_bins_vs_oracle(oracle):
     """Nothing is specialised to 346x260 / 5 bins: one 640x480 pair with the reference's shipped 16 event bins (N = 307,200 score
     pixels: the generic selection path, 60x80 heads, other conv tile choices) bit-equal to the oracle end to end."""
