@@ -12,14 +12,16 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 pkg = importlib.import_module("ei-nexus_official_amd")
-wl = bench.Workload(pkg, torch.device("cuda", 0), "sp_mnn", 32)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32  # 1: single pairs (conv16 + forked head branches)
+DENSE = "--dense" in sys.argv
+wl = bench.Workload(pkg, torch.device("cuda", 0), "sp_mnn", B, dense=DENSE, log_assignment=DENSE)
 ref = wl.step()
 ref_pos = [p.clone() for p in ref[0]["sparse_positions"]]
 ref_m = [m.clone() for m in ref[2]["matches0"]]
 for chunk in range(6):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 150
+    n = 150 if B >= 8 else 600
     if chunk % 2 == 0:
         for _ in range(n):
             out = wl.step()
@@ -33,5 +35,5 @@ for chunk in range(6):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     same = all(torch.equal(a, b) for a, b in zip(out[0]["sparse_positions"], ref_pos)) and all(torch.equal(a, b) for a, b in zip(out[2]["matches0"], ref_m))
-    print(f"chunk {chunk} ({'sync' if chunk % 2 == 0 else 'stream'}): {32 * n / dt:7.1f} pairs/s, allocated {torch.cuda.memory_allocated() / 1e6:8.1f} MB, "
+    print(f"chunk {chunk} ({'sync' if chunk % 2 == 0 else 'stream'}): {B * n / dt:7.1f} pairs/s, allocated {torch.cuda.memory_allocated() / 1e6:8.1f} MB, "
           f"reserved {torch.cuda.memory_reserved() / 1e6:8.1f} MB, outputs identical: {same}", flush=True)
