@@ -66,6 +66,19 @@ class BatchedFeats:
     def positions(self):
         return self.det.positions
 
+    def run_dense(self):
+        """The dense by-product (`normalized_descriptors`: upsample + normalise, cropped), enqueued on the CURRENT stream.  Part
+        of the extractor call unless the caller deferred it (EIM schedules it beside the other extractor's convolutions)."""
+        if not self.dense or self.normalized is not None:
+            return
+        w0, w1, h0, h1 = self.pads
+        Hp, Wp = self.padded
+        if self.cell == 8:
+            self.normalized = N.upsample_normalize(self.raw, (Hp, Wp), self.pads, self.scale)
+        else:
+            nd = N.normalize_map(self.raw, self.scale)
+            self.normalized = nd[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+
     def prepare(self):
         """Everything of the output dict that does not depend on the keypoint counts.  Called BEFORE
         the host waits for the counts, so the crop/clone kernels and the Python work run while the
@@ -88,6 +101,7 @@ class BatchedFeats:
         if self.cell == 8:
             out["coarse_descriptors"] = self.coarse
         if self.dense:
+            self.run_dense()  # no-op unless a caller deferred it and never ran it
             nd = self.normalized
             out["normalized_descriptors"] = nd
             C = nd.shape[1]
@@ -194,7 +208,7 @@ class ExtractorEngine:
             self._shapes[(H, W)] = s
         return s
 
-    def _run_handle(self, h, sh, x, mask, pads, scale, dense, nms_iters):
+    def _run_handle(self, h, sh, x, mask, pads, scale, dense, nms_iters, defer_dense=False):
         L = N.lib()
         dev = x.device
         B, _, H, W = x.shape
@@ -223,13 +237,8 @@ class ExtractorEngine:
         out = _lib.ExtractOut(P(bf.feats), P(bf.logits), P(bf.raw), P(bf.prob), P(bf.score), P(bf.coarse), P(bf.raw_cl), P(det.nms),
                               P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap)
         _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), nws, ctypes.byref(out), N._stream(x)), "einx_extract")
-        if dense:
-            w0, w1, h0, h1 = pads
-            if self.cell == 8:
-                bf.normalized = N.upsample_normalize(bf.raw, (Hp, Wp), pads, scale)
-            else:
-                nd = N.normalize_map(bf.raw, scale)
-                bf.normalized = nd[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+        if dense and not defer_dense:
+            bf.run_dense()
         return bf
 
     def redetect(self, bf, nms_iters=None):
@@ -268,7 +277,7 @@ class ExtractorEngine:
                 self.nms_iters = max(self.nms_base, self.nms_iters // 2)
                 self._calm = 0
 
-    def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None, input_div=0.0):
+    def run(self, x, mask, *, scale, dilate_mask, dense=False, nms_iters=None, input_div=0.0, defer_dense=False):
         """One einx_extract call (handle-level ABI) enqueues the whole network; the op-by-op path below it serves the
         unbounded-capacity configurations (no top-k: the descriptor buffer is sized from the real counts)."""
         if x.dim() != 4:
@@ -301,7 +310,7 @@ class ExtractorEngine:
             h = self.handle(scale, dilate_mask, input_div)
             sh = self.shapes(h, H, W)
             if sh.cap <= 8192 and self.use_handle:
-                return self._run_handle(h, sh, x, mask, pads, scale, dense, nms_iters or self.nms_iters)
+                return self._run_handle(h, sh, x, mask, pads, scale, dense, nms_iters or self.nms_iters, defer_dense=defer_dense)
         if input_div:
             N.div_inplace(x, input_div)
         t = x
@@ -335,10 +344,6 @@ class ExtractorEngine:
         prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
         bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
         self.redetect(bf, nms_iters)
-        if dense:
-            if self.cell == 8:
-                bf.normalized = N.upsample_normalize(raw, (Hp, Wp), pads, scale)
-            else:
-                nd = N.normalize_map(raw, scale)
-                bf.normalized = nd[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+        if dense and not defer_dense:
+            bf.run_dense()
         return bf

@@ -92,8 +92,9 @@ class NativeExtractor(nn.Module):
     def _prepare_input(self, x):
         return x
 
-    def extract_batched(self, x, score_mask=None, nms_iters=None, dense=None, prepared=False):
-        """prepared=True: `x` already went through _prepare_input (retry after an NMS overflow)."""
+    def extract_batched(self, x, score_mask=None, nms_iters=None, dense=None, prepared=False, defer_dense=False):
+        """prepared=True: `x` already went through _prepare_input (retry after an NMS overflow).
+        defer_dense=True: the dense descriptor map is left to the caller (`bf.run_dense()` on a stream of its choice)."""
         if self.training and self.uses_batchnorm:
             raise RuntimeError("the native path implements eval-mode BatchNorm (running statistics) only; call .eval() first")
         if not prepared:
@@ -103,7 +104,7 @@ class NativeExtractor(nn.Module):
             self._scale_host = float(self.descriptor_scale_factor.detach())
         scale = self._scale_host
         return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
-                       nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div)
+                       nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
 
     def forward(self, x, score_mask=None, **kwargs):
         bf = self.extract_batched(x, score_mask)
