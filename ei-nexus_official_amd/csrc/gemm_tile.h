@@ -144,10 +144,19 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
 #pragma unroll
     for (int i = 0; i < STAGE; ++i) st.rb[i] = *reinterpret_cast<const f32x4*>(bk + offb[i]);
   };
+#ifndef EINX_GEMM_ABL
+#define EINX_GEMM_ABL 0  // timing-only ablations (wrong results; tools/r3_exp16.sh): 1 no LDS commit (the loads die with it), 2 also one barrier per slab, 3 also no global loads, 4 loads kept alive but no LDS writes
+#endif
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();  // the previous slab's (or tile's) fragment reads are done
-    commit();
-    __syncthreads();
+    if (EINX_GEMM_ABL == 0) commit();
+    if (EINX_GEMM_ABL == 4) {
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) asm volatile("" ::"v"(st.ra[i]), "v"(st.rb[i]));
+    }
+    if (EINX_GEMM_ABL < 2) __syncthreads();
+    if (EINX_GEMM_ABL == 3) {
+    } else
     if (k0 + BK < K) {  // in flight under the MFMAs below
       if (whole) issue_whole(k0 + BK);
       else issue_slab(cur, k0 + BK, K, Ksplit, st);

@@ -82,8 +82,11 @@ struct GemmArgs {
 // the same 128 rows of X are computed on one XCD at about the same time and X is fetched into that
 // L2 once.  The next tile's first K-slab is requested during the current tile's last K-slab, so its
 // latency and the epilogue's stores overlap instead of serialising per tile.
+#ifndef EINX_GEMM_WG_PER_CU
+#define EINX_GEMM_WG_PER_CU 2  // resident workgroups per CU the register budget is set for
+#endif
 template <int EPI>
-__global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(const GemmArgs g) {  // two workgroups per CU
+__global__ __launch_bounds__(THREADS, EINX_GEMM_WG_PER_CU * THREADS / 256) void lg_gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tilesN = einx_cdiv(g.N, BN), tilesM = einx_cdiv(g.cap, BM);
   const int groups = tilesM * g.B;                       // A-row groups
@@ -693,6 +696,7 @@ unsigned gemm_grid(int tiles) {
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lg_gemm_kernel<EPI_BIAS>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     }
+    if (const char* e = getenv("EINX_GEMM_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // experiments: cap the resident workgroups per CU
     resident = (cus * per_cu) & ~7;
     if (resident < 8) resident = 8;
   }
