@@ -117,12 +117,13 @@ __global__ void random_positions_kernel(const float* u, int R, float s0, float s
   out[t * 3 + 2] = 0.0f;
 }
 
-// normalize_descriptors through LDS: a workgroup stages PT pixels x D channels with fully coalesced,
-// deeply pipelined loads (the thread-per-pixel form below issues D dependent strided loads from far
-// too few threads), one lane per pixel then walks the channels as the same sequential fmaf chain
-// c = 0..D-1, and all threads write the normalised map -- plus, optionally, the channels-last copy
-// of the raw map that desc_sample_kernel<.., CL> gathers from.  Element (c, pixel) lives at
-// lds[c*PT + ((pixel + c) & (PT-1))]: conflict-free along pixels and along channels.
+// normalize_descriptors through LDS: a workgroup stages PT pixels x D channels with fully coalesced loads, NM_BATCH of them
+// in flight per thread (clamped addresses, no branch around the load: a predicated loop body is neither unrolled nor
+// pipelined by hipcc and costs one HBM round trip per channel), one lane per pixel then walks the channels as the same
+// sequential fmaf chain c = 0..D-1, and all threads write the normalised map -- plus, optionally, the channels-last copy of
+// the raw map that desc_sample_kernel<.., CL> gathers from (one pixel's D channels per wave pass: contiguous stores, no
+// index division).  Element (c, pixel) lives at lds[c*PT + ((pixel + c) & (PT-1))]: conflict-free along pixels and channels.
+constexpr int NM_BATCH = 16;
 template <int PT>
 __global__ __launch_bounds__(256) void normalize_map_tile_kernel(const float* raw, int D, int P, float scale, float* out, float* raw_cl) {
   extern __shared__ float tile[];
@@ -133,7 +134,18 @@ __global__ __launch_bounds__(256) void normalize_map_tile_kernel(const float* ra
   const int px = tid % PT, cgrp = tid / PT;
   constexpr int CG = 256 / PT;  // channels handled per sweep
   const bool pv = p0 + px < P;
-  for (int c = cgrp; c < D; c += CG) tile[c * PT + ((px + c) & (PT - 1))] = pv ? rb[(size_t)c * P + p0 + px] : 0.0f;
+  const float* src = rb + (pv ? p0 + px : P - 1);
+  {
+    int c = cgrp;
+    for (; c + (NM_BATCH - 1) * CG < D; c += NM_BATCH * CG) {
+      float v[NM_BATCH];
+#pragma unroll
+      for (int u = 0; u < NM_BATCH; ++u) v[u] = src[(size_t)(c + u * CG) * P];
+#pragma unroll
+      for (int u = 0; u < NM_BATCH; ++u) tile[(c + u * CG) * PT + ((px + c + u * CG) & (PT - 1))] = pv ? v[u] : 0.0f;
+    }
+    for (; c < D; c += CG) tile[c * PT + ((px + c) & (PT - 1))] = pv ? src[(size_t)c * P] : 0.0f;
+  }
   __syncthreads();
   if (tid < PT) {
     // one lane per pixel walks the channels in order; the LDS reads of 16 channels are in flight at a time so
@@ -157,13 +169,23 @@ __global__ __launch_bounds__(256) void normalize_map_tile_kernel(const float* ra
   if (pv) {
     const float den = s_den[px];
     float* ob = out + (size_t)b * D * P + p0 + px;
-    for (int c = cgrp; c < D; c += CG) ob[(size_t)c * P] = scale * (tile[c * PT + ((px + c) & (PT - 1))] / den);
+    int c = cgrp;
+    for (; c + 3 * CG < D; c += 4 * CG) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = scale * (tile[(c + u * CG) * PT + ((px + c + u * CG) & (PT - 1))] / den);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ob[(size_t)(c + u * CG) * P] = v[u];
+    }
+    for (; c < D; c += CG) ob[(size_t)c * P] = scale * (tile[c * PT + ((px + c) & (PT - 1))] / den);
   }
   if (raw_cl) {
     float* cb = raw_cl + ((size_t)b * P + p0) * D;
-    for (int e = tid; e < PT * D; e += 256) {
-      const int pixel = e / D, c = e % D;
-      if (p0 + pixel < P) cb[(size_t)pixel * D + c] = tile[c * PT + ((pixel + c) & (PT - 1))];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int npx = min(PT, P - p0);
+    for (int pixel = wave; pixel < npx; pixel += 4) {
+      float* cp = cb + (size_t)pixel * D;
+      for (int c = lane; c < D; c += 64) cp[c] = tile[c * PT + ((pixel + c) & (PT - 1))];
     }
   }
 }
@@ -668,10 +690,7 @@ EINX_EXPORT int einx_normalize_map(const float* raw, int B, int D, int P, float 
   EINX_CHECK_ARG(B > 0 && D > 0 && P > 0, "bad shape");
   hipStream_t s = (hipStream_t)stream;
   EINX_PROF("normalize_map", s);
-  if (D <= 256) {
-    hipLaunchKernelGGL(normalize_map_tile_kernel<64>, dim3((unsigned)einx_cdiv(P, 64), (unsigned)B), dim3(256), (size_t)D * 64 * sizeof(float), s,
-                       raw, D, P, scale, out, raw_cl);
-  } else if (D <= 512) {
+  if (D <= 512) {  // 32-pixel tiles: 128-byte rows per channel, D * 128 bytes of LDS (4-5 workgroups per CU at D = 256)
     hipLaunchKernelGGL(normalize_map_tile_kernel<32>, dim3((unsigned)einx_cdiv(P, 32), (unsigned)B), dim3(256), (size_t)D * 32 * sizeof(float), s,
                        raw, D, P, scale, out, raw_cl);
   } else {

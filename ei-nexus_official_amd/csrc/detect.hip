@@ -17,17 +17,20 @@ namespace {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool mask_on(const uint8_t* mask, int b, int H, int W, int h0, int w0, int Hp, int Wp, int y, int x,
                                         int dilate) {
-  // mask zero-padded to [Hp,Wp]; optional 3x3 dilation evaluated inside the padded map
+  // mask zero-padded to [Hp,Wp]; optional 3x3 dilation evaluated inside the padded map.  The nine bytes are requested
+  // together (clamped addresses, validity folded into the test): no dependent load-and-branch chain per pixel
   const int r = dilate ? 1 : 0;
-  for (int dy = -r; dy <= r; ++dy)
-    for (int dx = -r; dx <= r; ++dx) {
-      const int yy = y + dy, xx = x + dx;
-      if (yy < 0 || yy >= Hp || xx < 0 || xx >= Wp) continue;
-      const int sy = yy - h0, sx = xx - w0;
-      if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-      if (mask[((size_t)b * H + sy) * W + sx]) return true;
+  bool any = false;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx, sy = yy - h0, sx = xx - w0;
+      const bool ok = dy >= -r && dy <= r && dx >= -r && dx <= r && yy >= 0 && yy < Hp && xx >= 0 && xx < Wp && sy >= 0 && sy < H && sx >= 0 && sx < W;
+      const uint8_t m = mask[((size_t)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)];
+      any |= ok && m != 0;
     }
-  return false;
+  return any;
 }
 
 // 8 lanes per cell: lane (cell j, row i) of a wave is lane j + 8*i and owns channels 8i..8i+7, i.e.
@@ -69,6 +72,29 @@ __global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B
   const int Hp = hc * 8, Wp = wc * 8;
   float* pr = prob + (size_t)b * 65 * cells + cell;
   const int y = h * 8 + i;
+  // events mask of the lane's 8 pixels (row y, columns 8w..8w+7), dilated 3x3 inside the padded map: the 3 x 10 bytes around
+  // them are requested together (clamped addresses, validity folded into the bit), bit k of `cols` = some row has an event in
+  // column 8w-1+k; a per-pixel mask_on() walk is up to 72 dependent byte loads per lane
+  unsigned cols = 0x3ffu;
+  if (mask) {
+    cols = 0;
+    const int r = dilate ? 1 : 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = y + dy, sy = yy - h0;
+      const bool rok = dy >= -r && dy <= r && yy >= 0 && yy < Hp && sy >= 0 && sy < H;
+      const uint8_t* mrow = mask + ((size_t)b * H + min(max(sy, 0), H - 1)) * W;
+      uint8_t m[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) m[k] = mrow[min(max(w * 8 - 1 + k - w0, 0), W - 1)];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int xx = w * 8 - 1 + k, sx = xx - w0;
+        if (rok && xx >= 0 && xx < Wp && sx >= 0 && sx < W && m[k]) cols |= 1u << k;
+      }
+    }
+  }
+  const unsigned window = (mask && !dilate) ? 2u : 7u;  // without dilation only the centre column counts
   float out[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -76,7 +102,7 @@ __global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B
     pr[(size_t)(8 * i + k) * cells] = p;
     const int x = w * 8 + k;
     float t = p;
-    if (mask && !mask_on(mask, b, H, W, h0, w0, Hp, Wp, y, x, dilate)) t = 0.0f;
+    if (!((cols >> k) & window)) t = 0.0f;
     if (border > 0 && (y < border || y >= Hp - border || x < border || x >= Wp - border)) t = 0.0f;
     out[k] = t;
   }
