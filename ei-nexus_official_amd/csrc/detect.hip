@@ -723,15 +723,42 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
       for (int t = 0; t < 4; ++t) v[t] = (i + t < N) ? m[i + t] : 0.0f;
     }
   };
+  // whole 16-byte groups only (every shipped geometry): SEL_UB loads per lane are requested together from clamped
+  // addresses and zeroed when they lie past the slice -- a loop of one guarded load per iteration is neither unrolled nor
+  // pipelined by hipcc and costs a memory round trip per 256 values (23 in a row on a 264x352 map)
+  constexpr int SEL_UB = 8;
+  const bool fast = vec && (N & 3) == 0 && N >= 4;
+  auto load_batch = [&](int i0, f32x4* q) {
+#pragma unroll
+    for (int u = 0; u < SEL_UB; ++u) {
+      const int idx = i0 + u * 256 + lane * 4;
+      q[u] = *reinterpret_cast<const f32x4*>(m + min(idx, N - 4));
+      if (idx >= w1) q[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
   int cnt_w = 0;
   bool neg = false;
-  for (int i0 = w0; i0 < w1; i0 += 256) {
-    float v[4];
-    load4(i0 + lane * 4, v);
+  if (fast) {
+    for (int i0 = w0; i0 < w1; i0 += 256 * SEL_UB) {
+      f32x4 q[SEL_UB];
+      load_batch(i0, q);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      cnt_w += (v[t] != 0.0f) ? 1 : 0;
-      neg = neg || (v[t] < 0.0f) || (v[t] != v[t]);
+      for (int u = 0; u < SEL_UB; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          cnt_w += (q[u][t] != 0.0f) ? 1 : 0;
+          neg = neg || (q[u][t] < 0.0f) || (q[u][t] != q[u][t]);
+        }
+    }
+  } else {
+    for (int i0 = w0; i0 < w1; i0 += 256) {
+      float v[4];
+      load4(i0 + lane * 4, v);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        cnt_w += (v[t] != 0.0f) ? 1 : 0;
+        neg = neg || (v[t] < 0.0f) || (v[t] != v[t]);
+      }
     }
   }
 #pragma unroll
@@ -752,10 +779,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
   const int nz = scratch[16];
   if (!sh_bad && nz <= SEL_LCAP) {
     int pos_w = scratch[wave];
-    for (int i0 = w0; i0 < w1; i0 += 256) {
-      float v[4];
-      const int i = i0 + lane * 4;
-      load4(i, v);
+    auto place = [&](int i, const float* v) {  // 256 values of the slice in raster order: lane-local counts, wave scan, scatter
       int c = 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) c += (v[t] != 0.0f) ? 1 : 0;
@@ -774,6 +798,23 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
           ++pos;
         }
       pos_w += __shfl(incl, 63, 64);
+    };
+    if (fast) {
+      for (int i0 = w0; i0 < w1; i0 += 256 * SEL_UB) {
+        f32x4 q[SEL_UB];
+        load_batch(i0, q);
+#pragma unroll
+        for (int u = 0; u < SEL_UB; ++u) {
+          const float v[4] = {q[u][0], q[u][1], q[u][2], q[u][3]};
+          if (i0 + u * 256 < w1) place(i0 + u * 256 + lane * 4, v);
+        }
+      }
+    } else {
+      for (int i0 = w0; i0 < w1; i0 += 256) {
+        float v[4];
+        load4(i0 + lane * 4, v);
+        place(i0 + lane * 4, v);
+      }
     }
   }
   __syncthreads();
