@@ -87,3 +87,45 @@ def test_batch_96_dense_descriptor_map_beyond_2_31_elements_equals_the_small_bat
     n = torch.linalg.vector_norm(nd[95], dim=0)
     scale = float(model.event_extractor.extractor.descriptor_scale_factor)
     assert float((n - scale).abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------ score map: events mask placement / dilation, div_inplace sizes
+@pytest.mark.parametrize("C,hc,wc,pads", [(65, 5, 7, (3, 3, 2, 2)), (65, 33, 44, (3, 3, 2, 2)), (65, 4, 6, (0, 0, 0, 0)), (1, 37, 53, (0, 0, 0, 0)),
+                                          (65, 3, 5, (1, 7, 5, 3))], ids=["c65_5x7", "c65_33x44", "c65_nopad", "c1_37x53", "c65_lopsided_pads"])
+@pytest.mark.parametrize("dilate", [False, True])
+def test_score_map_mask_placements_vs_oracle(oracle, C, hc, wc, pads, dilate):
+    """softmax / sigmoid + pixel shuffle + `score[~mask] = 0` (mask zero-padded, optionally dilated 3x3 inside the padded map,
+    EventExtractors.py:544-562) + border: single events in every corner, on the image edges, next to the padding, isolated
+    pixels and a random 2 % mask; the batched mask loads of the kernels must give exactly the per-pixel walk of the oracle."""
+    N = pkg.native
+    B = 3
+    cell = 8 if C == 65 else 1
+    Hp, Wp = hc * cell, wc * cell
+    w0, w1, h0, h1 = pads
+    H, W = Hp - h0 - h1, Wp - w0 - w1
+    rng = np.random.default_rng(C * 1000 + hc * 10 + int(dilate))
+    logits = rng.standard_normal((B, C, hc, wc)).astype(np.float32) * 2
+    mask = np.zeros((B, 1, H, W), bool)
+    for y, x in ((0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (H // 2, 0), (0, W // 2), (H // 2, W // 2), (H - 1, W // 3), (H // 3, W - 1)):
+        mask[0, 0, y, x] = True
+    mask[1, 0] = rng.random((H, W)) < 0.02
+    mask[2, 0, ::7, ::5] = True
+    for border in (0, 4):
+        prob, score = N.score_map(_t(logits), _t(mask), pads, dilate=dilate, border=border)
+        eprob, escore = oracle.logits_to_score(logits)
+        oracle.mask_border(escore, mask, pads, dilate, border)
+        # cell-1 networks: `probability` aliases `score` in the reference (depth_to_space returns its input), zeros included
+        assert np.array_equal(prob.cpu().numpy(), eprob if C == 65 else escore)
+        assert np.array_equal(score.cpu().numpy(), escore), f"border {border}"
+        assert float(escore.max()) > 0.0
+    _, s_none = N.score_map(_t(logits), None, pads, dilate=dilate, border=0)
+    assert np.array_equal(s_none.cpu().numpy(), oracle.logits_to_score(logits)[1])
+
+
+@pytest.mark.parametrize("n", [1, 255, 1023, 1024, 1025, 4097, 260 * 346, 3 * 260 * 346 + 5])
+def test_div_inplace_sizes(n):
+    N = pkg.native
+    x = torch.arange(n, dtype=torch.float32, device=DEV) * 0.37 + 1.0
+    ref = (x.cpu().numpy() / np.float32(255.0)).astype(np.float32)
+    N.div_inplace(x, 255.0)
+    assert np.array_equal(x.cpu().numpy(), ref)
