@@ -510,6 +510,16 @@ __global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
   for (int n = 0; n < NPW; ++n) acc[n] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
   const int nchunks = a.Cin / CK;
   issue_loads(0);
+  // the epilogue's per-channel constants are requested here, behind the first chunk's loads: fetched in the epilogue they are
+  // twelve guarded loads that hipcc serialises (a memory round trip each) at the end of a latency-bound workgroup
+  float e_bi[4], e_sc[4], e_sh[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int coc = min(co0 + wave * 16 + 4 * q + i, a.Cout - 1);
+    e_bi[i] = a.bias ? a.bias[coc] : 0.0f;
+    e_sc[i] = a.scale ? a.scale[coc] : 1.0f;
+    e_sh[i] = a.scale ? a.shift[coc] : 0.0f;
+  }
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();
 #pragma unroll
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
   for (int i = 0; i < 4; ++i) {
     const int co = co0 + wave * 16 + 4 * q + i;
     const bool cv = co < a.Cout;
-    const float bi = (cv && a.bias) ? a.bias[co] : 0.0f, sc = (cv && a.scale) ? a.scale[co] : 1.0f, sh = (cv && a.scale) ? a.shift[co] : 0.0f;
+    const float bi = e_bi[i], sc = e_sc[i], sh = e_sh[i];
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
       const int y = y0 + ty, x = x0 + 8 * n + tx;
