@@ -232,22 +232,34 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
   } else {
     const size_t pitch = (size_t)a.cap1 + 1;
     float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;
+    // the (max, lse) pairs of the lane's columns and rows are requested together from clamped addresses: loads guarded per
+    // element are serialised by hipcc (one L2 round trip each, 16 x 6 in a row -- longer than the tile's K loop)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 cst[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
+      cst[nt] = *reinterpret_cast<const f32x2*>(a.collse + ((size_t)b * a.cap1 + min(j0 + col_of(nt), m - 1)) * 2);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x2 rst[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rst[r] = *reinterpret_cast<const f32x2*>(a.rowlse + ((size_t)b * a.cap0 + min(i0 + row_of(mt, r), n - 1)) * 2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + row_of(mt, r);
         if (i >= n) continue;
-        const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
+        const float rm = rst[r][0], rl = rst[r][1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int j = j0 + col_of(nt);
           if (j >= m) continue;
-          const float cm = a.collse[((size_t)b * a.cap1 + j) * 2], cl = a.collse[((size_t)b * a.cap1 + j) * 2 + 1];
+          const float cm = cst[nt][0], cl = cst[nt][1];
           const float sv = f.acc[mt][nt][r];
           la[(size_t)i * pitch + j] = LG ? sv : ((sv - rm) - rl) + ((sv - cm) - cl);
         }
       }
+    }
   }
 }
 
