@@ -577,6 +577,102 @@ __global__ __launch_bounds__(256) void conv16_kernel(const ConvArgs a) {
   }
 }
 
+// 1x1 layers of small grids (the heads' second layers at single pairs) on the same instruction: workgroup = 64 output
+// channels x 16 NPW consecutive pixels of the flattened map, 4 waves = 4 M-tiles of 16 channels; K = the input channels in
+// their natural order (the 1x1 case of the K order above), 32 per LDS round = 8 instructions.  The 128-pixel tiles of
+// conv_block_kernel<1,...> give a 33x44 map 12 workgroups per 64 channels, each walking 8 rounds of 32 dependent 64-cycle
+// instructions per wave (23.6 us per launch at B=1); here 91 workgroups per 64 channels walk 8 x 8 40-cycle instructions.
+// Cin must be a multiple of 32.  Weight rows sit 80 floats apart in LDS (k rows q = 0..3 of one instruction on banks
+// 0 / 16 / 0 / 16 + channel: conflict-free per half-wave); pixel columns past the map read a clamped address and are never stored.
+template <int NPW>
+__global__ __launch_bounds__(256) void conv16_1x1_kernel(const ConvArgs a) {
+  constexpr int CK = 32, G = CK / 4, NPX = 16 * NPW, WP = kCoutTile + 16;
+  constexpr int IN_PER_THR = CK * NPX / 256, W_PER_THR = CK * (kCoutTile / 4) / 256;
+  __shared__ __attribute__((aligned(16))) float in_tile[CK * NPX];
+  __shared__ __attribute__((aligned(16))) float w_tile[CK * WP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, j = lane & 15;
+  const int HW = a.H * a.W;
+  const int tile = (int)blockIdx.x % a.tilesX, b = (int)blockIdx.x / a.tilesX;
+  const int co0 = (int)blockIdx.y * kCoutTile;
+  const int p0 = tile * NPX;
+  const float* in_b = a.in + (size_t)b * a.Cin * HW;
+  unsigned goff[IN_PER_THR], loff[IN_PER_THR];
+#pragma unroll
+  for (int i = 0; i < IN_PER_THR; ++i) {
+    const int e = tid + i * 256;
+    const int ch = e / NPX, px = e % NPX;
+    goff[i] = (unsigned)ch * (unsigned)HW + (unsigned)min(p0 + px, HW - 1);
+    loff[i] = (unsigned)e;
+  }
+  unsigned woff[W_PER_THR], wl[W_PER_THR];
+#pragma unroll
+  for (int i = 0; i < W_PER_THR; ++i) {
+    const int f = tid + i * 256;
+    const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
+    woff[i] = (unsigned)(r * a.CoutPad + co0 + c4 * 4);
+    wl[i] = (unsigned)(r * WP + c4 * 4);
+  }
+  float r_in[IN_PER_THR];
+  f32x4 r_w[W_PER_THR];
+  auto issue_loads = [&](int c) {
+    const float* ib = in_b + (size_t)c * CK * HW;
+#pragma unroll
+    for (int i = 0; i < IN_PER_THR; ++i) r_in[i] = ib[goff[i]];
+    const float* wb = a.w + (size_t)c * CK * a.CoutPad;
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i) r_w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+  };
+  f32x4v acc[NPW];
+#pragma unroll
+  for (int n = 0; n < NPW; ++n) acc[n] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+  const int nchunks = a.Cin / CK;
+  issue_loads(0);
+  float e_bi[4], e_sc[4], e_sh[4];  // epilogue constants, requested behind the first round's loads (see conv16_kernel)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int coc = min(co0 + wave * 16 + 4 * q + i, a.Cout - 1);
+    e_bi[i] = a.bias ? a.bias[coc] : 0.0f;
+    e_sc[i] = a.scale ? a.scale[coc] : 1.0f;
+    e_sh[i] = a.scale ? a.shift[coc] : 0.0f;
+  }
+  const int aoff = q * WP + wave * 16 + j, boff = q * NPX + j;
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IN_PER_THR; ++i) in_tile[loff[i]] = r_in[i];
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i) *reinterpret_cast<f32x4*>(w_tile + wl[i]) = r_w[i];
+    __syncthreads();
+    if (c + 1 < nchunks) issue_loads(c + 1);
+    float av[G], bv[G][NPW];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      av[g] = w_tile[aoff + g * 4 * WP];
+#pragma unroll
+      for (int n = 0; n < NPW; ++n) bv[g][n] = in_tile[boff + g * 4 * NPX + 16 * n];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int n = 0; n < NPW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], bv[g][n], acc[n], 0, 0, 0);
+  }
+  // ---- epilogue: bias -> ReLU -> BN affine -> NCHW store; C row 4q + i = output channel, column j = pixel
+  float* out_b = a.out + (size_t)b * a.Cout * HW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + wave * 16 + 4 * q + i;
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int p = p0 + 16 * n + j;
+      float v = acc[n][i] + e_bi[i];
+      if (a.relu) v = v > 0.0f ? v : 0.0f;
+      if (a.scale) v = fmaf(v, e_sc[i], e_sh[i]);
+      if (co < a.Cout && p < HW) out_b[(size_t)co * HW + p] = v;
+    }
+  }
+}
+
 // OIHW -> native [K][CoutPad], K = (ci>>1)*2*taps + tap*2 + (ci&1); zero padded.
 __global__ void conv_repack_kernel(const float* w, int cin, int cout, int taps, int coutPad, int krows, float* out) {
   const size_t n = (size_t)krows * coutPad;
@@ -719,6 +815,29 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     // enough waves to hide the staging latency (768 -> 1536 workgroups for 256 output channels at B=32)
     const long blocks256 = (long)einx_cdiv(H * W, 256) * B * (a.CoutPad / kCoutTile);
     a.tilesY = 1;
+    {  // small grids: one 16x16 accumulator per wave (conv16_1x1_kernel), the widest pixel run that still gives 512 workgroups
+      static const long max_wg128 = getenv("EINX_CONV16_1X1_MAX_WG") ? atol(getenv("EINX_CONV16_1X1_MAX_WG")) : 512;
+      const long blocks128 = (long)einx_cdiv(H * W, 128) * B * (a.CoutPad / kCoutTile);
+      if (blocks128 < max_wg128 && d->cin % 32 == 0) {
+        int npw = 1;
+        for (int cand = 4; cand > 1; cand >>= 1)
+          if ((long)einx_cdiv(H * W, 16 * cand) * B * (a.CoutPad / kCoutTile) >= 512) {
+            npw = cand;
+            break;
+          }
+        a.tilesX = einx_cdiv(H * W, 16 * npw);
+        dim3 grid((unsigned)(a.tilesX * B), (unsigned)(a.CoutPad / kCoutTile));
+        static thread_local char nm[64];
+        snprintf(nm, sizeof nm, "conv16_1x1_kernel<%d>", npw);
+        g_last_conv_kernel = nm;
+        EINX_PROF("conv16_1x1_kernel (small grid)", s);
+        if (npw == 4) hipLaunchKernelGGL(conv16_1x1_kernel<4>, grid, dim3(256), 0, s, a);
+        else if (npw == 2) hipLaunchKernelGGL(conv16_1x1_kernel<2>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv16_1x1_kernel<1>, grid, dim3(256), 0, s, a);
+        EINX_CHECK_LAUNCH();
+        return EINX_OK;
+      }
+    }
     if (blocks256 < 1024) {
       a.tilesX = einx_cdiv(H * W, 128);
       launch<1, 1, 128, 1, 4, 2, 1, 32, false>(a, B, s);
@@ -777,7 +896,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         a.tilesX = einx_cdiv(W, 8 * npw);
         a.tilesY = einx_cdiv(H, 2);
         dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
-        static char nm[64];
+        static thread_local char nm[64];
         snprintf(nm, sizeof nm, "conv16_kernel<%s,8,%d>", d->pool ? "true" : "false", npw);
         g_last_conv_kernel = nm;
         EINX_PROF("conv16_kernel 3x3 (small grid)", s);

@@ -121,6 +121,50 @@ def test_conv16_small_grid_kernel_bit_exact(oracle, shape):
     assert np.array_equal(_np(got), exp)
 
 
+CONV16_1X1_SHAPES = [
+    # B, cin, cout, H, W, relu, bn, N-tiles per wave
+    (1, 256, 65, 33, 44, False, True, 1),    # detector head's 1x1 at a single pair: 65 channels over two channel tiles
+    (1, 256, 256, 33, 44, False, True, 1),   # descriptor head's 1x1
+    (1, 256, 65, 33, 44, False, False, 1),   # SuperPoint's convPb (no BN)
+    (2, 32, 20, 5, 13, True, False, 1),      # one round, ragged pixel run (65 pixels) and ragged channels, ReLU
+    (3, 64, 130, 9, 31, True, True, 1),      # three channel tiles, last with two channels
+    (1, 128, 128, 130, 173, False, True, 4), # cell-1 heads at a quarter-size map: four N-tiles per wave, ragged last tile
+    (1, 128, 1, 60, 80, False, True, 1),     # SiLK's one-channel detector output
+    (2, 64, 128, 60, 80, True, True, 2),     # two N-tiles per wave
+]
+
+
+@pytest.mark.parametrize("shape", CONV16_1X1_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_conv16_1x1_small_grid_kernel_bit_exact(oracle, shape):
+    """conv16_1x1_kernel (1x1 layers of small grids on v_mfma_f32_16x16x4_f32, K = input channels in natural order): bit-equal to
+    the oracle and to conv_block_kernel<1,...> (the same layer at a batch the dispatcher sends there), and the kernel
+    the dispatcher really launches."""
+    B, cin, cout, H, W, relu, bn, npw = shape
+    seed = 5000 + cin * 3 + cout + H
+    x = synth.normalish(seed, (B, cin, H, W))
+    w = synth.synth_param("c.weight", (cout, cin, 1, 1), seed)
+    b = synth.uniform(seed + 1, (cout,), -0.5, 0.5)
+    bnp = scale = shift = None
+    if bn:
+        g, be = synth.uniform(seed + 2, (cout,), 0.5, 1.5), synth.uniform(seed + 3, (cout,), -0.3, 0.3)
+        mu, var = synth.uniform(seed + 4, (cout,), -0.3, 0.3), synth.uniform(seed + 5, (cout,), 0.5, 1.5)
+        g[0] = -g[0]
+        scale, shift = oracle.bn_fold(g, be, mu, var)
+        bnp = (_t(g), _t(be), _t(mu), _t(var), 1e-5)
+    exp = oracle.conv_block(x, w, b, scale, shift, relu=relu, pool=False)
+    layer = pkg.native.ConvLayer(_t(w), _t(b), bnp, relu=relu, pool=False)
+    got = layer(_t(x))
+    name = pkg.native.lib().einx_conv_last_kernel().decode()
+    assert name == f"conv16_1x1_kernel<{npw}>", name
+    assert np.array_equal(_np(got), exp)
+    # the large-grid kernel on the same images repeated: every copy equals the small-grid result
+    reps = -(-600 * 128 // (H * W * ((cout + 63) // 64)))  # enough copies for >= 512 128-pixel workgroups
+    if reps * B * cin * H * W <= 64 << 20:
+        big = layer(_t(np.concatenate([x] * reps, 0)))
+        assert pkg.native.lib().einx_conv_last_kernel().decode().startswith("conv_block_kernel<1,")
+        assert torch.equal(big[:B], got) and torch.equal(big[-B:], got)
+
+
 # ------------------------------------------------------------------ detector post-processing
 POST = Golden("post")
 
