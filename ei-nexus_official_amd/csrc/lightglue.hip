@@ -552,13 +552,19 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* hbuf, const int3
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
   float* row = hbuf + ((size_t)b * cap + i) * 512;
-  float v[8];
-  float s = 0.0f;
+  float v[8], gv[8], bv[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = row[lane + 64 * t];
+  // gamma / beta are requested with the row: read next to the stores below they are one L2 round trip per element
+  // (the compiler cannot move a load above a store through plain float pointers)
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    v[t] = row[lane + 64 * t];
-    s += v[t];
+    gv[t] = g[lane + 64 * t];
+    bv[t] = be[lane + 64 * t];
   }
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s += v[t];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   const float mean = s / 512.0f;
@@ -569,10 +575,7 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* hbuf, const int3
   for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
   const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int c = lane + 64 * t;
-    row[c] = einx_geluf(fmaf((v[t] - mean) * rstd, g[c], be[c]));
-  }
+  for (int t = 0; t < 8; ++t) row[lane + 64 * t] = einx_geluf(fmaf((v[t] - mean) * rstd, gv[t], bv[t]));
 }
 
 // matchability logit z = x . w + b per token, plus logsigmoid(z) and logsigmoid(-z)
