@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 cfgsweep
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -846,6 +846,38 @@ def gen_r2():
 
 
 GROUPS["r2"] = gen_r2
+
+
+# =========================================================================================
+# cfgsweep: every model YAML the reference ships (configs/model/**), built by the reference's own classes on the CPU:
+# which class the scripts use for it (EIM when it has an event_extractor section, else ImageImageMatcher), the module tree
+# as state_dict names -> shapes, and the attributes the evaluation scripts read.  The YAML text is not stored; the test
+# parses the files where they lie (this container only).
+# =========================================================================================
+def gen_cfgsweep():
+    import glob
+    from core.modules.ImageImageMatcher import ImageImageMatcher
+    cases = []
+    for path in sorted(glob.glob(os.path.join(REF, "configs/model/*.yaml")) + glob.glob(os.path.join(REF, "configs/model/test/*.yaml"))):
+        with open(path) as f:
+            cfg = yaml.safe_load(f)
+        cls = EIM if "event_extractor" in cfg else ImageImageMatcher
+        for st in ("pretrain_stage1", "pretrain_stage2"):  # checkpoint files are not available: build with fresh weights
+            cfg[st]["model_path"] = None
+        model = cls(_ref_stubs.to_attr(cfg), device="cpu")
+        keys = {k: list(v.shape) for k, v in sorted(model.state_dict().items())}
+        inner = model.matcher.matcher
+        case = {"file": os.path.relpath(path, REF), "name": cfg.get("name"), "cls": cls.__name__, "state_keys": keys,
+                "matcher_cls": type(inner).__name__ if inner is not None else None,
+                "image_ordering": model.image_extractor.extractor.ordering,
+                "event_ordering": model.event_extractor.extractor.ordering if cls is EIM else None,
+                "trainable": sorted(k for k, p_ in model.named_parameters() if p_.requires_grad)}
+        cases.append(case)
+        print(case["file"], case["cls"], len(keys), "tensors,", len(case["trainable"]), "trainable,", case["matcher_cls"])
+    save("cfgsweep.npz", meta=meta(group="cfgsweep"), cases=np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8))
+
+
+GROUPS["cfgsweep"] = gen_cfgsweep
 
 
 if __name__ == "__main__":
