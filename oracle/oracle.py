@@ -312,6 +312,8 @@ def extractor_forward(kind, sd, x, mask, *, top_k, radius=4, border=4, det_thr=1
     detector runs on the (H-18)x(W-18) maps and the keypoints are shifted by +9 (mapping_positions)."""
     B, _, H, W = x.shape
     cell = 8 if kind in ("vgg", "superpointv1") else 1
+    if kind == "silk":
+        mask = None  # SiLKModel.forward(self, image, *args, **kwargs) never looks at the mask it is handed (silk_extractor.py:177)
     if kind == "superpointv1":
         np.divide(x, np.float32(255.0), out=x)
     elif kind == "silk":

@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 cfgsweep
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii cfgsweep
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -846,6 +846,68 @@ def gen_r2():
 
 
 GROUPS["r2"] = gen_r2
+
+
+# =========================================================================================
+# ii: ImageImageMatcher (core/modules/ImageImageMatcher.py:75-82): the image extractor on both images, a score mask on the
+# first one only (superpoint_extractor.py:411-412: no dilation on the image side), then the matcher.
+# =========================================================================================
+II_CASES = [
+    dict(name="ii_sp_mnn", image_type="superpointv1", matcher="MNN", H=120, W=152, B=2, k=300, wseed=31, iseed=77, mseed=78),
+    dict(name="ii_silk_mnn", image_type="silk", matcher="MNN", H=60, W=76, B=2, k=200, wseed=32, iseed=79, mseed=80),
+]
+
+
+def ii_inputs(c):
+    img0 = synth.synth_image(c["iseed"], c["B"], c["H"], c["W"])
+    img1 = synth.synth_image(c["iseed"] + 1000, c["B"], c["H"], c["W"])
+    mask0 = synth.uniform01(c["mseed"], (c["B"], 1, c["H"], c["W"])) < np.float32(0.7)
+    return img0, img1, mask0
+
+
+def gen_ii():
+    from core.modules.ImageImageMatcher import ImageImageMatcher
+    out, cases = {}, []
+    for c in II_CASES:
+        with open(os.path.join(REF, "configs/model/SuperpointMatcher.yaml")) as f:
+            cfg = yaml.safe_load(f)
+        with open(os.path.join(REF, "configs/model/SiLKMatcher.yaml")) as f:
+            cfg["image_extractor"]["silk"] = yaml.safe_load(f)["image_extractor"]["silk"]
+        cfg["image_extractor"]["type"] = c["image_type"]
+        cfg["image_extractor"]["freeze"] = True
+        cfg["image_extractor"][c["image_type"]]["detection_top_k"] = c["k"]
+        cfg["matcher"]["type"] = c["matcher"]
+        cfg["matcher"]["freeze"] = True
+        for st in ("pretrain_stage1", "pretrain_stage2"):
+            cfg[st]["model_path"] = None
+        model = ImageImageMatcher(_ref_stubs.to_attr(cfg), device="cpu")
+        keys = load_synth_weights(model, c["wseed"])
+        model.eval()
+        img0, img1, mask0 = ii_inputs(c)
+        # descriptor-bias calibration as in `calibrate` (image extractor only, statistics of the first image batch)
+        sd = model.state_dict()
+        with torch.no_grad():
+            f = model.image_extractor(torch.from_numpy(img0.copy()), None)
+        key = [k for k in sd if k.endswith("convDb.bias") or k.endswith("_desH2.1.bias") or "descriptor_head" in k and k.endswith("1.bias")]
+        key = [k for k in key if sd[k].shape[0] == f["raw_descriptors"].shape[1]][-1:]
+        assert len(key) == 1, key
+        ov = (sd[key[0]] - f["raw_descriptors"].mean(dim=(0, 2, 3))).numpy()
+        model.load_state_dict({key[0]: torch.from_numpy(ov)}, strict=False)
+        out[f"{c['name']}.override.{key[0]}"] = ov
+        with torch.no_grad():
+            f0, f1, m = model(torch.from_numpy(img0.copy()), torch.from_numpy(img1.copy()), mask=torch.from_numpy(mask0))
+        feats_summary(f"{c['name']}.f0", f0, out)
+        feats_summary(f"{c['name']}.f1", f1, out)
+        match_summary(f"{c['name']}.m", m, out)
+        c = dict(c)
+        c["cfg"], c["state_keys"], c["override_key"] = cfg, keys, key[0]
+        cases.append(c)
+        print(c["name"], out[f"{c['name']}.f0.counts"], out[f"{c['name']}.f1.counts"], out[f"{c['name']}.m.matched_kpts0.lens"])
+    out["meta"] = meta(cases=cases)
+    save("ii.npz", **out)
+
+
+GROUPS["ii"] = gen_ii
 
 
 # =========================================================================================
