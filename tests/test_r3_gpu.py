@@ -129,3 +129,36 @@ def test_div_inplace_sizes(n):
     ref = (x.cpu().numpy() / np.float32(255.0)).astype(np.float32)
     N.div_inplace(x, 255.0)
     assert np.array_equal(x.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ EIM.forward's optional masks (EIM.py:44: events_mask=None, image_mask=None)
+def test_eim_forward_without_masks_and_with_an_image_mask_vs_oracle(oracle):
+    from helpers import sub_dict
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 150
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=17)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    H, W, B = 84, 108, 2
+    ev, emask = synth.synth_events(91, B, 5, H, W)
+    img = synth.synth_image(91, B, H, W)
+    imask = synth.uniform01(92, (B, 1, H, W)) < np.float32(0.6)
+    esub, isub = sub_dict(sd, "event_extractor.extractor."), sub_dict(sd, "image_extractor.extractor.")
+    for em, im in ((None, None), (emask, imask), (None, imask)):
+        ef, imf, m = model(_t(ev), _t(img), None if em is None else _t(em), None if im is None else _t(im))
+        oe = oracle.extractor_forward("vgg", esub, ev.copy(), em, top_k=150)
+        oi = oracle.extractor_forward("superpointv1", isub, img.copy(), im, top_k=150)
+        for got, exp in ((ef, oe), (imf, oi)):
+            assert np.array_equal(got["score"].cpu().numpy(), exp["score"])
+            assert np.array_equal(got["nms"].cpu().numpy(), exp["nms"])
+            for b in range(B):
+                assert np.array_equal(got["sparse_positions"][b].cpu().numpy(), exp["sparse_positions"][b])
+                assert np.array_equal(got["sparse_descriptors"][b].cpu().numpy(), exp["sparse_descriptors"][b])
+        for b in range(B):
+            r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
+            assert np.array_equal(m["matches0"][b].cpu().numpy()[0], r["matches0"])
+        if im is not None:  # the image-side mask zeroes scores exactly where it is False (no dilation on the image side)
+            assert float(imf["score"][~_t(im)].abs().max()) == 0.0
