@@ -601,6 +601,7 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
 #endif
     const float* rp = rows + cl * 2 * pw;
     bool odd = big;  // some element outside the fast division's range
+    float vmin = 0x1p20f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const float t0 = hx[it] * rp[x0[it]] + lx[it] * rp[x0[it] + 1];
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
 #elif EINX_UPS_EXP == 3  // timing experiment: no range check
         q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
 #else
-        odd |= !(fabsf(v) >= 0x1p-80f);  // also true for NaN; the upper end is checked once per sweep on the norms (|v| <= den < 2^20)
+        vmin = fminf(vmin, fabsf(v));  // lower end of the fast division's range, tested once per channel; the upper end once per sweep on the norms (|v| <= den < 2^20; a NaN element has a NaN norm)
         q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
 #endif
       }
@@ -625,6 +626,9 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
         for (int r = 0; r < UP_ROWS; ++r) buf[r * g.W + it * 64 + lane] = q[r];  // rows past nrow land in the slab's slack
       }
     }
+#if !defined(EINX_UPS_EXP) || EINX_UPS_EXP == 0
+    odd |= !(vmin >= 0x1p-80f);
+#endif
     if (__builtin_expect(__any(odd), 0)) {  // the same values with IEEE divisions
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {  // unrolled: a rolled loop would index the per-sweep register arrays dynamically (scratch)
