@@ -726,7 +726,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
   // whole 16-byte groups only (every shipped geometry): SEL_UB loads per lane are requested together from clamped
   // addresses and zeroed when they lie past the slice -- a loop of one guarded load per iteration is neither unrolled nor
   // pipelined by hipcc and costs a memory round trip per 256 values (23 in a row on a 264x352 map)
-  constexpr int SEL_UB = 8;
+  constexpr int SEL_UB = 12;
   const bool fast = vec && (N & 3) == 0 && N >= 4;
   auto load_batch = [&](int i0, f32x4* q) {
 #pragma unroll
@@ -779,25 +779,28 @@ __global__ __launch_bounds__(SEL_THREADS) void select_compact_kernel(const SelAr
   const int nz = scratch[16];
   if (!sh_bad && nz <= SEL_LCAP) {
     int pos_w = scratch[wave];
-    auto place = [&](int i, const float* v) {  // 256 values of the slice in raster order: lane-local counts, wave scan, scatter
-      int c = 0;
+    // 256 values of the slice in raster order (lane-major, then the lane's four elements).  Rank of a non-zero = non-zeros
+    // of lower lanes + of the lane's earlier elements: four ballots and masked population counts (v_mbcnt), no dependent
+    // chain of cross-lane shuffles (the 6-step wave scan this replaces was most of the kernel's longest phase)
+    auto place = [&](int i, const float* v) {
+      int before = 0, total = 0;
+      bool nzt[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) c += (v[t] != 0.0f) ? 1 : 0;
-      int incl = c;  // wave-inclusive scan of the per-lane counts
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+      for (int t = 0; t < 4; ++t) {
+        nzt[t] = v[t] != 0.0f;
+        const unsigned long long m = __ballot(nzt[t]);
+        before += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        total += __popcll(m);
       }
-      int pos = pos_w + incl - c;
+      int pos = pos_w + before;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (v[t] != 0.0f) {
+        if (nzt[t]) {
           cval[pos] = v[t];
           cidx[pos] = i + t;
           ++pos;
         }
-      pos_w += __shfl(incl, 63, 64);
+      pos_w += total;
     };
     if (fast) {
       for (int i0 = w0; i0 < w1; i0 += 256 * SEL_UB) {
