@@ -388,6 +388,7 @@ struct AttnArgs {
   const int32_t* nk;
   int capq, capk;
   float scale;
+  int kv_shift, Btot;  // keys / values of batch entry b come from entry (b + kv_shift) % Btot (cross attention over the two sides stacked in one buffer)
 };
 
 #ifndef EINX_AKB
@@ -406,7 +407,8 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   const int qb = item % gx;
   item /= gx;
   const int h = item % gy, b = item / gy;
-  const int nq = min(a.nq[b], a.capq), nk = min(a.nk[b], a.capk);
+  const int bk = a.kv_shift ? (b + a.kv_shift) % a.Btot : b;
+  const int nq = min(a.nq[b], a.capq), nk = min(a.nk[bk], a.capk);
   const int q0 = qb * 128;
   if (q0 >= nq || nk <= 0) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -424,8 +426,8 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
     qreg[t + 2] = v[2];
     qreg[t + 3] = v[3];
   }
-  const float* Kb = a.K + (size_t)b * a.capk * D + h * DH;
-  const float* Vb = a.V + (size_t)b * a.capk * D + h * DH;
+  const float* Kb = a.K + (size_t)bk * a.capk * D + h * DH;
+  const float* Vb = a.V + (size_t)bk * a.capk * D + h * DH;
   f32x16 o[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -689,6 +691,34 @@ char* carve_side(Side& s, char* p, int B, int cap) {
   return p;
 }
 
+// Both sides stacked: every buffer is [2B, cap, width], side 0 = entries 0..B-1, side 1 = entries B..2B-1.  LightGlue applies
+// the same weights to both sides, so every per-side launch becomes one launch over 2B entries (cross attention reads
+// the partner entry's keys / values); s0 / s1 stay views of the halves.  Never larger than two separate sides.
+char* carve_stacked(Side& s0, Side& s1, char* p, int B, int cap) {
+  const size_t tok = (size_t)B * cap;
+  auto take = [&](size_t width, float*& a0, float*& a1) {
+    a0 = (float*)p;
+    a1 = a0 + tok * width;
+    p += al(2 * tok * width * 4);
+  };
+  take(D, s0.x, s1.x);
+  take(128, s0.enc, s1.enc);
+  take(D, s0.q, s1.q);
+  take(D, s0.k, s1.k);
+  take(D, s0.v, s1.v);
+  take(D, s0.ctx, s1.ctx);
+  take(D, s0.msg, s1.msg);
+  take(512, s0.h, s1.h);
+  take(1, s0.cert, s1.cert);
+  take(1, s0.dust, s1.dust);
+  return p;
+}
+
+__global__ void lg_stack_counts_kernel(const int32_t* n, const int32_t* m, int B, int32_t* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 2 * B) out[t] = t < B ? n[t] : m[t - B];
+}
+
 // persistent launch size: resident workgroups of the tile kernels on this device (a multiple of
 // 8 so that every XCD gets the same number of slots), never more than the tiles there are
 unsigned gemm_grid(int tiles) {
@@ -762,8 +792,10 @@ int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const float* X, const fl
 }
 
 int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, const float* K, const float* V, const int32_t* nk, int capk,
-         float* O) {
+         float* O, int kv_shift = 0) {
   AttnArgs a;
+  a.kv_shift = kv_shift;
+  a.Btot = B;
   a.Q = Q;
   a.K = K;
   a.V = V;
@@ -860,7 +892,7 @@ EINX_EXPORT int einx_normalize_keypoints(const float* kpts, int rows, int cols, 
 EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) {
   if (B <= 0 || cap0 <= 0 || cap1 <= 0 || d != D) return 0;
   (void)input_dim;
-  return side_bytes(B, cap0) + side_bytes(B, cap1) + einx_mnn_ws_bytes(B, cap0, cap1) + 1024;
+  return side_bytes(B, cap0) + side_bytes(B, cap1) + einx_mnn_ws_bytes(B, cap0, cap1) + al((size_t)2 * B * 4) + 1024;
 }
 
 EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0,
@@ -886,10 +918,26 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   s1.cnt = m;
   s1.cap = cap1;
   char* p = (char*)ws;
-  p = carve_side(s0, p, B, cap0);
-  p = carve_side(s1, p, B, cap1);
+  // equal capacities (every shipped configuration): the two sides are stacked and every layer runs ONCE over 2B entries --
+  // half the launches, and at small batch twice the workgroups per launch (a single pair: 8.0 -> see profiles/r03_notes.md)
+  static const bool no_stack = getenv("EINX_LG_NO_STACK") != nullptr;
+  const bool stacked = cap0 == cap1 && !no_stack;
+  Side sb{};
+  if (stacked) {
+    p = carve_stacked(s0, s1, p, B, cap0);
+    int32_t* cnt2 = (int32_t*)p;
+    p += al((size_t)2 * B * 4);
+    hipLaunchKernelGGL(lg_stack_counts_kernel, dim3((unsigned)einx_cdiv(2 * B, 256)), dim3(256), 0, st, n, m, B, cnt2);
+    sb = s0;
+    sb.cnt = cnt2;
+  } else {
+    p = carve_side(s0, p, B, cap0);
+    p = carve_side(s1, p, B, cap1);
+  }
   void* mnn_ws = p;
   Side* sides[2] = {&s0, &s1};
+  Side* run[2] = {stacked ? &sb : &s0, &s1};  // what the shared-weight stages iterate over
+  const int nrun = stacked ? 1 : 2, Br = stacked ? 2 * B : B;
   const float sz[2][2] = {{h0, w0}, {h1, w1}};
 #define LG_CHECK(expr)                                                    \
   do {                                                                    \
@@ -898,7 +946,8 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
       return EINX_ERR_LAUNCH;                                             \
     }                                                                     \
   } while (0)
-  // ---- input projection (or copy) + positional encodings -----------------------------------
+  LG_CHECK(0);
+  // ---- input projection (or copy) + positional encodings (per side: own inputs, own image size) --------
   for (int sd = 0; sd < 2; ++sd) {
     Side& s = *sides[sd];
     if (w->in_w) {
@@ -915,32 +964,39 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   // ---- transformer layers --------------------------------------------------------------------
   for (int li = 0; li < w->n_layers; ++li) {
     const einx_lg_layer& L = w->layers[li];
-    for (int sd = 0; sd < 2; ++sd) {
-      Side& s = *sides[sd];
-      LG_CHECK(gemm_qkv_rope(st, s, B, s.x, L.Wqkv, L.bqkv, s.q, s.k, s.v));
-      LG_CHECK(attn(st, B, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
+    for (int sd = 0; sd < nrun; ++sd) {
+      Side& s = *run[sd];
+      LG_CHECK(gemm_qkv_rope(st, s, Br, s.x, L.Wqkv, L.bqkv, s.q, s.k, s.v));
+      LG_CHECK(attn(st, Br, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
       if (L.Wo) {
-        LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
-        LG_CHECK(ffn(st, s, B, s.msg, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+        LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
+        LG_CHECK(ffn(st, s, Br, s.msg, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
       } else {  // out_proj folded into the FFN's first Linear at load time: message = context
-        LG_CHECK(ffn(st, s, B, s.ctx, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+        LG_CHECK(ffn(st, s, Br, s.ctx, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
       }
     }
-    for (int sd = 0; sd < 2; ++sd) {
-      Side& s = *sides[sd];
-      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqk, L.bqk, D, s.q, D));
-      LG_CHECK(gemm(st, EPI_BIAS, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wv, L.bv, D, s.v, D));
+    for (int sd = 0; sd < nrun; ++sd) {
+      Side& s = *run[sd];
+      LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqk, L.bqk, D, s.q, D));
+      LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wv, L.bv, D, s.v, D));
     }
-    LG_CHECK(attn(st, B, s0.q, s0.cnt, s0.cap, s1.q, s1.v, s1.cnt, s1.cap, s0.ctx));
-    LG_CHECK(attn(st, B, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));
-    for (int sd = 0; sd < 2; ++sd) {
-      Side& s = *sides[sd];
+    if (stacked) {  // entry b attends to the keys / values of its partner entry (b + B) mod 2B
+      LG_CHECK(attn(st, Br, sb.q, sb.cnt, sb.cap, sb.q, sb.v, sb.cnt, sb.cap, sb.ctx, B));
+    } else {
+      LG_CHECK(attn(st, B, s0.q, s0.cnt, s0.cap, s1.q, s1.v, s1.cnt, s1.cap, s0.ctx));
+      LG_CHECK(attn(st, B, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));
+    }
+    for (int sd = 0; sd < nrun; ++sd) {
+      Side& s = *run[sd];
       if (L.Wco) {
-        LG_CHECK(gemm(st, EPI_BIAS, s, B, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wco, L.bco, D, s.msg, D));
-        LG_CHECK(ffn(st, s, B, s.msg, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+        LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wco, L.bco, D, s.msg, D));
+        LG_CHECK(ffn(st, s, Br, s.msg, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
       } else {
-        LG_CHECK(ffn(st, s, B, s.ctx, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+        LG_CHECK(ffn(st, s, Br, s.ctx, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
       }
+    }
+    for (int sd = 0; sd < 2; ++sd) {
+      Side& s = *sides[sd];
       float* ref = sd == 0 ? ref0 : ref1;
       if (ref && all_layers) {  // training-mode output: every layer's descriptors (lightglue.py:626-629)
         const size_t per = (size_t)s.cap * D;
@@ -951,12 +1007,15 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
     }
   }
   // ---- assignment ------------------------------------------------------------------------------
-  for (int sd = 0; sd < 2; ++sd) {
-    Side& s = *sides[sd];
-    LG_CHECK(gemm(st, EPI_DIV, s, B, s.x, D, nullptr, 0, 0x7fffffff, D, w->proj_w, w->proj_b, D, s.q, D, sqrtf(sqrtf((float)D))));
-    hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.x, s.cnt, s.cap, w->match_w,
+  for (int sd = 0; sd < nrun; ++sd) {
+    Side& s = *run[sd];
+    LG_CHECK(gemm(st, EPI_DIV, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, w->proj_w, w->proj_b, D, s.q, D, sqrtf(sqrtf((float)D))));
+    hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)Br), dim3(256), 0, st, s.x, s.cnt, s.cap, w->match_w,
                        w->match_b, s.cert, s.dust);
     LG_CHECK(0);
+  }
+  for (int sd = 0; sd < 2; ++sd) {
+    Side& s = *sides[sd];
     float* ref = sd == 0 ? ref0 : ref1;
     if (ref && !all_layers) {
       const size_t per = (size_t)s.cap * D;

@@ -162,3 +162,49 @@ def test_eim_forward_without_masks_and_with_an_image_mask_vs_oracle(oracle):
             assert np.array_equal(m["matches0"][b].cpu().numpy()[0], r["matches0"])
         if im is not None:  # the image-side mask zeroes scores exactly where it is False (no dilation on the image side)
             assert float(imf["score"][~_t(im)].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ LightGlue: both sides stacked in one launch == one launch per side
+@pytest.mark.parametrize("B,n,m", [(1, 1024, 1024), (3, 300, 300), (2, 517, 480)])
+def test_lightglue_stacked_sides_equal_the_per_side_path(B, n, m):
+    """Equal capacities run every layer once over 2B entries (cross attention reads the partner entry); a side-1 batch
+    padded by one unused row has another capacity and takes the launch-per-side path: every output must be bit-identical."""
+    from importlib import import_module
+    N = pkg.native
+    PairBatch = import_module(pkg.__name__ + ".core.modules.matchers._batched").PairBatch
+    LG = import_module(pkg.__name__ + ".core.modules.matchers.lightglue").LightGlue
+    lg = LG({"input_dim": 256}).to(DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=77)
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    cap = max(n, m)
+    rng = np.random.default_rng(B * 1000 + n)
+
+    def side(cnt, cap_):
+        pb = PairBatch()
+        k = np.zeros((B, cap_, 3), np.float32)
+        d = np.zeros((B, cap_, 256), np.float32)
+        k[:, :cnt, 0] = rng.uniform(0, 260, (B, cnt))
+        k[:, :cnt, 1] = rng.uniform(0, 346, (B, cnt))
+        v = rng.standard_normal((B, cnt, 256)).astype(np.float32)
+        d[:, :cnt] = v / np.linalg.norm(v, axis=-1, keepdims=True)
+        pb.kpts, pb.desc = _t(k), _t(d)
+        pb.counts = torch.tensor([cnt] * (B - 1) + [max(cnt - 7, 1)], dtype=torch.int32, device=DEV)  # one ragged entry
+        pb.cap, pb.B, pb.image_size, pb.counts_host = cap_, B, (260, 346), None
+        return pb
+
+    pb0, pb1 = side(n, cap), side(m, cap)
+    w = lg._pack()[0]
+    a = N.lightglue(w, pb0, pb1, want_la=True, want_ref=True)
+    pb1p = PairBatch()
+    pb1p.kpts = torch.cat([pb1.kpts, torch.zeros(B, 1, 3, device=DEV)], 1).contiguous()
+    pb1p.desc = torch.cat([pb1.desc, torch.zeros(B, 1, 256, device=DEV)], 1).contiguous()
+    pb1p.counts, pb1p.cap, pb1p.B, pb1p.image_size, pb1p.counts_host = pb1.counts, cap + 1, B, (260, 346), None
+    b = N.lightglue(w, pb0, pb1p, want_la=True, want_ref=True)
+    cnt0, cnt1 = pb0.counts.tolist(), pb1.counts.tolist()
+    for i in range(B):  # rows past an entry's count are never written
+        c0, c1 = cnt0[i], cnt1[i]
+        assert torch.equal(a.matches0[i, :c0], b.matches0[i, :c0]) and torch.equal(a.scores0[i, :c0], b.scores0[i, :c0])
+        assert torch.equal(a.matches1[i, :c1], b.matches1[i, :c1]) and torch.equal(a.scores1[i, :c1], b.scores1[i, :c1])
+        assert torch.equal(a.ref0[i, :c0], b.ref0[i, :c0]) and torch.equal(a.ref1[i, :c1], b.ref1[i, :c1])
+        assert torch.equal(a.la[i, :c0, :c1], b.la[i, :c0, :c1])
+    assert int((a.matches0 > -1).sum()) > 0

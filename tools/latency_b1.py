@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-pair latency of EIM.forward (the reference's own call pattern, test_events-image_same-time.py:130-194):
 wall time per forward, host enqueue time (forward_batched returns before the device is done) and device time.
-    python tools/latency_b1.py [B]          (EINX_OP_LEVEL=1: layer-by-layer op-level ABI instead of einx_extract)"""
+    python tools/latency_b1.py [B [SP_MNN|SP_LG|SiLK_MNN|SiLK_LG]]          (EINX_OP_LEVEL=1: layer-by-layer op-level ABI instead of einx_extract)"""
 import importlib
 import os
 import sys
@@ -17,14 +17,16 @@ synth = pkg.synth
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    name = sys.argv[2] if len(sys.argv) > 2 else "SP_MNN"  # SP_MNN | SP_LG | SiLK_MNN | SiLK_LG
     dev = "cuda:0"
-    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    cfg = pkg.default_config(name, event_channels=5)
     model = pkg.EIM(cfg, device=dev).eval()
     sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=11)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
         ext.dense_outputs = False
-    model.matcher.matcher.want_log_assignment = False
+    if name.endswith("MNN"):
+        model.matcher.matcher.want_log_assignment = False
     ev, mask = synth.synth_events(10_000, B, 5)
     img0 = torch.from_numpy(synth.synth_image(10_000, B)).to(dev)
     ev, mask = torch.from_numpy(ev).to(dev), torch.from_numpy(mask).to(dev)
@@ -57,7 +59,7 @@ def main():
     torch.cuda.synchronize()
     dev_ms = e0.elapsed_time(e1) / n
     mode = "op-level ABI" if os.environ.get("EINX_OP_LEVEL") == "1" else "einx_extract (handle-level ABI)"
-    print(f"B={B} {mode}: forward wall {t_wall / n * 1e3:.3f} ms, host enqueue {t_enq / n * 1e3:.3f} ms, "
+    print(f"B={B} {name} {mode}: forward wall {t_wall / n * 1e3:.3f} ms, host enqueue {t_enq / n * 1e3:.3f} ms, "
           f"back-to-back device+enqueue {dev_ms:.3f} ms per forward, overlap={model.overlap_extractors}")
 
 
