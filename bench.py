@@ -784,6 +784,8 @@ def run_rank(args):
             torch.cuda.empty_cache()
             w = leg("sp_mnn", 1, steps=50, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
             del w
+            w = leg("sp_lg", 1, steps=30, note="single-pair latency with the LightGlue matcher (configs/model/test/EI_SP_LG.yaml evaluated pair by pair): ms_per_step is ms per pair")
+            del w
             sec, mm = timed_stream(wl, 20)
             extras.append({"config": "sp_mnn", "workload": f"B{B} " + WORKLOADS["sp_mnn"][2], "pairs_per_step": B,
                            "calibrated_descriptors": bool(wl.calibrated), "value": round(B / sec, 2), "unit": "pairs/s",
