@@ -742,9 +742,9 @@ def run_rank(args):
 
     # ---- short extra legs: the other BASELINE configs, B=1 latency, the round-1 (un-calibrated) weights ----
     if do_extras:
-        def leg(config, batch, calibrate=True, steps=3, note=None):
+        def leg(config, batch, calibrate=True, steps=3, note=None, init=2):
             w = wl if (config == args.config and batch == B and calibrate == wl.calibrated) else Workload(pkg, dev, config, batch, calibrate=calibrate)
-            sec, mm = w.timed(steps)
+            sec, mm = w.timed(steps, init=init)
             e = {"config": config, "workload": f"B{batch} " + WORKLOADS[config][2], "pairs_per_step": batch, "calibrated_descriptors": bool(w.calibrated),
                  "value": round(batch / sec, 2), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": steps, "mean_matches": round(mm, 1)}
             if note:
@@ -765,10 +765,10 @@ def run_rank(args):
             stages = stage_rooflines(wl, lg_wl)
             del lg_wl
             torch.cuda.empty_cache()
-            w = leg("silk_mnn", 32, steps=10, note="BASELINE configs[2]")
+            w = leg("silk_mnn", 32, steps=10, note="BASELINE configs[2]", init=5)  # GB-sized activations: the allocator needs a few steps after empty_cache
             del w
             torch.cuda.empty_cache()
-            w = leg("silk_lg", 32, steps=5, note="configs/model/test/EI_SiLK_LG.yaml (SiLK family + LightGlue, 128-d descriptors through input_proj)")
+            w = leg("silk_lg", 32, steps=5, init=4, note="configs/model/test/EI_SiLK_LG.yaml (SiLK family + LightGlue, 128-d descriptors through input_proj)")
             del w
             torch.cuda.empty_cache()
             # the dict an unmodified reference caller gets: dense descriptor maps + dense positions + log_assignment
