@@ -253,6 +253,133 @@ __global__ __launch_bounds__(THREADS, EINX_GEMM_WG_PER_CU * THREADS / 256) void 
 }
 
 // ------------------------------------------------------------------------------------------
+// The same linears for SMALL grids (single pairs: fewer 128x128 tiles than CUs).  A launch that cannot fill the chip is
+// bound by the latency of ONE tile's K loop (8 waves x 32 MFMAs + staging per 32-deep slab, 10-20 us per tile however few
+// tiles there are): 64x64 tiles on 4 waves of one 32x32 accumulator each halve the matrix work per slab and give 4x the
+// workgroups.  Same K order per output (one k-ordered chain from +0), so results are bit-identical to lg_gemm_kernel;
+// same four epilogues.  K % 32 == 0 and N % 64 == 0 (every LightGlue shape); one tile per workgroup, no persistence.
+// ------------------------------------------------------------------------------------------
+constexpr int SBM = 64, SBN = 64, SBK = 32, SP = SBK + 1;
+template <int EPI>
+__global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
+  __shared__ float As[SBM * SP];
+  __shared__ float Bs[SBN * SP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.z;
+  const int n = g.cnt ? min(g.cnt[b], g.cap) : g.cap;
+  const int i0 = (int)blockIdx.y * SBM;
+  if (i0 >= n) return;
+  const int tj = (int)blockIdx.x;
+  int j0, t = 0;
+  const float* Wb;
+  int ldb;
+  if (EPI == EPI_ROPE) {  // four 64-column tiles per (q | k | v) block; W rows (hc + r) * 3 + t (see lg_gemm_kernel)
+    t = tj >> 2;
+    j0 = (tj & 3) * SBN;
+    Wb = g.W + (size_t)t * g.K;
+    ldb = 3 * g.K;
+  } else {
+    j0 = tj * SBN;
+    Wb = g.W;
+    ldb = g.K;
+  }
+  const float* A1 = g.X + (size_t)b * g.cap * g.ldx;
+  const float* A2 = g.X2 ? g.X2 + (size_t)b * g.cap * g.ldx2 : nullptr;
+  // staging: 64 rows x 8 float4 per operand and slab = 2 float4 per thread; rows past n read row n - 1 (never stored)
+  int ra[2], c4a[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * 256;
+    ra[i] = f >> 3;
+    c4a[i] = f & 7;
+  }
+  f32x4 va[2], vb[2];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = min(i0 + ra[i], n - 1);
+      const int k = k0 + c4a[i] * 4;
+      va[i] = (k < g.Ksplit) ? *reinterpret_cast<const f32x4*>(A1 + (size_t)row * g.ldx + k)
+                             : *reinterpret_cast<const f32x4*>(A2 + (size_t)row * g.ldx2 + (k - g.Ksplit));
+      vb[i] = *reinterpret_cast<const f32x4*>(Wb + (size_t)(j0 + ra[i]) * ldb + k);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  issue(0);
+  const int aoff = (wm * 32 + l31) * SP + half, boff = (wn * 32 + l31) * SP + half;
+  for (int k0 = 0; k0 < g.K; k0 += SBK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        As[ra[i] * SP + c4a[i] * 4 + e] = va[i][e];
+        Bs[ra[i] * SP + c4a[i] * 4 + e] = vb[i][e];
+      }
+    __syncthreads();
+    if (k0 + SBK < g.K) issue(k0 + SBK);
+    float av[2], bv[2];
+    av[0] = As[aoff];
+    bv[0] = Bs[boff];
+#pragma unroll
+    for (int kk = 0; kk < SBK / 2; ++kk) {
+      if (kk + 1 < SBK / 2) {
+        av[(kk + 1) & 1] = As[aoff + (kk + 1) * 2];
+        bv[(kk + 1) & 1] = Bs[boff + (kk + 1) * 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1], bv[kk & 1], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue: C row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32x32 tile, column l31
+  const int col = j0 + wn * 32 + l31;  // < N (N % 64 == 0); for EPI_ROPE the column inside the 256-wide q / k / v block
+  int rows[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rows[r] = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+  if (EPI == EPI_ROPE) {
+    float* Yt = (t == 0 ? g.Yq : t == 1 ? g.Yk : g.Yv) + (size_t)b * g.cap * 256;
+    const float* encb = g.enc + (size_t)b * g.cap * 128;
+    const float bq = g.bias[col * 3 + t];
+    const bool odd = lane & 1;
+    float cs[16], sn[16];
+    if (t < 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* e = encb + (size_t)min(rows[r], n - 1) * 128;
+        cs[r] = e[col & 63];
+        sn[r] = e[64 + (col & 63)];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r] + bq;
+      const float partner = __shfl_xor(v, 1, 64);
+      if (t < 2) v = (v * cs[r]) + ((odd ? partner : -partner) * sn[r]);
+      if (rows[r] < n) Yt[(size_t)rows[r] * 256 + col] = v;
+    }
+    return;
+  }
+  float* Y = g.Y + (size_t)b * g.cap * g.ldy;
+  const float bj = g.bias[col];
+  float old[16];
+  if (EPI == EPI_RESID) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = Y[(size_t)min(rows[r], n - 1) * g.ldy + col];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[r] + bj;
+    if (EPI == EPI_DIV) v = v / g.div;
+    if (EPI == EPI_RESID) v = old[r] + v;
+    if (rows[r] < n) Y[(size_t)rows[r] * g.ldy + col] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // FFN first half in ONE launch (round 3): h = GELU(LayerNorm(cat(x, msg) @ W0^T + b0)), lightglue.py:247-249 / :297-299.
 // LayerNorm needs whole 512-wide rows, which span four 128-column tiles.  Here a workgroup owns a GROUP of 128 rows: it
 // runs the group's four tiles back to back (same tile engine, the next tile's first K-slab prefetched as before), writes
@@ -737,6 +864,13 @@ unsigned gemm_grid(int tiles) {
   return (unsigned)(want < resident ? want : resident);
 }
 
+// fewer 128x128 tiles than CUs (and shapes the small kernel takes): 64x64 tiles, one per workgroup
+bool small_grid(int N, int cap, int B, int K, int Ksplit) {
+  static const long max_tiles = getenv("EINX_LG_SMALL_MAX_TILES") ? atol(getenv("EINX_LG_SMALL_MAX_TILES")) : 256;
+  const long tiles = (long)einx_cdiv(N, BN) * einx_cdiv(cap, BM) * B;
+  return tiles < max_tiles && K % SBK == 0 && N % SBN == 0 && (Ksplit >= K || Ksplit % SBK == 0);
+}
+
 int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx, const float* X2, int ldx2, int Ksplit, int K, const float* W,
          const float* bias, int N, float* Y, int ldy, float div = 1.0f) {
   GemmArgs g;
@@ -755,6 +889,14 @@ int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx,
   g.ldy = ldy;
   g.div = div;
   g.B = B;
+  if (small_grid(N, s.cap, B, K, Ksplit)) {
+    const dim3 sg((unsigned)(N / SBN), (unsigned)einx_cdiv(s.cap, SBM), (unsigned)B);
+    EINX_PROF("lg_gemm_small_kernel", st);
+    if (epi == EPI_BIAS) hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_BIAS>, sg, dim3(256), 0, st, g);
+    else if (epi == EPI_DIV) hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_DIV>, sg, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_RESID>, sg, dim3(256), 0, st, g);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   const dim3 grid(gemm_grid(einx_cdiv(N, BN) * einx_cdiv(s.cap, BM) * B));
   EINX_PROF("lg_gemm_kernel", st);
   if (epi == EPI_BIAS) hipLaunchKernelGGL(lg_gemm_kernel<EPI_BIAS>, grid, dim3(THREADS), 0, st, g);
@@ -785,6 +927,11 @@ int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const float* X, const fl
   g.Yq = q;
   g.Yk = k;
   g.Yv = v;
+  if (small_grid(3 * D, s.cap, B, D, 0x7fffffff)) {
+    EINX_PROF("lg_gemm_small_kernel", st);
+    hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_ROPE>, dim3((unsigned)(3 * D / SBN), (unsigned)einx_cdiv(s.cap, SBM), (unsigned)B), dim3(256), 0, st, g);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   const dim3 grid(gemm_grid(einx_cdiv(3 * D, BN) * einx_cdiv(s.cap, BM) * B));
   EINX_PROF("lg_gemm_kernel", st);
   hipLaunchKernelGGL(lg_gemm_kernel<EPI_ROPE>, grid, dim3(THREADS), 0, st, g);

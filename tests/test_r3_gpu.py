@@ -208,3 +208,46 @@ def test_lightglue_stacked_sides_equal_the_per_side_path(B, n, m):
         assert torch.equal(a.ref0[i, :c0], b.ref0[i, :c0]) and torch.equal(a.ref1[i, :c1], b.ref1[i, :c1])
         assert torch.equal(a.la[i, :c0, :c1], b.la[i, :c0, :c1])
     assert int((a.matches0 > -1).sum()) > 0
+
+
+@pytest.mark.parametrize("n,m", [(1024, 1024), (700, 613)])
+def test_lightglue_small_grid_kernels_equal_the_large_grid_kernels(n, m):
+    """A single pair runs its linears on lg_gemm_small_kernel (64x64 tiles, fewer than 256 128x128 tiles), the same pair as
+    entry 0 of a batch of 8 on lg_gemm_kernel: every output of the pair must be bit-identical (one k-ordered chain per output
+    in both kernels)."""
+    from importlib import import_module
+    N = pkg.native
+    PairBatch = import_module(pkg.__name__ + ".core.modules.matchers._batched").PairBatch
+    LG = import_module(pkg.__name__ + ".core.modules.matchers.lightglue").LightGlue
+    lg = LG({"input_dim": 256}).to(DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=78)
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    w = lg._pack()[0]
+    cap = max(n, m)
+    rng = np.random.default_rng(n)
+    B = 8
+
+    def arrays(cnt):
+        k = np.zeros((B, cap, 3), np.float32)
+        d = np.zeros((B, cap, 256), np.float32)
+        k[:, :cnt, 0] = rng.uniform(0, 260, (B, cnt))
+        k[:, :cnt, 1] = rng.uniform(0, 346, (B, cnt))
+        v = rng.standard_normal((B, cnt, 256)).astype(np.float32)
+        d[:, :cnt] = v / np.linalg.norm(v, axis=-1, keepdims=True)
+        return k, d
+
+    def batch(k, d, cnt, nb):
+        pb = PairBatch()
+        pb.kpts, pb.desc = _t(k[:nb]), _t(d[:nb])
+        pb.counts = torch.full((nb,), cnt, dtype=torch.int32, device=DEV)
+        pb.cap, pb.B, pb.image_size, pb.counts_host = cap, nb, (260, 346), None
+        return pb
+
+    (k0, d0), (k1, d1) = arrays(n), arrays(m)
+    big = N.lightglue(w, batch(k0, d0, n, B), batch(k1, d1, m, B), want_la=True, want_ref=True)
+    one = N.lightglue(w, batch(k0, d0, n, 1), batch(k1, d1, m, 1), want_la=True, want_ref=True)
+    assert torch.equal(one.matches0[0, :n], big.matches0[0, :n]) and torch.equal(one.scores0[0, :n], big.scores0[0, :n])
+    assert torch.equal(one.matches1[0, :m], big.matches1[0, :m]) and torch.equal(one.scores1[0, :m], big.scores1[0, :m])
+    assert torch.equal(one.ref0[0, :n], big.ref0[0, :n]) and torch.equal(one.ref1[0, :m], big.ref1[0, :m])
+    assert torch.equal(one.la[0, :n, :m], big.la[0, :n, :m])
+    assert int((one.matches0[0, :n] > -1).sum()) > 0
