@@ -251,3 +251,42 @@ def test_lightglue_small_grid_kernels_equal_the_large_grid_kernels(n, m):
     assert torch.equal(one.ref0[0, :n], big.ref0[0, :n]) and torch.equal(one.ref1[0, :m], big.ref1[0, :m])
     assert torch.equal(one.la[0, :n, :m], big.la[0, :n, :m])
     assert int((one.matches0[0, :n] > -1).sum()) > 0
+
+
+# ------------------------------------------------------------------ whole forwards at odd geometries (small-grid kernels, forked heads, ragged tiles)
+@pytest.mark.parametrize("cfg_name,B,H,W,bins,k", [
+    ("SP_MNN", 1, 41, 67, 5, 64), ("SP_MNN", 2, 97, 53, 3, 200), ("SP_MNN", 3, 64, 136, 16, 128), ("SP_MNN", 1, 135, 181, 5, 500),
+    ("SiLK_MNN", 1, 37, 45, 5, 80), ("SiLK_MNN", 2, 58, 83, 2, 150),
+], ids=lambda v: str(v))
+def test_whole_forward_at_odd_geometries_vs_oracle(oracle, cfg_name, B, H, W, bins, k):
+    """Single pairs and tiny batches at sizes that are not multiples of the cell / tile sizes: every launch takes a small-grid
+    path (conv16_kernel, conv16_1x1_kernel, forked head branches) with ragged tiles; keypoints, descriptors and matches must
+    equal per-pair oracle runs bit for bit."""
+    from helpers import sub_dict
+    cfg = pkg.default_config(cfg_name, event_channels=bins)
+    et, it = cfg.event_extractor.type, cfg.image_extractor.type
+    cfg.event_extractor[et].detection_top_k = k
+    cfg.image_extractor[it].detection_top_k = k
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(kk, tuple(v.shape)) for kk, v in model.state_dict().items()], seed=H * 7 + W)
+    model.load_state_dict({kk: torch.from_numpy(v) for kk, v in sd.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    ev, mask = synth.synth_events(H + W, B, bins, H, W)
+    img = synth.synth_image(H + W, B, H, W)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oe = oracle.extractor_forward(et, sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, top_k=k,
+                                  scale=cfg.event_extractor[et].descriptor_scale_factor)
+    oi = oracle.extractor_forward(it, sub_dict(sd, "image_extractor.extractor."), img.copy(), None, top_k=k,
+                                  scale=cfg.image_extractor[it].descriptor_scale_factor)
+    for got, exp in ((ef, oe), (imf, oi)):
+        for key in ("backbone_feats", "logits", "raw_descriptors", "score", "nms"):
+            assert np.array_equal(got[key].cpu().numpy(), exp[key]), key
+        for b in range(B):
+            assert np.array_equal(got["sparse_positions"][b].cpu().numpy(), exp["sparse_positions"][b])
+            assert np.array_equal(got["sparse_descriptors"][b].cpu().numpy(), exp["sparse_descriptors"][b])
+    for b in range(B):
+        if len(oe["sparse_descriptors"][b]) == 0 or len(oi["sparse_descriptors"][b]) == 0:
+            continue
+        r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
+        assert np.array_equal(m["matches0"][b].cpu().numpy()[0], r["matches0"])
