@@ -6,7 +6,7 @@
  * (ei-nexus_official_amd/) never imports, links or calls it.
  *
  * Parity status: PINNED -- every function here is checked against golden vectors captured
- * from the reference itself (tests/golden/gen_golden.py -> tests/golden/*.npz, torch 2.10 CPU),
+ * from the reference itself (tests/golden/gen_golden.py -> tests/golden/<group>.npz, torch 2.10 CPU),
  * see tests/test_oracle_golden.py.
  *
  * Numeric contract (shared with the HIP kernels, include/einx_math.h): fp32 everywhere,
