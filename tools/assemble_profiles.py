@@ -47,14 +47,15 @@ def main():
                                  "--no-cpu-baseline --no-extras") + "\n")
                 fo.write(open(os.path.join(EV, src + ".err")).read())
                 fo.write(open(os.path.join(EV, src + ".json")).read())
-    for src, dst in (("layer_table.txt", "conv_layer_table.txt"), ("latency_b1.txt", "latency_b1.txt")):
+    for src, dst in (("layer_table.txt", "conv_layer_table.txt"), ("latency_b1.txt", "latency_b1.txt"), ("latency_b1_lg.txt", "latency_b1_sp_lg.txt")):
         if os.path.exists(os.path.join(EV, src)):
             txt = "\n".join(ln for ln in open(os.path.join(EV, src)).read().splitlines() if "amdgpu.ids" not in ln)
             open(os.path.join(PR, f"{R}_{dst}"), "w").write(txt + "\n")
     if os.path.exists(os.path.join(EV, "up_bench.txt")):
         shutil.copy(os.path.join(EV, "up_bench.txt"), os.path.join(PR, f"{R}_dense_up_bench.txt"))
     for src, dst in (("prof_overlap", "sp_mnn_b32_kernel_stats.csv"), ("prof_single", "sp_mnn_b32_kernel_stats_single_stream.csv"),
-                     ("prof_lg", "sp_lg_b64_kernel_stats.csv"), ("prof_dense", "dense_kernel_stats.csv")):
+                     ("prof_lg", "sp_lg_b64_kernel_stats.csv"), ("prof_dense", "dense_kernel_stats.csv"),
+                     ("prof_b1_mnn", "sp_mnn_b1_kernel_stats.csv"), ("prof_b1_lg", "sp_lg_b1_kernel_stats.csv")):
         ff = glob.glob(os.path.join(EV, src, "**", "*kernel_stats.csv"), recursive=True)
         if not ff:
             continue
@@ -268,6 +269,26 @@ def write_readme(pmc, busy):
         if os.path.exists(ub):
             A("")
             A("`tools/up_bench.py --ref` (HIP events): " + " / ".join(ln.strip() for ln in open(ub).read().splitlines() if ln.strip()))
+        A("")
+    for tag, title in (("sp_mnn_b1", "SP+MNN"), ("sp_lg_b1", "SP+LightGlue")):
+        bk = os.path.join(PR, f"{R}_{tag}_kernel_stats.csv")
+        if not os.path.exists(bk):
+            continue
+        rows = list(csv.DictReader(open(bk)))
+        nf = 620.0  # forwards of tools/latency_b1.py: 20 warm-up + 3 x 200
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        A(f"## Single pair, {title} (`{R}_{tag}_kernel_stats.csv`: `rocprofv3 --kernel-trace --stats -- python3 tools/latency_b1.py 1 {'SP_MNN' if 'mnn' in tag else 'SP_LG'}`, 620 forwards)")
+        A("")
+        A(f"Kernel time per forward (sum over both sides / all streams): {tot / nf / 1e3:.0f} us.")
+        A("")
+        A("| kernel | launches per forward | avg us | us per forward |")
+        A("|---|---|---|---|")
+        for r in rows[:14]:
+            A(f"| `{short(r['Name'])[:80]}` | {int(r['Calls']) / nf:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / nf / 1e3:.0f} |")
+        lt = os.path.join(PR, f"{R}_latency_b1{'_sp_lg' if 'lg' in tag else ''}.txt")
+        if os.path.exists(lt):
+            A("")
+            A("`tools/latency_b1.py` without the profiler: " + open(lt).read().strip().splitlines()[-1])
         A("")
     tp = os.path.join(PR, f"{R}_pmc_conv_tiles.json")
     if os.path.exists(tp):

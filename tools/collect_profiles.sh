@@ -27,6 +27,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lg -o p -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kernel_only -o p -- python3 $R/bench.py --kernel-only > $O/prof_kernel_only.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dense -o p -- python3 $R/tools/up_bench.py > $O/prof_dense.log 2>&1
 python3 $R/tools/up_bench.py --ref > $O/up_bench.txt 2>/dev/null
+# single pairs: kernel list of 620 forwards each (SP+MNN, SP+LightGlue)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1_mnn -o p -- python3 $R/tools/latency_b1.py 1 SP_MNN > $O/prof_b1_mnn.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1_lg -o p -- python3 $R/tools/latency_b1.py 1 SP_LG > $O/prof_b1_lg.log 2>&1
+python3 $R/tools/latency_b1.py 1 SP_LG > $O/latency_b1_lg.txt 2>/dev/null
 echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --kernel-only > $O/pmc_$c.log 2>&1
