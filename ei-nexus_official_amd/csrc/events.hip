@@ -83,7 +83,7 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const VoxArgs a, int r
     for (long long ib = tid; ib - lane < n; ib += 8 * 1024) {  // the wave's lanes walk 8 x 64 consecutive events per trip
       float yv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) yv[u] = ib + u * 1024 < n ? a.y[o0 + ib + u * 1024] : -4.0f;
+      for (int u = 0; u < 8; ++u) yv[u] = a.y[o0 + (ib + u * 1024 < n ? ib + u * 1024 : n - 1)];  // clamped address: guarded loads are serialised by hipcc
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const long long i = ib + u * 1024;
@@ -183,9 +183,15 @@ __global__ __launch_bounds__(1024) void minmax_kernel(const int32_t* cnt_all, in
   __shared__ int slo[16], shi[16];
   const int32_t* cnt = cnt_all + (size_t)blockIdx.x * n;
   int lo = 0x7fffffff, hi = -0x7fffffff - 1;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    lo = min(lo, cnt[i]);
-    hi = max(hi, cnt[i]);
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {  // eight loads in flight; a clamped index re-reads a valid element (harmless for min / max)
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = cnt[min(i0 + u * 1024, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      lo = min(lo, v[u]);
+      hi = max(hi, v[u]);
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
