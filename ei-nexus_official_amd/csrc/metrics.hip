@@ -113,15 +113,30 @@ __global__ __launch_bounds__(256) void metric_nearest_kernel(const MetArgs a) {
   const float sx = ps[0], sy = ps[1];
   float best = einx_u2f(0x7f800000u);
   int bj = 0x7fffffff;
-  for (int j = lane; j < other_n; j += 64) {
-    if (!keep_o[j]) continue;
-    // norm of (warped0 - p1): the difference is taken in that direction on both sides
-    const float dx = SIDE == 0 ? sx - po[2 * j] : po[2 * j] - sx;
-    const float dy = SIDE == 0 ? sy - po[2 * j + 1] : po[2 * j + 1] - sy;
-    const float d = sqrtf(fmaf(dy, dy, dx * dx));
-    if (d < best) {
-      best = d;
-      bj = j;
+  // four candidates per lane and trip, their flags and coordinates requested together from clamped addresses (one guarded
+  // load per iteration is a memory round trip each); evaluated in ascending j as before (strict <: the first minimum wins)
+  for (int j0 = lane; j0 < other_n; j0 += 256) {
+    uint8_t kk[4];
+    float ox[4], oy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jc = min(j0 + 64 * u, other_n - 1);
+      kk[u] = keep_o[jc];
+      ox[u] = po[2 * jc];
+      oy[u] = po[2 * jc + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + 64 * u;
+      if (j >= other_n || !kk[u]) continue;
+      // norm of (warped0 - p1): the difference is taken in that direction on both sides
+      const float dx = SIDE == 0 ? sx - ox[u] : ox[u] - sx;
+      const float dy = SIDE == 0 ? sy - oy[u] : oy[u] - sy;
+      const float d = sqrtf(fmaf(dy, dy, dx * dx));
+      if (d < best) {
+        best = d;
+        bj = j;
+      }
     }
   }
 #pragma unroll
@@ -146,13 +161,24 @@ __global__ __launch_bounds__(256) void metric_nearest_kernel(const MetArgs a) {
   const float* v1 = SIDE == 0 ? da : db;
   const float* v2 = SIDE == 0 ? db : da;
   float sq = 0.0f, dot = 0.0f, n1 = 0.0f, n2 = 0.0f;
-  for (int c = lane; c < D; c += 64) {
-    const float x1 = v1[c], x2 = v2[c];
-    const float df = x1 - x2;
-    sq = fmaf(df, df, sq);
-    dot = fmaf(x1, x2, dot);
-    n1 = fmaf(x1, x1, n1);
-    n2 = fmaf(x2, x2, n2);
+  for (int c0 = lane; c0 < D; c0 += 256) {  // same per-lane order c = lane, lane + 64, ...; four channel pairs in flight
+    float a1[4], a2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cc = min(c0 + 64 * u, D - 1);
+      a1[u] = v1[cc];
+      a2[u] = v2[cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c0 + 64 * u >= D) continue;
+      const float x1 = a1[u], x2 = a2[u];
+      const float df = x1 - x2;
+      sq = fmaf(df, df, sq);
+      dot = fmaf(x1, x2, dot);
+      n1 = fmaf(x1, x1, n1);
+      n2 = fmaf(x2, x2, n2);
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
