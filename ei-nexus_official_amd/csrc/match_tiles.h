@@ -263,29 +263,47 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
   }
 }
 
+// (max, sum exp(v - max)) of `chunks` per-chunk pairs: the maximum first, then the sum in ascending chunk order.  The pairs are
+// requested eight at a time from clamped addresses (a loop of single dependent loads is one memory round trip per chunk).
+__device__ __forceinline__ void lse_merge(const float* st, int chunks, float& mx, float& s) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  mx = -einx_u2f(0x7f800000u);
+  for (int c0 = 0; c0 < chunks; c0 += 8) {
+    f32x2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(st + 2 * min(c0 + u, chunks - 1));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u][0]);  // a clamped duplicate cannot change a maximum
+  }
+  s = 0.0f;
+  for (int c0 = 0; c0 < chunks; c0 += 8) {
+    f32x2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(st + 2 * min(c0 + u, chunks - 1));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (c0 + u < chunks) s = fmaf(v[u][1], einx_expf(v[u][0] - mx), s);
+  }
+}
+
 // merge per-chunk (max, sumexp) -> (max, log-sum-exp); also zero the dustbin row/column of la
 __global__ void mnn_lse_kernel(const MnnArgs a) {
   const int b = blockIdx.y;
   const int n = min(a.n[b], a.cap0), m = min(a.m[b], a.cap1);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const float NEG = -einx_u2f(0x7f800000u);
   if (t < n) {
     const int chunks = (m + 63) / 64;
     const float* st = a.rowstat + ((size_t)b * a.cap0 + t) * a.nc64 * 2;
-    float mx = NEG;
-    for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, st[2 * c]);
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s = fmaf(st[2 * c + 1], einx_expf(st[2 * c] - mx), s);
+    float mx, s;
+    lse_merge(st, chunks, mx, s);
     a.rowlse[((size_t)b * a.cap0 + t) * 2] = mx;
     a.rowlse[((size_t)b * a.cap0 + t) * 2 + 1] = einx_logf(s);
   }
   if (t < m) {
     const int chunks = (n + WROWS - 1) / WROWS;
     const float* st = a.colstat + ((size_t)b * a.cap1 + t) * a.nr64 * 2;
-    float mx = NEG;
-    for (int c = 0; c < chunks; ++c) mx = fmaxf(mx, st[2 * c]);
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s = fmaf(st[2 * c + 1], einx_expf(st[2 * c] - mx), s);
+    float mx, s;
+    lse_merge(st, chunks, mx, s);
     a.collse[((size_t)b * a.cap1 + t) * 2] = mx;
     a.collse[((size_t)b * a.cap1 + t) * 2 + 1] = einx_logf(s);
   }
