@@ -246,7 +246,11 @@ size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);
  * outputs as einx_mnn; scores are exp(max log-assignment) for mutual matches (:402-418);
  * ref0/ref1: optional ref_descriptors, or NULL.  ref_layers 0/1: [B,cap,d], the last layer
  * (eval, lightglue.py:626-629); ref_layers == n_layers: [B,n_layers,cap,d], every layer
- * (what the reference stacks when self.training, lightglue.py:626-629,709-710). */
+ * (what the reference stacks when self.training, lightglue.py:626-629,709-710).
+ * Schedule (same results either way): with cap0 == cap1 the two sides are stacked in the workspace and every layer is one
+ * launch over 2B entries; grids of fewer than 256 128x128 tiles (up to 7 pairs) run their linears on 64x64 tiles.
+ * ws: device scratch of einx_lg_ws_bytes(B, cap0, cap1, d, input_dim) bytes; rows of the outputs past an entry's
+ * count are left unwritten. */
 int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0, const float* kpts1,
                    const float* desc1, const int32_t* m, int cap1, int B, float h0, float w0, float h1, float w1, void* ws,
                    int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, float* ref0, float* ref1,
