@@ -42,6 +42,53 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _first_device(obj, depth=0):
+    """HIP device of the first tensor found in a call argument (tensor, feats dict / list of tensors, PairBatch, BatchedFeats)."""
+    if torch.is_tensor(obj):
+        return obj.device if obj.device.type == "cuda" else None
+    if depth > 2 or obj is None or isinstance(obj, (str, int, float, bool)):
+        return None
+    if isinstance(obj, dict):
+        obj = list(obj.values())
+    if isinstance(obj, (list, tuple)):
+        for v in obj[:16]:
+            d = _first_device(v, depth + 1)
+            if d is not None:
+                return d
+        return None
+    for name in ("desc", "score", "kpts"):  # PairBatch / BatchedFeats
+        t = getattr(obj, name, None)
+        if torch.is_tensor(t) and t.device.type == "cuda":
+            return t.device
+    return None
+
+
+def on_input_device(fn):
+    """The kernels are launched through ctypes on the stream of the INPUTS' device; HIP wants that device to be the current
+    one.  torch's own operators switch devices per call, the reference therefore works with a model on cuda:1 while
+    cuda:0 is current -- this decorator gives the drop-in's entry points the same behaviour (no-op on the current device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for a in args[1:] if args and not torch.is_tensor(args[0]) and hasattr(args[0], "__dict__") else args:
+            dev = _first_device(a)
+            if dev is not None:
+                break
+        if dev is None:
+            for a in kwargs.values():
+                dev = _first_device(a)
+                if dev is not None:
+                    break
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+
+    return wrapped
+
+
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 

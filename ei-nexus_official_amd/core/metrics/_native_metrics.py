@@ -3,6 +3,7 @@ import ctypes
 
 import torch
 
+from ..._native import on_input_device
 from ... import _native as N
 from ..._lib import MetricParams, check
 
@@ -14,6 +15,7 @@ def metric_names(mma_thr=(1, 3), vdd_thr=(1, 3), prefix_vdd="VDD"):
     return names
 
 
+@on_input_device
 def pair_metrics(kpts0, desc0, n, kpts1, desc1, m, mk0, mk1, nmatch, size0, size1, homography=None, mma_thr=(1, 3), vdd_thr=(1, 3),
                  ordering="yx", rep_nan_if_empty=False):
     """All tensors on the device: kpts [B,cap,3], desc [B,cap,D], counts int32 [B], matched keypoints
@@ -44,6 +46,7 @@ def pair_metrics(kpts0, desc0, n, kpts1, desc1, m, mk0, mk1, nmatch, size0, size
     return out
 
 
+@on_input_device
 def batch_metrics(ev, im, mr, homography=None, mma_thr=(1, 3), vdd_thr=(1, 3)):
     """Metrics for a whole EIM.forward_batched result (BatchedFeats x2 + MatchResult), no host sync."""
     return pair_metrics(ev.det.positions, ev.sparse_desc, ev.det.counts, im.det.positions, im.sparse_desc, im.det.counts, mr.mk0, mr.mk1,

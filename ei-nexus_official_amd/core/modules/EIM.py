@@ -9,6 +9,7 @@ import os
 import torch
 from torch import nn
 
+from ..._native import on_input_device
 from .Extractors import EventKeypointsExtractor, ImageKeypointsExtractor
 from .Matchers import Matcher
 from .matchers._batched import full_batch_lists
@@ -53,6 +54,7 @@ class EIM(nn.Module):
             st = EIM._side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("EINX_SIDE_PRIO", "0")))
         return st
 
+    @on_input_device
     def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False, before_match=None):
         """Enqueue the whole pipeline; returns device-side results without synchronising.
         The event and image extractors share nothing, so the event side is enqueued on a second HIP
@@ -113,6 +115,7 @@ class EIM(nn.Module):
             buf = self._host_bufs[name] = torch.empty(shape, dtype=torch.int32, pin_memory=True)
         return buf
 
+    @on_input_device
     def _enqueue(self, events, image, events_mask=None, image_mask=None, slot=0):
         """Device side of one forward, nothing waits: both extractors, the matcher, the two small count read-backs
         (non-blocking copies into pinned buffers of `slot`, each followed by an event) and every output that does
@@ -138,6 +141,7 @@ class EIM(nn.Module):
         p["pre"] = full_batch_lists(mr) if mr is not None else None
         return p
 
+    @on_input_device
     def _finish(self, p):
         """Host side of one forward: wait for the two read-backs, cut the per-pair lists."""
         ev, im, mr, pre = p["ev"], p["im"], p["mr"], p["pre"]
@@ -185,6 +189,7 @@ class EIM(nn.Module):
             matches = self.matcher(events_feats, image_feats)
         return events_feats, image_feats, matches
 
+    @on_input_device
     def forward(self, events, image, events_mask=None, image_mask=None):
         """The host reads the counts back in two steps: the per-image keypoint counts are copied (pinned buffer,
         non-blocking) as soon as both extractors are done, so the feature lists are built while the matcher still

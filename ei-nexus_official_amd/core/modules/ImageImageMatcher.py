@@ -3,6 +3,7 @@ core/modules/ImageImageMatcher.py:13-85)."""
 import torch
 from torch import nn
 
+from ..._native import on_input_device
 from .Extractors import ImageKeypointsExtractor
 from .Matchers import Matcher
 
@@ -22,6 +23,7 @@ class ImageImageMatcher(nn.Module):
             m = torch.load(config.pretrain_stage2.model_path, map_location=device)
             self.matcher.load_state_dict({k[8:]: v for k, v in m.items() if "matcher" in k})
 
+    @on_input_device
     def forward(self, image0, image1, mask=None):
         f0 = self.image_extractor(image0, mask=mask)
         f1 = self.image_extractor(image1)

@@ -8,6 +8,7 @@ same torch generators in the same order), autograd and the losses are not part o
 import torch
 from torch import nn
 
+from ..._native import on_input_device
 from ... import _native as N
 
 from .matchers.MNN import NearestNeighborMatcher
@@ -52,6 +53,7 @@ class Matcher(nn.Module):
     def _cols(self):
         return 3 if self.matcher_type == "MNN" else 2
 
+    @on_input_device
     def match_batched(self, bf0, bf1):
         """BatchedFeats x2 -> MatchResult on the device (no sync).  The matched keypoints are also
         packed pair after pair so that materialize() cuts the per-pair lists with one split call."""
@@ -119,6 +121,7 @@ class Matcher(nn.Module):
         feats["sparse_descriptors"] = torch.stack(feats["sparse_descriptors"], dim=0)
         return feats
 
+    @on_input_device
     def forward(self, feats0, feats1, *args, **kargs):
         if self.matcher is None:
             return {"matches0": None, "matches1": None, "matching_scores0": None, "matching_scores1": None, "similarity": None,

@@ -2,6 +2,7 @@
 import torch
 from torch import nn
 
+from ..._native import on_input_device
 from ... import _native as N
 from ..._extract import ExtractorEngine
 from .net.vgg import block_spec
@@ -92,6 +93,7 @@ class NativeExtractor(nn.Module):
     def _prepare_input(self, x):
         return x
 
+    @on_input_device
     def extract_batched(self, x, score_mask=None, nms_iters=None, dense=None, prepared=False, defer_dense=False):
         """prepared=True: `x` already went through _prepare_input (retry after an NMS overflow).
         defer_dense=True: the dense descriptor map is left to the caller (`bf.run_dense()` on a stream of its choice)."""
@@ -106,6 +108,7 @@ class NativeExtractor(nn.Module):
         return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
                        nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
 
+    @on_input_device
     def forward(self, x, score_mask=None, **kwargs):
         bf = self.extract_batched(x, score_mask)
         for _ in range(9):

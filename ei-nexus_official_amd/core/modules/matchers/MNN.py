@@ -9,6 +9,7 @@ run as a second-neighbour tile pass + a masked finalize (einx_mnn_thresh).
 import torch
 from torch import nn
 
+from ...._native import on_input_device
 from .... import _native as N
 from ._batched import from_feats, materialize_matches, stacked_outputs
 
@@ -24,6 +25,7 @@ class NearestNeighborMatcher(nn.Module):
         self.want_log_assignment = True
         self.return_similarity = False
 
+    @on_input_device
     def match_batched(self, pb0, pb1):
         """device-side: no host sync"""
         r = N.mnn(pb0.desc, pb0.counts, pb1.desc, pb1.counts, want_la=self.want_log_assignment, ratio_thresh=self.ratio_thresh,
@@ -31,6 +33,7 @@ class NearestNeighborMatcher(nn.Module):
         return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 3)
 
     @torch.no_grad()
+    @on_input_device
     def forward(self, feats0, feats1):
         """B == 1: the per-pair dict of the frozen path.  B > 1 (stacked [B,n,*] inputs, every pair
         with the same n and m -- the un-frozen Matcher branch): whole-batch tensors, lists of matched

@@ -12,6 +12,7 @@ import ctypes
 import torch
 from torch import nn
 
+from ...._native import on_input_device
 from .... import _lib
 from .... import _native as N
 from ._batched import from_feats, materialize_matches, stacked_outputs
@@ -196,6 +197,7 @@ class LightGlue(nn.Module):
         self._packed = (w, layers, keep)
         return self._packed
 
+    @on_input_device
     def match_batched(self, pb0, pb1, all_layers=False):
         if pb0.desc.shape[-1] != self.conf.input_dim or pb1.desc.shape[-1] != self.conf.input_dim:
             raise AssertionError("descriptor dimension does not match conf.input_dim")
@@ -204,6 +206,7 @@ class LightGlue(nn.Module):
         return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 2)
 
     @torch.no_grad()
+    @on_input_device
     def forward(self, feats0, feats1):
         """B == 1: the per-pair dict (matched keypoints in pixel coordinates, lightglue.py:689-698).
         B > 1 (stacked [B,n,*] inputs): whole-batch tensors and per-pair matched keypoints in

@@ -154,3 +154,39 @@ def test_native_wrappers_reject_wrong_dtypes():
     nat._dev_check(FakeCuda(torch.zeros(4)), None)
     with pytest.raises(RuntimeError, match="HIP device"):
         nat._dev_check(torch.zeros(4))
+
+
+def test_entry_points_switch_to_the_inputs_device(monkeypatch):
+    """ctypes launches need the inputs' device to be current (torch's own operators switch per call, so the reference works
+    with a model on cuda:1 while cuda:0 is current): the entry-point decorator enters torch.cuda.device(inputs' device) when
+    it differs from the current one, and does nothing otherwise or for CPU inputs."""
+    nat = pkg._native
+    entered = []
+
+    class FakeGuard:
+        def __init__(self, dev):
+            self.dev = dev
+
+        def __enter__(self):
+            entered.append(self.dev)
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", FakeGuard)
+    seen = {}
+    monkeypatch.setattr(nat, "_first_device", lambda obj, depth=0: seen.get(id(obj)))
+
+    class M:
+        @nat.on_input_device
+        def forward(self, x, y=None):
+            return "ran"
+
+    a, b = object(), object()
+    seen[id(a)] = torch.device("cuda", 1)
+    seen[id(b)] = torch.device("cuda", 0)
+    assert M().forward(a) == "ran" and entered == [torch.device("cuda", 1)]
+    assert M().forward(b) == "ran" and len(entered) == 1  # already current: no guard
+    assert M().forward(object(), y=a) == "ran" and len(entered) == 2  # found among the keyword arguments
+    assert M().forward(torch.zeros(2)) == "ran" and len(entered) == 2  # CPU input: left to the wrappers' own error
