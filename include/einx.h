@@ -8,6 +8,7 @@
  *   - plain pointers + sizes; every pointer is DEVICE memory unless it says "host";
  *   - tensors are dense, fp32, NCHW / row-major, exactly the reference's logical layouts;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
+ *   - the caller makes the device of `stream` and of the buffers the current HIP device (hipSetDevice) before a call;
  *   - return 0 on success, negative on error (einx_last_error() gives the text);
  *   - no allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.
  * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
