@@ -215,7 +215,10 @@ __global__ void normalize_map_kernel(const float* raw, int B, int D, int P, floa
 // each row of a band is stored as one 256-byte segment per channel.  Pass 1 accumulates the per-pixel
 // squared norm as the sequential fmaf chain c = 0..D-1, pass 2 recomputes and writes scale * v / norm.
 constexpr int UP_COLS = 384;  // columns per workgroup: whole 346-pixel rows, so a band is one contiguous run per channel
-constexpr int UP_ROWS = 8;    // rows per sweep: a band of the usual 1/8 scale (the first band takes two sweeps)
+#ifndef EINX_UP_ROWS
+#define EINX_UP_ROWS 8
+#endif
+constexpr int UP_ROWS = EINX_UP_ROWS;    // rows per sweep: a band of the usual 1/8 scale (the first band takes two sweeps)
   // 
 
 __global__ __launch_bounds__(UP_COLS) void upsample_band_kernel(const float* raw, int D, int hc, int wc, int Hp, int Wp, int h0, int w0, int H,
@@ -368,7 +371,10 @@ constexpr int UP_PAIRS = 16;  // (channel, coarse row) pairs a wave of the store
 #endif
 constexpr int UPD_PAIRS = EINX_UPD_PAIRS;  // ... and a wave of the den kernel per round (registers: five of its workgroups per CU)
 
-constexpr int UP_MAX_EXTRA = 8;
+#ifndef EINX_UP_MAX_EXTRA
+#define EINX_UP_MAX_EXTRA 8
+#endif
+constexpr int UP_MAX_EXTRA = EINX_UP_MAX_EXTRA;
 struct UpGeom {
   int D, hc, wc, Hp, Wp, h0, w0, H, W;
   int units;  // hc first sweeps + n_extra further sweeps of bands taller than UP_ROWS (band 0 at the shipped size)
