@@ -72,15 +72,10 @@ def on_input_device(fn):
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
         dev = None
-        for a in args[1:] if args and not torch.is_tensor(args[0]) and hasattr(args[0], "__dict__") else args:
+        for a in list(args) + list(kwargs.values()):  # `self` (a module) holds no tensor attribute the scan looks at
             dev = _first_device(a)
             if dev is not None:
                 break
-        if dev is None:
-            for a in kwargs.values():
-                dev = _first_device(a)
-                if dev is not None:
-                    break
         if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
             return fn(*args, **kwargs)
         with torch.cuda.device(dev):
