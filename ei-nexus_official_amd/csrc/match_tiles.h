@@ -39,6 +39,7 @@ struct MnnArgs {
 };
 
 // MODE 0: arg-max keys.  MODE 1: per-chunk softmax statistics.  MODE 2: write log_assignment.
+// MODE 5: MODE 0 and MODE 1 on one visit of the tile (MNN with log_assignment: two similarity passes instead of three).
 // MODE 3: write the raw similarity tile to a.la as [B,cap0,cap1] (MNN.py:88 `similarity`).
 // MODE 4: second neighbour (topk(2)[1], MNN.py:13-14): per row the maximum over all columns but the arg-max
 //         column found by MODE 0 (an equal value at another index counts, as topk returns it), same per column.
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
       }
   }
 
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 5) {
     // ---- column arg-max over this wave's 64 rows (ascending i, strict > keeps the first) ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
         }
         if ((lane & 31) == 0 && i < n && bj != 0x7fffffff) atomicMax(&a.rowkey[(size_t)b * a.cap0 + i], pack_key(bv, bj));
       }
-  } else if (MODE == 1) {
+  }
+  if (MODE == 1 || MODE == 5) {
     const int wave = threadIdx.x >> 6;
     const int cchunk = (j0 >> 6) + (wave & 1), rchunk = i0 / WROWS + (wave >> 1);
     // rows: (max, sum exp(v-max)) over this wave's 64 columns
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
         o[1] = s;
       }
     }
+  } else if (MODE == 0) {
   } else if (MODE == 4) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {

@@ -75,7 +75,10 @@ EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, 
     return EINX_ERR_LAUNCH;
   }
   const dim3 grid((unsigned)einx_cdiv(cap1, BN), (unsigned)einx_cdiv(cap0, BM), (unsigned)B);
-  {
+  if (la) {  // arg-max keys and the log_assignment's softmax statistics from one visit of every tile
+    EINX_PROF("mnn_tile_kernel<5>", s);
+    hipLaunchKernelGGL(mnn_tile_kernel<5>, grid, dim3(THREADS), 0, s, a);
+  } else {
     EINX_PROF("mnn_tile_kernel<0>", s);
     hipLaunchKernelGGL(mnn_tile_kernel<0>, grid, dim3(THREADS), 0, s, a);
   }
@@ -94,8 +97,6 @@ EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, 
   }
   EINX_CHECK_LAUNCH();
   if (la) {
-    hipLaunchKernelGGL(mnn_tile_kernel<1>, grid, dim3(THREADS), 0, s, a);
-    EINX_CHECK_LAUNCH();
     hipLaunchKernelGGL(mnn_lse_kernel, dim3((unsigned)einx_cdiv(mx + 1, 256), (unsigned)B), dim3(256), 0, s, a);
     EINX_CHECK_LAUNCH();
     hipLaunchKernelGGL(mnn_tile_kernel<2>, grid, dim3(THREADS), 0, s, a);
