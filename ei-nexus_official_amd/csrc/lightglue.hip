@@ -1210,12 +1210,9 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   LG_CHECK(0);
   hipLaunchKernelGGL(mnn_lse_kernel, dim3((unsigned)einx_cdiv(mx + 1, 256), (unsigned)B), dim3(256), 0, st, a);
   LG_CHECK(0);
-  hipLaunchKernelGGL((mnn_tile_kernel<0, true>), grid, dim3(THREADS), 0, st, a);
+  if (la) hipLaunchKernelGGL((mnn_tile_kernel<6, true>), grid, dim3(THREADS), 0, st, a);  // arg-max + log_assignment write in one visit
+  else hipLaunchKernelGGL((mnn_tile_kernel<0, true>), grid, dim3(THREADS), 0, st, a);
   LG_CHECK(0);
-  if (la) {
-    hipLaunchKernelGGL((mnn_tile_kernel<2, true>), grid, dim3(THREADS), 0, st, a);
-    LG_CHECK(0);
-  }
   hipLaunchKernelGGL(lg_finalize_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, st, a.rowkey, a.colkey, n, m, cap0, cap1,
                      w->filter_threshold, matches0, matches1, scores0, scores1);
   LG_CHECK(0);

@@ -39,7 +39,9 @@ struct MnnArgs {
 };
 
 // MODE 0: arg-max keys.  MODE 1: per-chunk softmax statistics.  MODE 2: write log_assignment.
-// MODE 5: MODE 0 and MODE 1 on one visit of the tile (MNN with log_assignment: two similarity passes instead of three).
+// MODE 5: MODE 0 and MODE 1 on one visit of the tile, and the raw similarity into a.la (MNN with log_assignment: ONE
+//         similarity pass; mnn_lse_kernel + mnn_la_apply_kernel finish the dual softmax in place).
+// MODE 6: MODE 0 and MODE 2 on one visit (LightGlue: arg-max of the assignment scores and the log_assignment write).
 // MODE 3: write the raw similarity tile to a.la as [B,cap0,cap1] (MNN.py:88 `similarity`).
 // MODE 4: second neighbour (topk(2)[1], MNN.py:13-14): per row the maximum over all columns but the arg-max
 //         column found by MODE 0 (an equal value at another index counts, as topk returns it), same per column.
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
       }
   }
 
-  if (MODE == 0 || MODE == 5) {
+  if (MODE == 0 || MODE == 5 || MODE == 6) {
     // ---- column arg-max over this wave's 64 rows (ascending i, strict > keeps the first) ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -185,7 +187,22 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
         o[1] = s;
       }
     }
-  } else if (MODE == 0) {
+    if (MODE == 5) {  // the raw similarity goes to the log_assignment buffer; mnn_la_apply_kernel turns it into the dual softmax in place
+      const size_t pitch = (size_t)a.cap1 + 1;
+      float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + row_of(mt, r);
+          if (i >= n) continue;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int j = j0 + col_of(nt);
+            if (j < m) la[(size_t)i * pitch + j] = f.acc[mt][nt][r];
+          }
+        }
+    }
   } else if (MODE == 4) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -232,7 +249,8 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
           if (j < m) sim[(size_t)i * a.cap1 + j] = f.acc[mt][nt][r];
         }
       }
-  } else {
+  }
+  if (MODE == 2 || MODE == 6) {
     const size_t pitch = (size_t)a.cap1 + 1;
     float* la = a.la + (size_t)b * (a.cap0 + 1) * pitch;
     // the (max, lse) pairs of the lane's columns and rows are requested together from clamped addresses: loads guarded per
@@ -316,6 +334,22 @@ __global__ void mnn_lse_kernel(const MnnArgs a) {
     if (t <= m) la[(size_t)n * pitch + t] = (a.dust1 && t < m) ? a.dust1[(size_t)b * a.cap1 + t] : 0.0f;
     if (t <= n) la[(size_t)t * pitch + m] = (a.dust0 && t < n) ? a.dust0[(size_t)b * a.cap0 + t] : 0.0f;
   }
+}
+
+// log_assignment[i][j] = log_softmax(sim, -1) + log_softmax(sim, -2) (MNN.py:97-99) in place on the raw similarity that
+// mnn_tile_kernel<5> left in the buffer: the same expression on the same values as mnn_tile_kernel<2>, without a third
+// similarity pass.  One thread per element, rows contiguous along j.
+__global__ __launch_bounds__(256) void mnn_la_apply_kernel(const MnnArgs a) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  const int n = min(a.n[b], a.cap0), m = min(a.m[b], a.cap1);
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || j >= m) return;
+  const size_t pitch = (size_t)a.cap1 + 1;
+  float* p = a.la + (size_t)b * (a.cap0 + 1) * pitch + (size_t)i * pitch + j;
+  const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
+  const float cm = a.collse[((size_t)b * a.cap1 + j) * 2], cl = a.collse[((size_t)b * a.cap1 + j) * 2 + 1];
+  const float sv = *p;
+  *p = ((sv - rm) - rl) + ((sv - cm) - cl);
 }
 
 // keys -> matches, mutual check, scores (MNN.py:25-32, :100-101)
