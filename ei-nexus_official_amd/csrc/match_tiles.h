@@ -340,16 +340,18 @@ __global__ void mnn_lse_kernel(const MnnArgs a) {
 // mnn_tile_kernel<5> left in the buffer: the same expression on the same values as mnn_tile_kernel<2>, without a third
 // similarity pass.  One thread per element, rows contiguous along j.
 __global__ __launch_bounds__(256) void mnn_la_apply_kernel(const MnnArgs a) {
-  const int b = blockIdx.z, i = blockIdx.y;
+  const int b = blockIdx.z;
   const int n = min(a.n[b], a.cap0), m = min(a.m[b], a.cap1);
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || j >= m) return;
+  if (j >= m) return;
   const size_t pitch = (size_t)a.cap1 + 1;
-  float* p = a.la + (size_t)b * (a.cap0 + 1) * pitch + (size_t)i * pitch + j;
-  const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
   const float cm = a.collse[((size_t)b * a.cap1 + j) * 2], cl = a.collse[((size_t)b * a.cap1 + j) * 2 + 1];
-  const float sv = *p;
-  *p = ((sv - rm) - rl) + ((sv - cm) - cl);
+  for (int i = blockIdx.y; i < n; i += gridDim.y) {  // one row per workgroup unless cap0 exceeds the grid's y limit
+    float* p = a.la + (size_t)b * (a.cap0 + 1) * pitch + (size_t)i * pitch + j;
+    const float rm = a.rowlse[((size_t)b * a.cap0 + i) * 2], rl = a.rowlse[((size_t)b * a.cap0 + i) * 2 + 1];
+    const float sv = *p;
+    *p = ((sv - rm) - rl) + ((sv - cm) - cl);
+  }
 }
 
 // keys -> matches, mutual check, scores (MNN.py:25-32, :100-101)

@@ -99,7 +99,7 @@ EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, 
   if (la) {
     hipLaunchKernelGGL(mnn_lse_kernel, dim3((unsigned)einx_cdiv(mx + 1, 256), (unsigned)B), dim3(256), 0, s, a);
     EINX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mnn_la_apply_kernel, dim3((unsigned)einx_cdiv(cap1, 256), (unsigned)cap0, (unsigned)B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mnn_la_apply_kernel, dim3((unsigned)einx_cdiv(cap1, 256), (unsigned)(cap0 < 32768 ? cap0 : 32768), (unsigned)B), dim3(256), 0, s, a);
     EINX_CHECK_LAUNCH();
   }
   return EINX_OK;
