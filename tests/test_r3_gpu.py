@@ -290,3 +290,36 @@ def test_whole_forward_at_odd_geometries_vs_oracle(oracle, cfg_name, B, H, W, bi
             continue
         r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
         assert np.array_equal(m["matches0"][b].cpu().numpy()[0], r["matches0"])
+
+
+# ------------------------------------------------------------------ non-default detector parameters through the whole extractor
+@pytest.mark.parametrize("cfg_name,radius,border,k,thr", [("SP_MNN", 2, 8, 300, 1.0), ("SP_MNN", 0, 0, 500, 1.0), ("SP_MNN", 3, 1, 0, 0.02),
+                                                           ("SiLK_MNN", 1, 6, 400, 1.0)], ids=lambda v: str(v))
+def test_extractors_with_other_detector_parameters_vs_oracle(oracle, cfg_name, radius, border, k, thr):
+    """nms_radius / remove_borders / detection_top_k / detection_threshold other than the shipped 4 / 4 / 1024 / 1.0 (radius 0 = no
+    NMS, top_k 0 with an active threshold = unbounded capacity path) through both extractors vs the oracle."""
+    from helpers import sub_dict
+    cfg = pkg.default_config(cfg_name, event_channels=5)
+    et, it = cfg.event_extractor.type, cfg.image_extractor.type
+    for sec in (cfg.event_extractor[et], cfg.image_extractor[it]):
+        sec.nms_radius, sec.remove_borders, sec.detection_top_k, sec.detection_threshold = radius, border, (k or None), thr
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(kk, tuple(v.shape)) for kk, v in model.state_dict().items()], seed=radius * 10 + border)
+    model.load_state_dict({kk: torch.from_numpy(v) for kk, v in sd.items()}, strict=False)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    H, W, B = 72, 104, 2
+    ev, mask = synth.synth_events(55 + radius, B, 5, H, W)
+    img = synth.synth_image(55 + radius, B, H, W)
+    ef = model.event_extractor(_t(ev), _t(mask))
+    imf = model.image_extractor(_t(img))
+    kw = dict(top_k=k, radius=radius, border=border, det_thr=thr)
+    oe = oracle.extractor_forward(et, sub_dict(sd, "event_extractor.extractor."), ev.copy(), mask, scale=cfg.event_extractor[et].descriptor_scale_factor, **kw)
+    oi = oracle.extractor_forward(it, sub_dict(sd, "image_extractor.extractor."), img.copy(), None, scale=cfg.image_extractor[it].descriptor_scale_factor, **kw)
+    for got, exp in ((ef, oe), (imf, oi)):
+        assert np.array_equal(got["score"].cpu().numpy(), exp["score"])
+        assert np.array_equal(got["nms"].cpu().numpy(), exp["nms"])
+        for b in range(B):
+            assert np.array_equal(got["sparse_positions"][b].cpu().numpy(), exp["sparse_positions"][b]), f"image {b}"
+            assert np.array_equal(got["sparse_descriptors"][b].cpu().numpy(), exp["sparse_descriptors"][b])
+    assert sum(len(p) for p in oe["sparse_positions"]) > 0
