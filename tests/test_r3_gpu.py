@@ -49,7 +49,14 @@ def _tiled(a, B):
     return np.concatenate([a] * (B // a.shape[0]), axis=0)
 
 
+def _need_free_gb(gb):
+    free = torch.cuda.mem_get_info()[0] / 2**30
+    if free < gb:
+        pytest.skip(f"needs {gb} GB of free device memory, {free:.0f} GB available")
+
+
 def test_batch_384_activations_beyond_2_31_elements_equal_the_small_batch():
+    _need_free_gb(96)
     B = 384
     assert B * 64 * 264 * 352 > 2**31
     model = _model()
@@ -70,6 +77,7 @@ def test_batch_384_activations_beyond_2_31_elements_equal_the_small_batch():
 
 
 def test_batch_96_dense_descriptor_map_beyond_2_31_elements_equals_the_small_batch():
+    _need_free_gb(48)
     B = 96
     assert B * 256 * 260 * 346 > 2**31
     model = _model(dense_event=True)
