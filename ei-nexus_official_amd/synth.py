@@ -129,3 +129,78 @@ def synth_unit_descriptors(seed, n, dim, scale=1.0):
     d = normalish(seed, (n, dim), lane=5).astype(np.float64)
     d = d / np.maximum(np.sqrt((d * d).sum(-1, keepdims=True)), 1e-12)
     return (d * scale).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "Same scene" workloads (round 4).  Independent random networks on independent random inputs give descriptors that are
+# nearly orthogonal across the two sides (a handful of mutual nearest neighbours in 1024, LightGlue scores ~1e-6), a
+# regime in which float tolerances on the matcher outputs check nothing.  The recipes below are RULES on top of the
+# name-synthesised weights (no stored data): the event extractor computes the image extractor's function (same conv
+# weights, identity BatchNorm where the image side has none), and the event voxels are the image / 255 in every bin
+# plus a sparse perturbation -- events and image of one scene.  Hundreds of mutual matches per pair follow.
+# ---------------------------------------------------------------------------------------------------------------------
+_EV = "event_extractor.extractor."
+_IM = "image_extractor.extractor."
+_EV_SLOTS = [f"backbone.l{s}.{i}" for s in (1, 2, 3, 4) for i in (0, 1)] + \
+    ["detector_head._detH1", "detector_head._detH2", "descriptor_head._desH1", "descriptor_head._desH2"]
+_SP_SLOTS = [f"conv{s}{ab}" for s in (1, 2, 3, 4) for ab in "ab"] + ["convPa", "convPb", "convDa", "convDb"]
+_SILK_HEADS = "model.backbone._heads._mods."
+_SILK_SLOTS = [f"model.backbone._backbone.layers.{s}.{i}" for s in (0, 1, 2, 3) for i in (0, 1)] + \
+    [_SILK_HEADS + "logits._detH1", _SILK_HEADS + "logits._detH2", _SILK_HEADS + "raw_descriptors._desH1",
+     _SILK_HEADS + "raw_descriptors._desH2"]
+
+
+def _embed(dst_shape, src, fill=0.0):
+    out = np.full(dst_shape, np.float32(fill), np.float32)
+    out[tuple(slice(0, s) for s in src.shape)] = src
+    return out
+
+
+def twin_overrides(sd):
+    """sd: numpy state dict of an EIM (event VGG / VGG_NP + image SuperPointv1 / SiLK).  Returns the event-extractor entries
+    that make it the image extractor's twin: conv i <- image conv i (a thinner image layer is embedded in the leading
+    channels, the rest zero; a 1-channel first layer is spread evenly over the event bins), BatchNorm <- the image side's
+    BatchNorm (SiLK) or the identity (SuperPoint has none)."""
+    silk = any(k.startswith(_IM + "model.backbone.") for k in sd)
+    out = {}
+    for es, ims in zip(_EV_SLOTS, _SILK_SLOTS if silk else _SP_SLOTS):
+        ew = _EV + es + ".0.weight"
+        iw = _IM + ims + (".0.weight" if silk else ".weight")
+        w = sd[iw]
+        shape = sd[ew].shape
+        if w.shape[1] == 1 and shape[1] > 1:
+            w = (np.repeat(w, shape[1], 1) / np.float32(shape[1])).astype(np.float32)
+        out[ew] = _embed(shape, w)
+        out[_EV + es + ".0.bias"] = _embed(shape[:1], sd[iw[:-6] + "bias"])
+        ebn = _EV + es + (".2." if _EV + es + ".2.weight" in sd else ".1.")
+        ibn = _IM + ims + (".2." if _IM + ims + ".2.weight" in sd else ".1.")
+        for leaf, ident in (("weight", 1.0), ("bias", 0.0), ("running_mean", 0.0), ("running_var", 1.0)):
+            out[ebn + leaf] = _embed(shape[:1], sd[ibn + leaf], ident) if silk else np.full(shape[:1], np.float32(ident), np.float32)
+    return out
+
+
+def twin_events(ev, img, alpha=0.05):
+    """event voxels of the same scene: image / 255 in every bin + alpha x the sparse synthetic events"""
+    return (ev * np.float32(alpha) + img / np.float32(255.0)).astype(np.float32)
+
+
+def lightglue_calibration(sd, x, prefix="", temperature=32.0, z_mean=3.0, layer=8):
+    """Random-weight LightGlue ends in descriptors dominated by one common vector (norm ~47 of ~48), so its assignment is
+    flat.  Remove it where a trained network would not have it in the first place -- in the last block's residual update
+    (cross_attn.ffn.3.bias <- bias - mean(x), the same vector on both sides: lightglue.py:327-328) --, scale final_proj so that a
+    typical centred descriptor has |mdesc|^2 = `temperature` (lightglue.py:391-394: sim = <W x0 + b, W x1 + b> / 16) and shift
+    the matchability logit to a mean of `z_mean`.  x: [N,256] final-layer descriptors of both sides (the matcher's
+    ref_descriptors).  Returns (overrides, scale): final_proj.weight is W * float32(scale) elementwise (a rule; fixtures store
+    the scalar), final_proj.bias is scaled alike, the two bias vectors are data."""
+    p = f"{prefix}log_assignment.{layer}."
+    fb = f"{prefix}transformers.{layer}.cross_attn.ffn.3.bias"
+    x = np.asarray(x, np.float64)
+    mean = x.mean(0)
+    xc = x - mean
+    cn = float(np.sqrt((xc ** 2).sum(1)).mean())
+    scale = np.float32(np.sqrt(temperature) * 4.0 / cn)
+    z = xc @ sd[p + "matchability.weight"].astype(np.float64).reshape(-1)
+    return {fb: (sd[fb].astype(np.float64) - mean).astype(np.float32),
+            p + "final_proj.weight": (sd[p + "final_proj.weight"] * scale).astype(np.float32),
+            p + "final_proj.bias": (sd[p + "final_proj.bias"] * scale).astype(np.float32),
+            p + "matchability.bias": np.array([z_mean - float(z.mean())], np.float32)}, scale

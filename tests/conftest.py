@@ -24,15 +24,16 @@ def pytest_sessionfinish(session, exitstatus):
     """Measured float errors of the tolerance-based comparisons (helpers.close_and_record): printed and kept as
     gpurun_out/parity_errors.json (the GPU box merges gpurun_out/ back)."""
     import json
-    from helpers import recorded_errors
+    from helpers import recorded_errors, recorded_flips
     errs = recorded_errors()
-    if not errs:
+    flips = recorded_flips()
+    if not errs and not flips:
         return
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, "parity_errors.json"), "w") as f:
-            json.dump(errs, f, indent=1, sort_keys=True)
+            json.dump(dict(errs, **({"assignment_flips": flips} if flips else {})), f, indent=1, sort_keys=True)
     except OSError:
         pass
     tr = session.config.pluginmanager.get_plugin("terminalreporter")
@@ -42,3 +43,8 @@ def pytest_sessionfinish(session, exitstatus):
         for k in sorted(errs):
             e = errs[k]
             tr.write_line(f"  {k}: {e['max_abs_err']:.3e} / {e['atol']:.1e}   (|ref| <= {e['max_abs_ref']:.3g}, {e['n']} values)")
+        if flips:
+            tr.write_line("match-assignment flips (tag: flips / assignments compared, matched in the checker; margins of flipped rows):")
+            for k in sorted(flips):
+                e = flips[k]
+                tr.write_line(f"  {k}: {e['flips']} / {e['compared']} ({e['matched']} matched)" + (f"  margins {e['margins']}" if e["margins"] else ""))

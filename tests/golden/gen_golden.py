@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii cfgsweep
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii lgcal cfgsweep
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -908,6 +908,171 @@ def gen_ii():
 
 
 GROUPS["ii"] = gen_ii
+
+
+# =========================================================================================
+# lgcal (round 4): LightGlue end to end in a NON-degenerate regime + the reference's own float noise floor.
+#   * "same scene" pairs (synth.twin_overrides / twin_events: the event extractor is the image extractor's twin, events =
+#     image / 255 + sparse perturbation) -> ~700 mutual nearest neighbours of 1024 on the input descriptors;
+#   * LightGlue's assignment head calibrated like the descriptor heads were (synth.lightglue_calibration: final_proj centred
+#     and scaled, matchability shifted) -> hundreds of matches per pair with matching_scores spread over 0.01 .. 0.95;
+#   * noise floor: the SAME reference model on the SAME inputs with (a) 1 instead of 8 torch threads and (b) the keypoints of
+#     both sides permuted (LightGlue is permutation-equivariant; outputs are un-permuted before comparing).  What differs is
+#     pure summation order inside the reference -- the tests bound log_assignment by a multiple of it instead of a hand-picked
+#     tolerance, and count assignment flips against it.
+# =========================================================================================
+LGCAL_CASES = [
+    dict(name="sp_lg_twin", event_type="vgg", image_type="superpointv1", matcher="LightGlue", ce=5, B=2, wseed=41, iseed=51),
+    dict(name="silk_lg_twin", event_type="vgg_np", image_type="silk", matcher="LightGlue", ce=5, B=1, wseed=42, iseed=52),
+]
+LG_TEMPERATURE = 32.0
+
+
+def _one(f, b):
+    return {k: f[k][b][None] for k in ("sparse_positions", "sparse_descriptors", "image_size")}
+
+
+def _perm(seed, n):
+    return np.argsort(synth.uniform01(seed, (n,)), kind="stable")
+
+
+COND_EPS = 2e-6
+
+
+def lg_noise_floor(lg, f0, f1, seed, n_perm=3):
+    """f0/f1: single-pair feature dicts ([1,n,*]).  Returns (differences, float64 result): the reference-vs-reference
+    differences described above (maxima over `n_perm` keypoint permutations) and the fp32 reference's distance from the SAME
+    reference module evaluated in float64 on the same fp32 inputs (`*_f64`: its own rounding error)."""
+    import copy
+    n, m = f0["sparse_positions"].shape[1], f1["sparse_positions"].shape[1]
+    with torch.no_grad():
+        base = lg(f0, f1)
+        torch.set_num_threads(1)
+        one = lg(f0, f1)
+        torch.set_num_threads(8)
+        dbl = lambda f: {k: (v.double() if torch.is_tensor(v) else v) for k, v in f.items()}  # noqa: E731
+        r64 = copy.deepcopy(lg).double()(dbl(f0), dbl(f1))
+        # conditioning: the reference on descriptors that differ by +-COND_EPS (uniform) -- the size at which extractor outputs
+        # of two correct fp32 implementations differ; what an END-TO-END comparison of log_assignment inherits from upstream
+        jit = lambda t, s_: t + torch.from_numpy(synth.uniform(s_, tuple(t.shape), -COND_EPS, COND_EPS))  # noqa: E731
+        rc = lg(dict(f0, sparse_descriptors=jit(f0["sparse_descriptors"], seed + 50)), dict(f1, sparse_descriptors=jit(f1["sparse_descriptors"], seed + 51)))
+    la_b, m0_b, ms_b = base["log_assignment"][0], base["matches0"][0], base["matching_scores0"][0]
+    sc = la_b[:-1, :-1]
+    t2r = sc.topk(2, dim=1).values
+    t2c = sc.topk(2, dim=0).values
+    out = {
+        "la_threads": float((one["log_assignment"][0] - la_b).abs().max()),
+        "ms_threads": float((one["matching_scores0"][0] - ms_b).abs().max()),
+        "flips_threads": int((one["matches0"][0] != m0_b).sum()),
+        "la_perm": 0.0, "ms_perm": 0.0, "ref_perm": 0.0, "flips_perm": 0,
+        "la_f64": float((la_b.double() - r64["log_assignment"][0]).abs().max()),
+        "ms_f64": float((ms_b.double() - r64["matching_scores0"][0]).abs().max()),
+        "ref_f64": float((base["ref_descriptors0"].double() - r64["ref_descriptors0"]).abs().max()),
+        "flips_f64": int((r64["matches0"][0] != m0_b).sum()),
+        "la_cond": float((rc["log_assignment"][0] - la_b).abs().max()), "ms_cond": float((rc["matching_scores0"][0] - ms_b).abs().max()),
+        "flips_cond": int((rc["matches0"][0] != m0_b).sum()), "cond_eps": COND_EPS,
+        "la_absmax": float(la_b.abs().max()),
+        "min_row_gap": float((t2r[:, 0] - t2r[:, 1]).min()),
+        "min_col_gap": float((t2c[0] - t2c[1]).min()),
+        "matches": int((m0_b > -1).sum()),
+    }
+    for j in range(n_perm):
+        p0, p1 = torch.from_numpy(_perm(seed + 2 * j, n)), torch.from_numpy(_perm(seed + 2 * j + 1, m))
+        g0 = dict(f0, sparse_positions=f0["sparse_positions"][:, p0], sparse_descriptors=f0["sparse_descriptors"][:, p0])
+        g1 = dict(f1, sparse_positions=f1["sparse_positions"][:, p1], sparse_descriptors=f1["sparse_descriptors"][:, p1])
+        with torch.no_grad():
+            pr = lg(g0, g1)
+        inv0, inv1 = torch.empty_like(p0), torch.empty_like(p1)
+        inv0[p0] = torch.arange(n)
+        inv1[p1] = torch.arange(m)
+        # un-permute: row i of the permuted run is keypoint p0[i]; the dustbin row / column stays last
+        r0 = torch.cat([inv0, torch.tensor([n])])
+        r1 = torch.cat([inv1, torch.tensor([m])])
+        la_p = pr["log_assignment"][0][r0][:, r1]
+        m0_p = pr["matches0"][0][inv0]
+        m0_p = torch.where(m0_p > -1, p1[m0_p.clamp(min=0)], m0_p)
+        out["la_perm"] = max(out["la_perm"], float((la_p - la_b).abs().max()))
+        out["ms_perm"] = max(out["ms_perm"], float((pr["matching_scores0"][0][inv0] - ms_b).abs().max()))
+        out["ref_perm"] = max(out["ref_perm"], float((pr["ref_descriptors0"][0, 0][inv0] - base["ref_descriptors0"][0, 0]).abs().max()))
+        out["flips_perm"] = max(out["flips_perm"], int((m0_b != m0_p).sum()))
+    return out, r64
+
+
+def gen_lgcal():
+    out, cases, noise = {}, [], {}
+    for c in LGCAL_CASES:
+        cfg = model_cfg(c["event_type"], c["image_type"], c["matcher"], c["ce"], 1024,
+                        lg_input_dim=(128 if c["image_type"] == "silk" else 256))
+        model, keys = build_eim(cfg, c["wseed"])
+        sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.twin_overrides(sd).items()}, strict=False)
+        ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"])
+        img = synth.synth_image(c["iseed"], c["B"])
+        ev = synth.twin_events(ev, img)
+        for k_, v_ in calibrate(model, ev, mask, img).items():
+            out[f"{c['name']}.override.{k_}"] = v_
+        lg = model.matcher.matcher
+        with torch.no_grad():
+            ef = model.event_extractor(torch.from_numpy(ev), torch.from_numpy(mask))
+            imf = model.image_extractor(torch.from_numpy(img.copy()), None)
+            r = lg(_one(ef, 0), _one(imf, 0))
+        x = np.concatenate([r["ref_descriptors0"][0, 0].numpy(), r["ref_descriptors1"][0, 0].numpy()], 0)
+        lsd = {k: v.numpy().copy() for k, v in lg.state_dict().items()}
+        over, scale = synth.lightglue_calibration(lsd, x, temperature=LG_TEMPERATURE)
+        lg.load_state_dict({k: torch.from_numpy(v) for k, v in over.items()}, strict=False)
+        for k_, v_ in over.items():
+            if "final_proj" not in k_:  # final_proj.{weight,bias} are the synthesised ones * float32(lgscale): a rule, not data
+                out[f"{c['name']}.override.matcher.matcher.{k_}"] = v_
+        out[f"{c['name']}.lgscale"] = np.array([scale], np.float32)
+        with torch.no_grad():
+            ef, imf, m = model(torch.from_numpy(ev), torch.from_numpy(img.copy()), torch.from_numpy(mask))
+        feats_summary(f"{c['name']}.ev", ef, out)
+        feats_summary(f"{c['name']}.im", imf, out)
+        match_summary(f"{c['name']}.m", m, out)
+        out[f"{c['name']}.m.la_probe2"] = torch.stack([x_[0, ::31, ::29] for x_ in m["log_assignment"]]).numpy()
+        for b in range(c["B"]):
+            nf, r64 = lg_noise_floor(lg, _one(ef, b), _one(imf, b), 900 + b)
+            noise[f"{c['name']}.{b}"] = nf
+            out[f"{c['name']}.m.la_probe2_f64.{b}"] = r64["log_assignment"][0, ::31, ::29].numpy()  # float64
+            out[f"{c['name']}.m.matching_scores0_f64.{b}"] = r64["matching_scores0"][0].numpy()
+            v = m["matching_scores0"][b].reshape(-1)[m["matches0"][b].reshape(-1) > -1].numpy()
+            print(c["name"], b, "matches", nf["matches"], "scores q10/50/90", np.quantile(v, [0.1, 0.5, 0.9]).round(3), nf)
+        c = dict(c)
+        c["cfg"], c["state_keys"], c["temperature"] = cfg, keys, LG_TEMPERATURE
+        cases.append(c)
+    # noise floor of the fixtures that already exist (lg.npz stand-alone cases, e2e.npz LightGlue cases): same models, same inputs
+    for c in LG_CASES:
+        lg = LightGlue(_ref_stubs.to_attr({"input_dim": c["input_dim"], "ratio_thresh": False, "distance_thresh": False}))
+        load_synth_weights(lg, c["wseed"])
+        lg.eval()
+        d0, d1, k0, k1 = lg_inputs(c)
+        size = torch.tensor([260, 346])
+        f0 = {"sparse_descriptors": torch.from_numpy(d0)[None], "sparse_positions": torch.from_numpy(k0)[None], "image_size": [size]}
+        f1 = {"sparse_descriptors": torch.from_numpy(d1)[None], "sparse_positions": torch.from_numpy(k1)[None], "image_size": [size]}
+        noise[f"lg.{c['name']}"], r64 = lg_noise_floor(lg, f0, f1, 910)
+        la64 = r64["log_assignment"][0]
+        out[f"lg.{c['name']}.la_f64"] = (la64 if c["n"] <= 300 else la64[::37, ::41]).numpy()  # same probes as lg.npz, float64
+        print("lg." + c["name"], noise[f"lg.{c['name']}"])
+    for c in E2E_CASES:
+        if c["matcher"] != "LightGlue":
+            continue
+        cfg = model_cfg(c["event_type"], c["image_type"], c["matcher"], c["ce"], 1024,
+                        lg_input_dim=(128 if c["image_type"] == "silk" else 256))
+        model, _ = build_eim(cfg, c["wseed"])
+        ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"])
+        img = synth.synth_image(c["iseed"], c["B"])
+        calibrate(model, ev, mask, img)
+        with torch.no_grad():
+            ef = model.event_extractor(torch.from_numpy(ev), torch.from_numpy(mask))
+            imf = model.image_extractor(torch.from_numpy(img.copy()), None)
+        noise[f"e2e.{c['name']}"], r64 = lg_noise_floor(model.matcher.matcher, _one(ef, 0), _one(imf, 0), 920)
+        out[f"e2e.{c['name']}.la_probe_f64"] = r64["log_assignment"][0, ::97, ::89][:8, :8].numpy()
+        print("e2e." + c["name"], noise[f"e2e.{c['name']}"])
+    out["meta"] = meta(cases=cases, noise=noise)
+    save("lgcal.npz", **out)
+
+
+GROUPS["lgcal"] = gen_lgcal
 
 
 # =========================================================================================

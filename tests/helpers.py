@@ -55,6 +55,54 @@ def state_dict_for(case_meta, golden=None, seed_key="wseed"):
     return sd
 
 
+def twin_state_dict_for(case_meta, golden):
+    """"Same scene" fixtures (tests/golden/lgcal.npz): name-synthesised weights, then the twin RULE (synth.twin_overrides),
+    then the fixture's stored calibration vectors; LightGlue's final_proj.{weight,bias} are the synthesised ones * float32(lgscale)."""
+    name = case_meta["name"]
+    sd = synth.synth_state_dict(list(case_meta["state_keys"].items()), case_meta["wseed"])
+    sd.update(synth.twin_overrides(sd))
+    sd.update(golden.overrides(name))
+    for leaf in ("weight", "bias"):
+        key = "matcher.matcher.log_assignment.8.final_proj." + leaf
+        sd[key] = (sd[key] * golden[f"{name}.lgscale"][0]).astype(np.float32)
+    return sd
+
+
+def twin_inputs(c):
+    ev, mask = synth.synth_events(c["iseed"], c["B"], c["ce"])
+    img = synth.synth_image(c["iseed"], c["B"])
+    return synth.twin_events(ev, img), mask, img
+
+
+_LG_NOISE = None
+
+
+def lg_noise(tag):
+    """The reference's OWN float noise on this fixture (tests/golden/gen_golden.py::lg_noise_floor: same model, same inputs,
+    keypoints permuted / 1 torch thread): {'la_perm', 'ms_perm', 'ref_perm', 'flips_perm', 'la_absmax', ...}."""
+    global _LG_NOISE
+    if _LG_NOISE is None:
+        z = np.load(os.path.join(GOLDEN, "lgcal.npz"))
+        _LG_NOISE = json.loads(bytes(z["meta"]).decode())["noise"]
+    return _LG_NOISE[tag]
+
+
+LA_NOISE_FACTOR = 2.0
+
+
+def la_bound(tag):
+    """log_assignment bound = LA_NOISE_FACTOR x what the reference differs from ITSELF by when only its summation order changes
+    (1.9e-4 .. 4.4e-4 on these fixtures, so the north_star's 1e-4 is below the reference's own reproducibility)."""
+    return max(1e-4, LA_NOISE_FACTOR * max(lg_noise(tag)["la_perm"], lg_noise(tag)["la_threads"]))
+
+
+def la_bound_e2e(tag):
+    """End-to-end comparisons against the reference: its extractors' floats differ from ours by ~1e-6 (conv accumulation order),
+    and log_assignment is ill-conditioned in its inputs -- the REFERENCE moves by `la_cond` (0.7e-3 .. 2.8e-3) when its input
+    descriptors are jittered by +-2e-6 (gen_golden.py::lg_noise_floor).  Bound = same-input bound + that measured response."""
+    return la_bound(tag) + lg_noise(tag)["la_cond"]
+
+
 def sub_dict(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
@@ -223,3 +271,35 @@ def close_and_record(tag, got, exp, atol, rtol=0.0):
 
 def recorded_errors():
     return _ERRORS
+
+
+_FLIPS = {}
+
+
+def record_flips(tag, got, exp, la=None):
+    """Counts match-assignment differences (`got` vs `exp`, -1 = unmatched) under `tag` and, given the checker's
+    log_assignment [n+1,m+1], the decision margin of every flipped row (best minus second best of its row and of the two
+    candidate columns).  Target 0; the table goes to gpurun_out/parity_errors.json next to the float maxima."""
+    got, exp = np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)
+    assert got.shape == exp.shape, (tag, got.shape, exp.shape)
+    bad = np.nonzero(got != exp)[0]
+    rec = _FLIPS.setdefault(tag, {"compared": 0, "matched": 0, "flips": 0, "margins": []})
+    rec["compared"] += int(got.size)
+    rec["matched"] += int((exp > -1).sum())
+    rec["flips"] += int(bad.size)
+    if la is not None:
+        sc = np.asarray(la)[:-1, :-1]
+        for i in bad[:16]:
+            row = np.sort(sc[i])[::-1]
+            gaps = [float(row[0] - row[1])] if row.size > 1 else []
+            for j in (got[i], exp[i]):
+                if j >= 0:
+                    col = np.sort(sc[:, j])[::-1]
+                    if col.size > 1:
+                        gaps.append(float(col[0] - col[1]))
+            rec["margins"].append({"row": int(i), "got": int(got[i]), "exp": int(exp[i]), "min_gap": min(gaps) if gaps else None})
+    return int(bad.size)
+
+
+def recorded_flips():
+    return _FLIPS

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import close_and_record, Golden, load_pkg, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth
+from helpers import (close_and_record, Golden, la_bound, la_bound_e2e, lg_noise, load_pkg, mnn_inputs, record_flips, score_map, split,
+                     state_dict_for, sub_dict, synth, twin_inputs, twin_state_dict_for)
 
 pytestmark = pytest.mark.gpu
 pkg = load_pkg()
@@ -553,14 +554,16 @@ def test_properties_at_bench_batch():
 
 # ------------------------------------------------------------------ LightGlue
 LG = Golden("lg")
-# Float tolerances of the LightGlue path, next to what is MEASURED (helpers.close_and_record prints the maxima at the end
-# of the session; profiles/r03_parity_errors.json keeps the round's table):
-#   matching_scores, ref_descriptors, matched keypoints: the north_star's 1e-4 absolute (measured <= 2.1e-5 / 1.1e-5)
-#   log_assignment: does NOT meet 1e-4.  Measured maximum 3.8e-4 absolute (on entries of magnitude 5..74, not proportional to
-#   the magnitude: 1.7e-4 at |la| = 5.3, 3.8e-4 at 50.7) after nine transformer layers summed in another order (flash-style
-#   attention, fused projections) than the reference's BLAS; the CPU oracle differs from the reference by as much
-#   (tests/test_oracle_golden.py).  Bound used: 5e-4 absolute, no relative term.  Match ASSIGNMENTS are compared exactly.
-LA_ATOL, LA_RTOL = 5e-4, 0.0
+LGCAL = Golden("lgcal")
+# Float tolerances of the LightGlue path, next to what is MEASURED (helpers.close_and_record / record_flips print the maxima and
+# the assignment-flip counts at the end of the session; profiles/r04_parity_errors.json keeps the round's table):
+#   matching_scores, ref_descriptors, matched keypoints: the north_star's 1e-4 absolute.
+#   log_assignment: the reference does not reproduce ITSELF to 1e-4 -- with its keypoints permuted it moves by 1.8e-4 .. 4.3e-4,
+#   and it is 1.7e-4 .. 3.7e-4 away from its own float64 evaluation (tests/golden/lgcal.npz `noise`, generated by
+#   gen_golden.py::lg_noise_floor).  Bound = helpers.la_bound(fixture) = 2 x that floor for comparisons on identical inputs;
+#   end-to-end comparisons against the reference add the reference's measured response to +-2e-6 of input-descriptor noise
+#   (helpers.la_bound_e2e).  The float64 results are stored too, so the kernels are also held to the same bound against the
+#   exact answer.  Match ASSIGNMENTS are compared exactly and every comparison's flip count is recorded (target 0).
 
 
 def _lg_model(c):
@@ -584,18 +587,21 @@ def test_lightglue_vs_golden(oracle, name):
     f1 = {"sparse_descriptors": _t(d1)[None], "sparse_positions": _t(k1)[None], "image_size": [size]}
     r = lg(f0, f1)
     # bit-exact match assignments against the reference
-    assert np.array_equal(_np(r["matches0"]), LG[f"{name}.matches0"])
-    assert np.array_equal(_np(r["matches1"]), LG[f"{name}.matches1"])
+    assert record_flips(f"lg.{name}.matches0 vs reference", _np(r["matches0"]), LG[f"{name}.matches0"]) == 0
+    assert record_flips(f"lg.{name}.matches1 vs reference", _np(r["matches1"]), LG[f"{name}.matches1"]) == 0
     close_and_record(f"lg.{name}.matching_scores0 vs reference", _np(r["matching_scores0"]), LG[f"{name}.mscores0"], atol=FTOL)
     close_and_record(f"lg.{name}.matching_scores1 vs reference", _np(r["matching_scores1"]), LG[f"{name}.mscores1"], atol=FTOL)
     assert np.array_equal(_np(r["matched_kpts0"]), LG[f"{name}.matched_kpts0"])
     assert np.array_equal(_np(r["matched_kpts1"]), LG[f"{name}.matched_kpts1"])
     la = _np(r["log_assignment"])
     assert la.shape == (1, c["n"] + 1, c["m"] + 1)
+    bound = la_bound(f"lg.{name}")
     if f"{name}.la" in LG:
-        close_and_record(f"lg.{name}.log_assignment vs reference", la, LG[f"{name}.la"], atol=LA_ATOL, rtol=LA_RTOL)
+        close_and_record(f"lg.{name}.log_assignment vs reference", la, LG[f"{name}.la"], atol=bound)
+        close_and_record(f"lg.{name}.log_assignment vs reference in float64", la[0], LGCAL[f"lg.{name}.la_f64"], atol=bound)
     else:
-        close_and_record(f"lg.{name}.log_assignment vs reference", la[0, ::37, ::41], LG[f"{name}.la_probe"], atol=LA_ATOL, rtol=LA_RTOL)
+        close_and_record(f"lg.{name}.log_assignment vs reference", la[0, ::37, ::41], LG[f"{name}.la_probe"], atol=bound)
+        close_and_record(f"lg.{name}.log_assignment vs reference in float64", la[0, ::37, ::41], LGCAL[f"lg.{name}.la_f64"], atol=bound)
     sn = max(1, c["n"] // 16)
     ref = _np(r["ref_descriptors0"])
     assert ref.shape == (1, 1, c["n"], 256)
@@ -603,8 +609,8 @@ def test_lightglue_vs_golden(oracle, name):
     assert tuple(r["prune0"].shape) == (1, c["n"]) and float(r["prune0"][0, 0]) == 9.0
     if name != "full":
         exp = oracle.lightglue(sd, k0, d0, k1, d1)
-        assert np.array_equal(_np(r["matches0"])[0], exp["matches0"])
-        close_and_record(f"lg.{name}.log_assignment vs oracle", la[0], exp["log_assignment"], atol=LA_ATOL, rtol=LA_RTOL)
+        assert record_flips(f"lg.{name}.matches0 vs oracle", _np(r["matches0"])[0], exp["matches0"], exp["log_assignment"]) == 0
+        close_and_record(f"lg.{name}.log_assignment vs oracle", la[0], exp["log_assignment"], atol=bound)
         close_and_record(f"lg.{name}.ref_descriptors0 vs oracle", ref[0, 0], exp["ref_descriptors0"], atol=FTOL)
 
 
@@ -624,7 +630,7 @@ def test_e2e_lightglue(oracle, name):
     for key in ("matches0", "matches1"):
         exp = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
         for b in range(c["B"]):
-            assert np.array_equal(_np(m[key][b])[0], exp[b]), key
+            assert record_flips(f"e2e.{name}.{key} vs reference", _np(m[key][b])[0], exp[b]) == 0, key
     for key in ("matched_kpts0", "matched_kpts1"):
         exp = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
         for b in range(c["B"]):
@@ -637,7 +643,60 @@ def test_e2e_lightglue(oracle, name):
     for b in range(c["B"]):
         la = _np(m["log_assignment"][b])
         assert list(la.shape) == E2E[f"{name}.m.la_shapes"][b].tolist()
-        close_and_record(f"e2e.{name}.log_assignment vs reference", la[0, ::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b], atol=LA_ATOL, rtol=LA_RTOL)
+        close_and_record(f"e2e.{name}.log_assignment vs reference", la[0, ::97, ::89][:8, :8], E2E[f"{name}.m.la_probe"][b],
+                         atol=la_bound_e2e(f"e2e.{name}"))
+
+
+@pytest.mark.parametrize("name", list(LGCAL.cases))
+def test_e2e_lightglue_same_scene(oracle, name):
+    """Round 4: EIM.forward + LightGlue in a NON-degenerate regime ("same scene" pairs, calibrated assignment head; fixtures
+    generated from the reference, tests/golden/lgcal.npz): 750-790 matches per pair, matching_scores spread over 0.003 .. 0.95.
+    Extractors bit-equal to the oracle; assignments equal to the reference AND to the oracle (flip counts recorded);
+    matching_scores to 1e-4; log_assignment to the noise-floor-derived bounds, also against the reference in float64."""
+    c = LGCAL.cases[name]
+    cfg = pkg.configs.to_attr(c["cfg"])
+    model = pkg.EIM(cfg, device=DEV)
+    sd = twin_state_dict_for(c, LGCAL)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("descriptor_scale_factor") for k in missing), (missing, unexpected)
+    model.eval()
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = False
+    ev, mask, img = twin_inputs(c)
+    ef, imf, m = model(_t(ev), _t(img), _t(mask))
+    oef, oimf = _oracle_feats(oracle, c, sd, ev, mask, img)
+    _assert_feats_equal_oracle(ef, oef)
+    _assert_feats_equal_oracle(imf, oimf)
+    for b in range(c["B"]):
+        nf = lg_noise(f"{name}.{b}")
+        o = oracle.lightglue(sub_dict(sd, "matcher.matcher."), oef["sparse_positions"][b], oef["sparse_descriptors"][b],
+                             oimf["sparse_positions"][b], oimf["sparse_descriptors"][b])
+        for key in ("matches0", "matches1"):
+            exp = split(LGCAL[f"{name}.m.{key}"], LGCAL[f"{name}.m.{key}.lens"])[b]
+            got = _np(m[key][b])[0]
+            assert record_flips(f"lgcal.{name}.{key} vs reference", got, exp) == 0, f"pair {b}: {key}"
+            la_o = o["log_assignment"] if key == "matches0" else o["log_assignment"].T
+            assert record_flips(f"lgcal.{name}.{key} vs oracle", got, np.asarray(o[key]).reshape(-1), la_o) == 0, f"pair {b}: {key}"
+        assert int((_np(m["matches0"][b]) > -1).sum()) == nf["matches"] >= 100
+        for key in ("matching_scores0", "matching_scores1"):
+            exp = split(LGCAL[f"{name}.m.{key}"], LGCAL[f"{name}.m.{key}.lens"])[b]
+            close_and_record(f"lgcal.{name}.{key} vs reference", _np(m[key][b])[0], exp, atol=FTOL)
+            close_and_record(f"lgcal.{name}.{key} vs oracle", _np(m[key][b])[0], np.asarray(o[key]).reshape(-1), atol=FTOL)
+        close_and_record(f"lgcal.{name}.matching_scores0 vs reference in float64", _np(m["matching_scores0"][b])[0],
+                         LGCAL[f"{name}.m.matching_scores0_f64.{b}"], atol=FTOL)
+        for key in ("matched_kpts0", "matched_kpts1"):
+            exp = split(LGCAL[f"{name}.m.{key}"], LGCAL[f"{name}.m.{key}.lens"])[b]
+            assert tuple(m[key][b].shape) == exp.shape
+            np.testing.assert_allclose(_np(m[key][b]), exp, atol=FTOL)
+        la = _np(m["log_assignment"][b])
+        assert list(la.shape) == LGCAL[f"{name}.m.la_shapes"][b].tolist()
+        # identical inputs (the GPU extractors are bit-equal to the oracle's): 2 x the reference's own noise floor
+        close_and_record(f"lgcal.{name}.log_assignment vs oracle", la[0], o["log_assignment"], atol=la_bound(f"{name}.{b}"))
+        # end to end against the reference (extractor floats differ by ~1e-6 upstream): + its measured input sensitivity
+        close_and_record(f"lgcal.{name}.log_assignment vs reference", la[0, ::31, ::29], LGCAL[f"{name}.m.la_probe2"][b],
+                         atol=la_bound_e2e(f"{name}.{b}"))
+        close_and_record(f"lgcal.{name}.log_assignment vs reference in float64", la[0, ::31, ::29], LGCAL[f"{name}.m.la_probe2_f64.{b}"],
+                         atol=la_bound_e2e(f"{name}.{b}"))
 
 
 def test_detect_generic_path_dense_and_negative(oracle):
@@ -892,7 +951,7 @@ def test_lightglue_weight_folding_is_equivalent():
     lg.refresh()
     b = lg(f0, f1)
     assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
-    np.testing.assert_allclose(_np(a["log_assignment"]), _np(b["log_assignment"]), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(_np(a["log_assignment"]), _np(b["log_assignment"]), atol=la_bound("lg.d256"), rtol=0)
     np.testing.assert_allclose(_np(a["ref_descriptors0"]), _np(b["ref_descriptors0"]), atol=2e-5, rtol=1e-5)
 
 
@@ -962,7 +1021,7 @@ def test_ragged_keypoint_counts_in_a_batch(oracle, matcher):
             r = oracle.lightglue(sub_dict(sdn, "matcher.matcher."), k0, d0, k1, d1, size0=(H, W), size1=(H, W))
             assert np.array_equal(_np(m["matches0"][b])[0], r["matches0"])
             np.testing.assert_allclose(_np(m["matching_scores0"][b])[0], r["matching_scores0"], atol=FTOL)
-            np.testing.assert_allclose(_np(m["log_assignment"][b])[0], r["log_assignment"], atol=2e-4, rtol=1e-4)
+            np.testing.assert_allclose(_np(m["log_assignment"][b])[0], r["log_assignment"], atol=la_bound("lg.d256"), rtol=0)
             cols = 2
         mk0, mk1 = oracle.matched_kpts(k0, k1, r["matches0"], cols)
         assert np.array_equal(_np(m["matched_kpts0"][b]), mk0) and np.array_equal(_np(m["matched_kpts1"][b]), mk1)
@@ -1006,7 +1065,7 @@ def test_unfrozen_matcher_vs_reference_golden(name):
     assert np.array_equal(_np(r["matches1"]), TRAIN[f"{name}.matches1"])
     np.testing.assert_allclose(_np(r["matching_scores0"]), TRAIN[f"{name}.matching_scores0"], atol=FTOL)
     np.testing.assert_allclose(_np(r["matching_scores1"]), TRAIN[f"{name}.matching_scores1"], atol=FTOL)
-    np.testing.assert_allclose(_np(r["log_assignment"]), TRAIN[f"{name}.log_assignment"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(_np(r["log_assignment"]), TRAIN[f"{name}.log_assignment"], atol=la_bound("lg.d256"), rtol=0)
     for b in range(B):
         np.testing.assert_allclose(_np(r["matched_kpts0"][b]), TRAIN[f"{name}.matched_kpts0.{b}"], atol=1e-6)
         np.testing.assert_allclose(_np(r["matched_kpts1"][b]), TRAIN[f"{name}.matched_kpts1.{b}"], atol=1e-6)
@@ -1075,7 +1134,7 @@ def test_unfrozen_matcher_random_padding(oracle, name):
         o = oracle.lightglue_stacked(sd, P0, D0, P1, D1, (260, 346), (260, 346), training=True)
         assert np.array_equal(_np(r["matches0"]), o["matches0"]) and np.array_equal(_np(r["matches1"]), o["matches1"])
         np.testing.assert_allclose(_np(r["matching_scores0"]), o["matching_scores0"], atol=FTOL)
-        np.testing.assert_allclose(_np(r["log_assignment"]), o["log_assignment"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(_np(r["log_assignment"]), o["log_assignment"], atol=la_bound("lg.d256"), rtol=0)
         np.testing.assert_allclose(_np(r["ref_descriptors0"]), o["ref_descriptors0"], atol=FTOL, rtol=FTOL)
         np.testing.assert_allclose(_np(r["ref_descriptors1"]), o["ref_descriptors1"], atol=FTOL, rtol=FTOL)
         for b in range(B):

@@ -16,13 +16,14 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, close_and_record, load_pkg, r2_mnn_inputs, rep_inputs, sub_dict, synth, tie_map
+from helpers import GOLDEN, close_and_record, la_bound, load_pkg, r2_mnn_inputs, record_flips, rep_inputs, sub_dict, synth, tie_map
 
 pytestmark = pytest.mark.gpu
 pkg = load_pkg()
 DEV = "cuda:0"
 FTOL = 1e-4
-LA_ATOL, LA_RTOL = 5e-4, 0.0  # log_assignment: see tests/test_gpu_parity.py (measured 3.8e-4 at most; 1.8e-4 at B=64)
+# log_assignment: bounded by a multiple of the reference's OWN summation-order / rounding noise on the matching fixture
+# (helpers.la_bound, tests/golden/lgcal.npz), not by a hand-picked number
 
 _Z = np.load(os.path.join(GOLDEN, "r2.npz"))
 _META = json.loads(bytes(_Z["meta"]).decode())
@@ -159,15 +160,35 @@ def test_other_geometry_vga_16_bins_vs_oracle(oracle):
     assert 0 < ef["sparse_positions"][0].shape[0] <= 1024 and tuple(ef["score"].shape) == (1, 1, H, W)
 
 
+def _calibrate_lightglue(model, sd, ef, imf):
+    """synth.lightglue_calibration from the final descriptors of pair 0 (the same rule as tests/golden/lgcal.npz and bench.py)"""
+    one = lambda f: {"sparse_positions": f["sparse_positions"][0][None], "sparse_descriptors": f["sparse_descriptors"][0][None],  # noqa: E731
+                     "image_size": [f["image_size"][0]]}
+    r = model.matcher.matcher(one(ef), one(imf))
+    x = np.concatenate([_np(r["ref_descriptors0"])[0, 0], _np(r["ref_descriptors1"])[0, 0]], 0)
+    over, _ = synth.lightglue_calibration(sd, x, prefix="matcher.matcher.")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in over.items()}, strict=False)
+    sd.update(over)
+
+
 def test_baseline_batch_sampled_pairs_vs_oracle_lightglue(oracle):
-    """configs[3]: B=64 SP+LightGlue; extractor outputs bit-equal, match assignments equal, floats to 1e-4."""
+    """configs[3]: B=64 SP+LightGlue on "same scene" pairs with a calibrated assignment head (hundreds of confident matches per
+    pair, synth.twin_overrides / lightglue_calibration): extractor outputs bit-equal, match assignments equal (flips are counted
+    and reported; target 0), matching scores to 1e-4, log_assignment to a multiple of the reference's own noise floor."""
     B = 64
     cfg, model, sd = _bench_like_model("SP_LG")
+    tw = synth.twin_overrides(sd)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in tw.items()}, strict=False)
+    sd.update(tw)
     ev, mask = synth.synth_events(10_000, B, 5)
     img = synth.synth_image(10_000, B)
+    ev = synth.twin_events(ev, img)
     ev_t, mask_t, img_t = _t(ev), _t(mask), _t(img)
     _calibrate(model, sd, ev_t, img_t, mask_t)
+    ef, imf, _ = model(ev_t, img_t.clone(), mask_t)
+    _calibrate_lightglue(model, sd, ef, imf)
     ef, imf, m = model(ev_t, img_t.clone(), mask_t)
+    bound = la_bound("sp_lg_twin.0")
     for b in (0, B // 2, B - 1):
         oe, oi = _oracle_pair(oracle, cfg, sd, ev, mask, img, b)
         for got, exp in ((ef, oe), (imf, oi)):
@@ -176,19 +197,23 @@ def test_baseline_batch_sampled_pairs_vs_oracle_lightglue(oracle):
         r = oracle.lightglue(sub_dict(sd, "matcher.matcher."), oe["sparse_positions"][0], oe["sparse_descriptors"][0],
                              oi["sparse_positions"][0], oi["sparse_descriptors"][0])
         g0, e0 = _np(m["matches0"][b])[0], np.asarray(r["matches0"]).reshape(-1)
-        if not np.array_equal(g0, e0):
+        assert int((e0 > -1).sum()) >= 100, f"pair {b}: the calibrated workload should match hundreds of keypoints, got {int((e0 > -1).sum())}"
+        nflip = record_flips("B64 sp_lg (same scene) matches0 vs oracle", g0, e0, r["log_assignment"])
+        if nflip:
             # flash-style attention sums in a different order than the oracle: an assignment may flip only where the
-            # oracle's own decision margin is inside the 1e-4 float tolerance
+            # oracle's own decision margin is inside the float noise
             la = r["log_assignment"]
             bad = np.nonzero(g0 != e0)[0]
             assert len(bad) <= 2, f"pair {b}: {len(bad)} assignments differ"
             for i in bad:
                 row = np.sort(la[i, :-1])[::-1]
-                assert row[0] - row[1] < LA_ATOL + LA_RTOL * abs(row[0]), f"pair {b}: row {i} differs with margin {row[0] - row[1]}"
+                assert row[0] - row[1] < bound, f"pair {b}: row {i} differs with margin {row[0] - row[1]}"
         gla = _np(m["log_assignment"][b])[0] if m["log_assignment"][b] is not None else None
         if gla is not None:
-            close_and_record("B64 sp_lg log_assignment vs oracle", gla[::53, ::47], r["log_assignment"][::53, ::47], atol=LA_ATOL, rtol=LA_RTOL)
-        close_and_record("B64 sp_lg matching_scores0 vs oracle", _np(m["matching_scores0"][b])[0], np.asarray(r["matching_scores0"]).reshape(-1), atol=1e-4)
+            close_and_record("B64 sp_lg (same scene) log_assignment vs oracle", gla[::53, ::47], r["log_assignment"][::53, ::47], atol=bound)
+        es = np.asarray(r["matching_scores0"]).reshape(-1)
+        assert es.max() > 0.9 and ((es > 0.1) & (es < 0.9)).sum() >= 100
+        close_and_record("B64 sp_lg (same scene) matching_scores0 vs oracle", _np(m["matching_scores0"][b])[0], es, atol=1e-4)
 
 
 # ------------------------------------------------------------------ r2 fixtures: tie maps with survivors
