@@ -98,8 +98,9 @@ SIGNATURES = {
     "einx_gather_matches": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     "einx_events_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "einx_voxel_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, ctypes.c_int64]),
     "einx_voxel_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                c_void_p]),
+                                c_size_t, c_void_p]),
     "einx_events_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "einx_metrics_ws_bytes": (c_size_t, [ctypes.POINTER(MetricParams)]),
     "einx_pair_metrics": (c_int, [ctypes.POINTER(MetricParams)] + [c_void_p] * 13),

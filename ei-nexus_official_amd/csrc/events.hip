@@ -6,13 +6,28 @@
 // datasets/visualize.py:23-50 (draw_events_accumulation_image) with the `> 0` mask of
 // test_events-image_same-time.py:137.
 //
-// Scatter-add (the reference's put_(accumulate=True)): the voxel grid accumulates in LDS tiles (fp32 LDS atomics,
-// exact up to summation order), the count image uses integer global atomics and is bit-exact.
+// Scatter-add (round 4: DETERMINISTIC).  The reference's eight put_(accumulate=True) calls add, per voxel, the contributions
+// of corner (dx,dy,dt) = (0,0,0) of all events in event order, then corner (0,0,1) ... (1,1,1) -- torch's serial path (and the
+// order oracle/einx_oracle.c::orc_voxel_grid restates; with >= 32768 events and several threads torch itself switches to
+// unordered atomic adds).  The kernels below reproduce exactly that order without any float atomic: every voxel is owned
+// by ONE wave, which walks its events in order and resolves the collisions inside a 64-event batch in lane order.  Two runs
+// are bit-identical and `raw` is bit-equal to the oracle at every size.  The count image uses integer atomics (exact).
 #include <mutex>
 
 #include "einx_common.h"
 
 namespace {
+
+// timing-only ablations (wrong results; never in the shipped library): -DEINX_TIMING_ONLY_BUILD -DVOX_EXP=1..4
+#if defined(EINX_TIMING_ONLY_BUILD) && defined(VOX_EXP)
+#define VOX_EXP_ON(k) (VOX_EXP == (k))
+#else
+#define VOX_EXP_ON(k) 0
+#endif
+constexpr int VOX_BANDS = 16;   // column bands = waves of a scatter workgroup (each voxel column has ONE owner wave)
+constexpr int VOX_SEGS = 16;    // event segments = waves of a scatter workgroup (each wave sweeps one contiguous share)
+constexpr int VOX_TAGS = 128;   // per-wave collision tags
+constexpr int VOX_CACHE = 4;    // 64-event chunks of a band list kept in registers over the eight corners
 
 // All samples of a batch go through ONE launch per stage: blockIdx.y is the sample, the device copy of the
 // offsets array (one small host-to-device copy per call) delimits its events.
@@ -23,87 +38,284 @@ struct VoxArgs {
   const float* p;
   const int64_t* offs;  // device [B+1]
   int bins, H, W;
-  float* grid;  // [B,bins,H,W]
+  int rows, nslab, bw;  // rows per slab, slabs per sample, columns per band
+  float* grid;          // [B,bins,H,W]
+  float4* rec;          // [N] (xf, yf, t_norm, value) per event
+  uint32_t* keys;       // [N] (y0 + 2) << 16 | (x0 + 2), both clamped to [0, 65535]: what the sweep reads instead of x and y
+  int32_t* counts;      // [B][nslab][VOX_BANDS][VOX_SEGS] list lengths
+  uint32_t* lists;      // [4 N] event indices (in-sample): per slab, per band, per segment, in event order
+  double* part;         // [B][nslab][3] statistics of the non-zero voxels of a slab
 };
 
-// Scatter through LDS tiles instead of global float atomics: scattered `global_atomic_add_f32` (64 lanes in 64
-// different rows) runs at ~0.08 TB/s on this chip, which made the scatter 80 % of the call.  A workgroup owns
-// `rows` image rows of one sample for all time bins (bins*rows*W floats in LDS), sweeps that sample's events
-// (reading y first and skipping events that cannot touch its rows), accumulates with LDS atomics, then writes
-// its slab with plain coalesced stores -- no memset of the grid, and the per-sample statistics of the non-zero
-// voxels come from the slab while it is still in LDS.
-__global__ __launch_bounds__(1024) void voxel_tile_kernel(const VoxArgs a, int rows, double* stats_all) {
-  extern __shared__ float tile[];  // [bins][rows][W]
-  __shared__ double sh[3][16];
-  __shared__ int wqueue[16 * 128];  // per-wave queue of event indices that touch this slab
-  const int b = blockIdx.y;
-  const int r0 = blockIdx.x * rows;
-  const int nr = min(rows, a.H - r0);
-  const int tid = threadIdx.x;
-  const int slab = a.bins * rows * a.W;
-  for (int i = tid; i < slab; i += 1024) tile[i] = 0.0f;
-  __syncthreads();
+__device__ __forceinline__ uint32_t vox_key(int x0, int y0) {
+  const int xc = min(max(x0, -2), 65533) + 2, yc = min(max(y0, -2), 65533) + 2;
+  return ((uint32_t)yc << 16) | (uint32_t)xc;
+}
+__device__ __forceinline__ int vox_key_x(uint32_t k) { return (int)(k & 0xFFFFu) - 2; }
+__device__ __forceinline__ int vox_key_y(uint32_t k) { return (int)(k >> 16) - 2; }
+// events per segment: a sample's events are split into VOX_SEGS contiguous shares of whole 512-event trips
+__device__ __forceinline__ long long vox_seg(long long n) { return ((n + VOX_SEGS * 512 - 1) / (VOX_SEGS * 512)) * 512; }
+
+// which slabs / bands an event can touch (its rows y0, y0+1 and columns x0, x0+1); the SAME tests size the lists
+// (voxel_prep_kernel) and fill them (voxel_scatter_kernel)
+__device__ __forceinline__ bool vox_hits_slab(int y0, int r0, int nr) { return y0 + 1 >= r0 && y0 < r0 + nr; }
+__device__ __forceinline__ bool vox_hits_band(int x0, int band, int bw, int W) {
+  return (x0 >= 0 && x0 < W && x0 / bw == band) || (x0 + 1 >= 0 && x0 + 1 < W && (x0 + 1) / bw == band);
+}
+
+// Per event: the normalised record (time_normalization in float64 like numpy, then float32 like torch -- one double
+// division per event instead of one per slab that sweeps it), the packed cell key, and the lengths of the
+// (slab, band, segment) lists it will join.  One workgroup per (segment, sample): the histogram lives in LDS (integer
+// atomics: exact) and leaves with plain stores -- no global atomic, no memset of the counts.
+constexpr int VOX_PREP_BINS = 4096;  // nslab * VOX_BANDS that fit the LDS histogram; beyond that: global atomics
+template <bool LDS_HIST>
+__global__ __launch_bounds__(1024) void voxel_prep_kernel(const VoxArgs a) {
+  __shared__ int hist[LDS_HIST ? VOX_PREP_BINS : 1];
+  const int b = blockIdx.y, seg = blockIdx.x;
   const long long o0 = a.offs[b], n = a.offs[b + 1] - o0;
+  const int nb = a.nslab * VOX_BANDS;
+  int32_t* counts = a.counts + (size_t)b * nb * VOX_SEGS;
+  if (LDS_HIST) {
+    for (int j = threadIdx.x; j < nb; j += 1024) hist[j] = 0;
+    __syncthreads();
+  }
   if (n > 0) {
+    const long long sg = vox_seg(n), lo = seg * sg, hi = min(n, lo + sg);
     const double* t = a.t + o0;
     const double t0d = t[0], tld = t[n - 1];
     const double den = (tld - t0d) + 1e-8;
     const float tf0 = (float)(0.0 / den);
     const float tfl = (float)((tld - t0d) / den);
-    // Every lane tests its events on y alone (8 loads in flight); the few that can touch this slab (rows/H of
-    // them) are appended to a per-wave LDS queue and processed 64 at a time with all lanes busy -- without
-    // the queue nearly every wave would run the whole body for every event with one or two active lanes.
-    // No workgroup barrier inside the sweep: the 16 waves run independently.
-    const int lane = tid & 63, wave = tid >> 6;
-    int* queue = wqueue + wave * 128;
-    int qn = 0;  // wave-uniform
-    auto process = [&](long long i) {
-      const float yf = a.y[o0 + i];
-      const int y0 = (int)yf;  // .int() truncates toward zero
-      // time_normalization in float64 (numpy), then float32 (torch) exactly as the reference
+    for (long long i = lo + threadIdx.x; i < hi; i += 1024) {
       const float tf = (float)((t[i] - t0d) / den);
       const float tn = ((float)(a.bins - 1) * (tf - tf0)) / (tfl - tf0);
-      const float xf = a.x[o0 + i];
+      const float xf = a.x[o0 + i], yf = a.y[o0 + i];
       float value = a.p[o0 + i];
       if (value < 1.0f) value = -1.0f;
-      const int x0 = (int)xf, t0 = (int)tn;
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx)
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const int xl = x0 + dx, yl = y0 + dy, tl = t0 + dt;
-            if (xl < a.W && xl >= 0 && yl < r0 + nr && yl >= r0 && yl >= 0 && tl >= 0 && tl < a.bins) {
-              const float w = value * (1.0f - fabsf((float)xl - xf)) * (1.0f - fabsf((float)yl - yf)) * (1.0f - fabsf((float)tl - tn));
-              atomicAdd(&tile[(tl * rows + (yl - r0)) * a.W + xl], w);
-            }
+      a.rec[o0 + i] = make_float4(xf, yf, tn, value);
+      const uint32_t key = vox_key((int)xf, (int)yf);  // .int() truncates toward zero
+      a.keys[o0 + i] = key;
+      const int x0 = vox_key_x(key), y0 = vox_key_y(key);
+      // rows y0, y0+1 lie in at most two neighbouring slabs, columns x0, x0+1 in at most two neighbouring bands
+      const int s_lo = max(0, (y0 < 0 ? -1 : y0 / a.rows)), s_hi = min(a.nslab - 1, (y0 + 1 < 0 ? -1 : (y0 + 1) / a.rows));
+      for (int sl = s_lo; sl <= s_hi; ++sl) {
+        const int r0 = sl * a.rows, nr = min(a.rows, a.H - r0);
+        if (!vox_hits_slab(y0, r0, nr)) continue;
+        const int b_lo = max(0, (x0 < 0 ? -1 : x0 / a.bw)), b_hi = min(VOX_BANDS - 1, (x0 + 1 < 0 ? -1 : (x0 + 1) / a.bw));
+        for (int bd = b_lo; bd <= b_hi; ++bd)
+          if (vox_hits_band(x0, bd, a.bw, a.W)) {
+            if (LDS_HIST) atomicAdd(&hist[sl * VOX_BANDS + bd], 1);
+            else atomicAdd(&counts[(sl * VOX_BANDS + bd) * VOX_SEGS + seg], 1);
           }
-    };
-    for (long long ib = tid; ib - lane < n; ib += 8 * 1024) {  // the wave's lanes walk 8 x 64 consecutive events per trip
-      float yv[8];
+      }
+    }
+  }
+  if (LDS_HIST) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < nb; j += 1024) counts[j * VOX_SEGS + seg] = hist[j];
+  }
+}
+
+// Appends up to 64 hits (one per lane, in lane = event order) to the (band, segment) sub-lists they touch.  `curv`: lane v holds
+// the cursor of band v.  ONE copy of this code (noinline): inlined at its call sites and unrolled over the bands, the kernel
+// grew to 72 KB of instructions and no longer fitted the instruction cache.
+__device__ __noinline__ void vox_distribute(uint32_t ev, bool valid, const uint32_t* keys, uint32_t* lists, const int* sub_base, int seg,
+                                            int bw, int W, int& curv) {
+  const int lane = threadIdx.x & 63;
+  const int x0 = vox_key_x(keys[valid ? ev : 0]);
+  const int b0 = (valid && x0 >= 0 && x0 < W) ? x0 / bw : -1;
+  const int b1 = (valid && x0 + 1 >= 0 && x0 + 1 < W) ? (x0 + 1) / bw : -1;
+  for (int v = 0; v < VOX_BANDS; ++v) {
+    const bool own = b0 == v || b1 == v;
+    const unsigned long long m = __ballot(own);
+    if (m == 0) continue;
+    const int cur = __builtin_amdgcn_readlane(curv, v);
+    if (own) lists[sub_base[v * VOX_SEGS + seg] + cur + __popcll(m & ((1ull << lane) - 1ull))] = ev;
+    if (lane == v) curv += __popcll(m);
+  }
+}
+
+struct VoxSlab {
+  float* tile;
+  unsigned* tag;
+  int c_lo, c_hi, r0, nr, rows, W, bins;
+};
+
+// One corner (dx,dy,dt) of up to 64 events (one per lane, in lane = event order) into the wave's columns of the LDS slab.
+__device__ __forceinline__ void vox_corner_add(const VoxSlab sb, const float4 r, bool in, int dx, int dy, int dt) {
+  const int lane = threadIdx.x & 63;
+  const float xf = r.x, yf = r.y, tn = r.z, value = r.w;
+  const int xl = (int)xf + dx, yl = (int)yf + dy, tl = (int)tn + dt;
+  const float w = value * (1.0f - fabsf((float)xl - xf)) * (1.0f - fabsf((float)yl - yf)) * (1.0f - fabsf((float)tl - tn));
+  bool pend = in && xl >= sb.c_lo && xl < sb.c_hi && yl >= sb.r0 && yl < sb.r0 + sb.nr && yl >= 0 && tl >= 0 && tl < sb.bins && w != 0.0f;
+  const int cell = pend ? (tl * sb.rows + (yl - sb.r0)) * sb.W + xl : 0;
+  const int h = cell & (VOX_TAGS - 1);
+  volatile unsigned* tag = sb.tag;
+  volatile float* tile = sb.tile;
+  while (__ballot(pend)) {  // lanes on one voxel (or one tag) go in lane order: the lowest pending lane wins the tag
+    if (pend) atomicMin(sb.tag + h, (unsigned)lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool win = pend && tag[h] == (unsigned)lane;
+    if (win) {
+      tile[cell] = tile[cell] + w;
+      tag[h] = 0xFFFFFFFFu;
+      pend = false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// One workgroup per (slab of `rows` image rows, sample); wave w sweeps event segment w and owns column band w.
+//   1. sweep (no workgroup barrier): a wave tests the keys of its contiguous share of the sample's events, 512 per trip with
+//      8 loads in flight per lane; hits are compacted in event order into a per-wave LDS queue and, 64 at a time, appended to
+//      the (band, segment) sub-lists they touch -- ranks from one ballot per band, so every sub-list is in event order, and
+//      the sub-lists of a band lie behind each other in segment order: one list per band, in event order.
+//   2. scatter: for each of the eight corners in the reference's loop order, a wave walks its band's list 64 events at a
+//      time (the first VOX_CACHE chunks stay in registers over the corners).  Lanes whose corner lands on the same voxel are
+//      serialised in lane (= event) order with a table of ds_min tags (an integer minimum is order independent); the
+//      voxel itself is updated with a plain LDS read-add-write, since no other wave owns its column.  Adding a zero weight
+//      cannot change an accumulator that started at +0, so such lanes sit out.
+//   3. the slab leaves LDS with plain coalesced stores (no memset of the grid); the statistics of its non-zero voxels are
+//      summed in a fixed order and written per slab (no atomics): the normalisation adds them up slab by slab.
+__global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a, int want_stats) {
+  extern __shared__ float tile[];  // [bins][rows][W]
+  __shared__ double sh[3][16];
+  __shared__ uint32_t wqueue[16 * 128];
+  __shared__ unsigned tags[VOX_BANDS * VOX_TAGS];
+  __shared__ int sub_base[VOX_BANDS * VOX_SEGS + 1];  // relative to slab_base
+  __shared__ long long red[16];
+  __shared__ int wsum[4];
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int rows = a.rows, r0 = sl * rows, nr = min(rows, a.H - r0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = a.bins * rows * a.W;
+  for (int i = tid; i < slab; i += 1024) tile[i] = 0.0f;
+  for (int i = tid; i < VOX_BANDS * VOX_TAGS; i += 1024) tags[i] = 0xFFFFFFFFu;
+  const long long o0 = a.offs[b], n = a.offs[b + 1] - o0;
+  // list bases: sum of the sample's counts before this slab + exclusive prefix over this slab's (band, segment) counts
+  const int per_slab = VOX_BANDS * VOX_SEGS;
+  const int32_t* counts = a.counts + (size_t)b * a.nslab * per_slab;
+  {
+    long long acc = 0;
+    for (int j = tid; j < sl * per_slab; j += 1024) acc += counts[j];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) yv[u] = a.y[o0 + (ib + u * 1024 < n ? ib + u * 1024 : n - 1)];  // clamped address: guarded loads are serialised by hipcc
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) red[wave] = acc;
+    int v = 0, incl = 0;
+    if (tid < per_slab) {
+      v = counts[sl * per_slab + tid];
+      incl = v;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long long i = ib + u * 1024;
-        const int y0 = (int)yv[u];
-        const bool hit = i < n && y0 + 1 >= r0 && y0 < r0 + nr;
-        const unsigned long long m = __ballot(hit);
-        if (m == 0) continue;
-        if (hit) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
-        qn += __popcll(m);
-        if (qn >= 64) {  // wave-uniform
-          process((long long)queue[lane]);
-          qn -= 64;
-          if (lane < qn) {
-            const int v = queue[64 + lane];
-            queue[lane] = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wsum[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < per_slab) {
+      int pre = 0;
+      for (int w = 0; w < wave; ++w) pre += wsum[w];
+      sub_base[tid] = pre + incl - v;
+      if (tid == per_slab - 1) sub_base[per_slab] = pre + incl;
+    }
+  }
+  __syncthreads();
+  long long slab_base = 4 * o0;
+  for (int w = 0; w < 16; ++w) slab_base += red[w];
+  uint32_t* lists = a.lists + slab_base;
+  if (n > 0 && !VOX_EXP_ON(1)) {
+    {  // ---- 1. sweep segment `wave`
+      const long long seg = vox_seg(n), lo = wave * seg, hi = min(n, lo + seg);
+      const uint32_t* keys = a.keys + o0;
+      uint32_t* queue = wqueue + wave * 128;
+      int qn = 0;    // wave-uniform
+      int curv = 0;  // lane v: cursor of the (band v, this segment) sub-list
+      for (long long base = lo; base < hi; base += 512) {
+        uint32_t kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long long i = base + u * 64 + lane;
+          kv[u] = keys[i < n ? i : n - 1];  // clamped address: guarded loads are serialised by hipcc
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long long i = base + u * 64 + lane;
+          const bool hit = i < hi && vox_hits_slab(vox_key_y(kv[u]), r0, nr);
+          const unsigned long long m = __ballot(hit);
+          if (m == 0) continue;
+          if (hit) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+          qn += __popcll(m);
+          if (qn >= 64) {  // wave-uniform
+            if (!VOX_EXP_ON(4)) vox_distribute(queue[lane], true, keys, lists, sub_base, wave, a.bw, a.W, curv);
+            qn -= 64;
+            if (lane < qn) {
+              const uint32_t v = queue[64 + lane];
+              queue[lane] = v;
+            }
           }
         }
       }
+      if (qn > 0 && !VOX_EXP_ON(4)) vox_distribute(lane < qn ? queue[lane] : 0u, lane < qn, keys, lists, sub_base, wave, a.bw, a.W, curv);
     }
-    if (lane < qn) process((long long)queue[lane]);
+    // the lists are read by other waves of this workgroup: same CU, same L1 -> a workgroup-scope release is enough
+    if (!VOX_EXP_ON(3)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    else __threadfence();
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (!VOX_EXP_ON(2) && !VOX_EXP_ON(4)) {  // ---- 2. scatter band `wave`
+      const uint32_t* mylist = lists + sub_base[wave * VOX_SEGS];
+      const int mylen = sub_base[(wave + 1) * VOX_SEGS] - sub_base[wave * VOX_SEGS];
+      const float4* rec = a.rec + o0;
+      VoxSlab sb;
+      sb.tile = tile;
+      sb.tag = tags + wave * VOX_TAGS;
+      sb.c_lo = wave * a.bw;
+      sb.c_hi = min(a.W, sb.c_lo + a.bw);
+      sb.r0 = r0;
+      sb.nr = nr;
+      sb.rows = rows;
+      sb.W = a.W;
+      sb.bins = a.bins;
+      float4 rc[VOX_CACHE];
+      {
+        uint32_t ix[VOX_CACHE];
+#pragma unroll
+        for (int k = 0; k < VOX_CACHE; ++k) ix[k] = __builtin_nontemporal_load(mylist + (k * 64 + lane < mylen ? k * 64 + lane : 0));
+#pragma unroll
+        for (int k = 0; k < VOX_CACHE; ++k) rc[k] = rec[mylen > 0 ? ix[k] : 0];
+      }
+      const int nchunk = (mylen + 63) >> 6;
+      // sensors deliver integer pixel coordinates: a corner with dx = 1 (dy = 1) then weighs every event with an exact zero
+      // and is skipped for the whole list (the test is exact: such lanes would sit out one by one anyway)
+      bool fx = false, fy = false;
+#pragma unroll 1
+      for (int c = 0; c < mylen; c += 64) {
+        const bool in = c + lane < mylen;
+        const float4 r = rec[__builtin_nontemporal_load(mylist + (in ? c + lane : 0))];
+        fx |= in && r.x != (float)(int)r.x;
+        fy |= in && r.y != (float)(int)r.y;
+      }
+      const bool any_fx = __ballot(fx) != 0, any_fy = __ballot(fy) != 0;
+      for (int corner = 0; corner < 8; ++corner) {
+        const int dx = corner >> 2, dy = (corner >> 1) & 1, dt = corner & 1;
+        if ((dx && !any_fx) || (dy && !any_fy)) continue;
+        // the cached chunks take turns in rc[0] (one copy of the corner code; VOX_CACHE turns per corner restore the order),
+        // longer lists read their further chunks again per corner
+#pragma unroll 1
+        for (int k = 0; k < max(nchunk, VOX_CACHE); ++k) {
+          float4 r = rc[0];
+          if (k < VOX_CACHE) {
+#pragma unroll
+            for (int q = 0; q + 1 < VOX_CACHE; ++q) rc[q] = rc[q + 1];
+            rc[VOX_CACHE - 1] = r;
+          } else {
+            r = rec[__builtin_nontemporal_load(mylist + (k * 64 + lane < mylen ? k * 64 + lane : 0))];
+          }
+          if (k < nchunk) vox_corner_add(sb, r, k * 64 + lane < mylen, dx, dy, dt);
+        }
+      }
+    }
   }
   __syncthreads();
   float* grid = a.grid + (size_t)b * a.bins * a.H * a.W;
@@ -122,14 +334,13 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const VoxArgs a, int r
       }
     }
   }
-  if (stats_all) {
+  if (want_stats) {  // fixed order: thread-strided partials, butterfly over the lanes, the 16 waves in turn
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       c += __shfl_xor(c, off, 64);
       sm += __shfl_xor(sm, off, 64);
       q += __shfl_xor(q, off, 64);
     }
-    const int wave = tid >> 6, lane = tid & 63;
     if (lane == 0) {
       sh[0][wave] = c;
       sh[1][wave] = sm;
@@ -143,23 +354,28 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const VoxArgs a, int r
         s2 += sh[1][w];
         q2 += sh[2][w];
       }
-      double* stats = stats_all + 4 * b;
-      atomicAdd(&stats[0], c2);
-      atomicAdd(&stats[1], s2);
-      atomicAdd(&stats[2], q2);
+      double* part = a.part + ((size_t)b * a.nslab + sl) * 3;
+      part[0] = c2;
+      part[1] = s2;
+      part[2] = q2;
     }
   }
 }
 
 // (v - mean) / std (unbiased) on the non-zero voxels; std == 0 -> only centre; grid (blocks, B)
-__global__ void voxel_normalize_kernel(float* grid_all, long long n, const double* stats_all) {
+__global__ void voxel_normalize_kernel(float* grid_all, long long n, const double* part_all, int nslab) {
   float* grid = grid_all + (size_t)blockIdx.y * n;
-  const double* stats = stats_all + 4 * blockIdx.y;
-  const double cnt = stats[0];
+  const double* part = part_all + (size_t)blockIdx.y * nslab * 3;
+  double cnt = 0.0, sum = 0.0, sq = 0.0;
+  for (int sl = 0; sl < nslab; ++sl) {  // slab order: the same bits in every block and every run
+    cnt += part[3 * sl];
+    sum += part[3 * sl + 1];
+    sq += part[3 * sl + 2];
+  }
   if (cnt <= 0.0) return;
-  const double mean = stats[1] / cnt;
+  const double mean = sum / cnt;
   double var = 0.0;
-  if (cnt > 1.0) var = (stats[2] - cnt * mean * mean) / (cnt - 1.0);
+  if (cnt > 1.0) var = (sq - cnt * mean * mean) / (cnt - 1.0);
   if (var < 0.0) var = 0.0;
   const float meanf = (float)mean;
   const float stdf = (float)sqrt(var);
@@ -250,16 +466,13 @@ constexpr int kMaxDev = 64;
 thread_local PinnedOffsets g_offs[kMaxDev];
 
 // copies the host offsets to the workspace and returns the largest per-sample event count (-1 on bad input)
-long long stage_offsets(const int64_t* offsets_host, int B, int H, int W, void* ws, hipStream_t s, int64_t** dev) {
+long long stage_offsets(const int64_t* offsets_host, int B, int64_t* p, hipStream_t s) {
   long long mx = 0;
   for (int b = 0; b < B; ++b) {
     const long long n = offsets_host[b + 1] - offsets_host[b];
     if (n < 0) return -1;
     mx = n > mx ? n : mx;
   }
-  char* p = (char*)ws + (size_t)B * 32 + (size_t)B * H * W * sizeof(int32_t) + (size_t)B * 8;
-  p = (char*)(((size_t)p + 7) & ~(size_t)7);
-  *dev = (int64_t*)p;
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= kMaxDev) return -2;
   PinnedOffsets& st = g_offs[devid];
@@ -287,28 +500,72 @@ int reserve_voxel_lds(size_t lds) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   std::lock_guard<std::mutex> lk(mu);
   if (lds <= granted[dev]) return 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&voxel_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&voxel_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return -1;
   granted[dev] = lds;
   return 0;
 }
 }  // namespace
 
+namespace {
+// slab geometry of the scatter: `rows` image rows x all bins stay under ~62 KB of LDS (+17 KB of queues / tags) so that two
+// workgroups share a CU
+struct VoxGeom {
+  int rows, nslab, bw;
+};
+VoxGeom vox_geom(int bins, int H, int W) {
+  VoxGeom g;
+  g.rows = (int)(16000 / ((long long)bins * W));
+  g.rows = g.rows < 1 ? 1 : (g.rows > H ? H : g.rows);
+  g.nslab = einx_cdiv(H, g.rows);
+  g.bw = einx_cdiv(W, VOX_BANDS);
+  return g;
+}
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+// workspace of einx_voxel_grid: per-slab statistics fp64 [B][nslab][3] | list lengths int32 [B][nslab][16][16] | device offsets
+// int64 [B+1] | event records float4 [N] | cell keys uint32 [N] | event lists uint32 [4 N]   (N = total_events = offsets_host[B])
+EINX_EXPORT size_t einx_voxel_ws_bytes(int B, int bins, int H, int W, int64_t total_events) {
+  if (B <= 0 || bins <= 0 || H <= 0 || W <= 0 || total_events < 0) return 0;
+  const VoxGeom g = vox_geom(bins, H, W);
+  return al256((size_t)B * g.nslab * 3 * sizeof(double)) + al256((size_t)B * g.nslab * VOX_BANDS * VOX_SEGS * sizeof(int32_t)) +
+         al256(((size_t)B + 1) * sizeof(int64_t)) + al256((size_t)total_events * sizeof(float4)) +
+         al256((size_t)total_events * sizeof(uint32_t)) + al256((size_t)total_events * 4 * sizeof(uint32_t)) + 256;
+}
+
 EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t, const float* p, const int64_t* offsets_host, int B,
-                                int bins, int H, int W, int normalize, float* grid, void* ws, void* stream) {
+                                int bins, int H, int W, int normalize, float* grid, void* ws, size_t ws_bytes, void* stream) {
   EINX_CHECK_ARG(x && y && t && p && offsets_host && grid && ws, "null pointer");
-  EINX_CHECK_ARG(B > 0 && bins > 0 && H > 0 && W > 0, "bad shape");
+  EINX_CHECK_ARG(B > 0 && bins > 0 && H > 0 && W > 0 && H < 60000 && W < 60000, "bad shape");
+  EINX_CHECK_ARG(offsets_host[0] == 0, "offsets_host[0] must be 0");
   hipStream_t s = (hipStream_t)stream;
   const size_t per = (size_t)bins * H * W;
-  double* stats = (double*)ws;  // [B][4]
-  int64_t* offs = nullptr;
-  const long long mx = stage_offsets(offsets_host, B, H, W, ws, s, &offs);
+  const VoxGeom g = vox_geom(bins, H, W);
+  const int64_t N = offsets_host[B];
+  EINX_CHECK_ARG(N >= 0 && N < ((int64_t)1 << 31), "bad event count");
+  EINX_CHECK_ARG(ws_bytes >= einx_voxel_ws_bytes(B, bins, H, W, N), "workspace smaller than einx_voxel_ws_bytes");
+  char* wp = (char*)(((size_t)ws + 255) & ~(size_t)255);
+  VoxArgs a;
+  a.part = (double*)wp;
+  wp += al256((size_t)B * g.nslab * 3 * sizeof(double));
+  a.counts = (int32_t*)wp;
+  const size_t counts_bytes = (size_t)B * g.nslab * VOX_BANDS * VOX_SEGS * sizeof(int32_t);
+  wp += al256(counts_bytes);
+  int64_t* offs = (int64_t*)wp;
+  wp += al256(((size_t)B + 1) * sizeof(int64_t));
+  a.rec = (float4*)wp;
+  wp += al256((size_t)N * sizeof(float4));
+  a.keys = (uint32_t*)wp;
+  wp += al256((size_t)N * sizeof(uint32_t));
+  a.lists = (uint32_t*)wp;
+  const long long mx = stage_offsets(offsets_host, B, offs, s);
   EINX_CHECK_ARG(mx != -1, "offsets must be non-decreasing");
-  if (mx == -2 || hipMemsetAsync(stats, 0, (size_t)B * 32, s) != hipSuccess) {
+  const bool lds_hist = g.nslab * VOX_BANDS <= VOX_PREP_BINS;  // else: counted with global atomics into zeroed counters
+  if (mx == -2 || (!lds_hist && hipMemsetAsync(a.counts, 0, counts_bytes, s) != hipSuccess)) {
     einx_set_error("einx_voxel_grid: memset / copy failed");
     return EINX_ERR_LAUNCH;
   }
-  VoxArgs a;
   a.x = x;
   a.y = y;
   a.t = t;
@@ -317,20 +574,23 @@ EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t,
   a.bins = bins;
   a.H = H;
   a.W = W;
+  a.rows = g.rows;
+  a.nslab = g.nslab;
+  a.bw = g.bw;
   a.grid = grid;
-  // rows per workgroup: the slab bins*rows*W floats stays under ~68 KB (+8 KB of per-wave queues) so that two workgroups share a CU
-  int rows = (int)(17000 / ((long long)bins * W));
-  rows = rows < 1 ? 1 : (rows > H ? H : rows);
-  const size_t lds = (size_t)bins * rows * W * sizeof(float);
-  EINX_CHECK_ARG(lds <= 150 * 1024, "bins * W too large for the LDS tile scatter");
+  const size_t lds = (size_t)bins * g.rows * W * sizeof(float);
+  EINX_CHECK_ARG(lds <= 140 * 1024, "bins * W too large for the LDS tile scatter");
   if (reserve_voxel_lds(lds) != 0) {
     einx_set_error("einx_voxel_grid: cannot reserve %zu bytes of LDS", lds);
     return EINX_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(voxel_tile_kernel, dim3((unsigned)einx_cdiv(H, rows), (unsigned)B), dim3(1024), lds, s, a, rows, normalize ? stats : nullptr);
+  if (lds_hist) hipLaunchKernelGGL(voxel_prep_kernel<true>, dim3(VOX_SEGS, (unsigned)B), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL(voxel_prep_kernel<false>, dim3(VOX_SEGS, (unsigned)B), dim3(1024), 0, s, a);
+  EINX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(voxel_scatter_kernel, dim3((unsigned)g.nslab, (unsigned)B), dim3(1024), lds, s, a, normalize);
   EINX_CHECK_LAUNCH();
   if (normalize) {
-    hipLaunchKernelGGL(voxel_normalize_kernel, dim3(128, (unsigned)B), dim3(256), 0, s, grid, (long long)per, stats);
+    hipLaunchKernelGGL(voxel_normalize_kernel, dim3(128, (unsigned)B), dim3(256), 0, s, grid, (long long)per, a.part, g.nslab);
     EINX_CHECK_LAUNCH();
   }
   return EINX_OK;
@@ -344,8 +604,8 @@ EINX_EXPORT int einx_events_mask(const float* x, const float* y, const int64_t* 
   const int n = H * W;
   int32_t* cnt = (int32_t*)((char*)ws + (size_t)B * 32);
   int32_t* mm = (int32_t*)((char*)ws + (size_t)B * 32 + (size_t)B * n * sizeof(int32_t));
-  int64_t* offs = nullptr;
-  const long long mx = stage_offsets(offsets_host, B, H, W, ws, s, &offs);
+  int64_t* offs = (int64_t*)(((size_t)((char*)ws + (size_t)B * 32 + (size_t)B * n * sizeof(int32_t) + (size_t)B * 8) + 7) & ~(size_t)7);
+  const long long mx = stage_offsets(offsets_host, B, offs, s);
   EINX_CHECK_ARG(mx != -1, "offsets must be non-decreasing");
   if (mx == -2 || hipMemsetAsync(cnt, 0, (size_t)B * n * sizeof(int32_t), s) != hipSuccess) {
     einx_set_error("einx_events_mask: memset / copy failed");

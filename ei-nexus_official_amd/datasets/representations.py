@@ -30,9 +30,9 @@ def events_to_voxel_grid_batch(events_list, input_size, normalize=True, device="
     x, y, t, p, offs = _pack(events_list, device)
     L = N.lib()
     grid = torch.empty((B, bins, H, W), dtype=torch.float32, device=device)
-    ws = torch.empty(L.einx_events_ws_bytes(B, H, W), dtype=torch.uint8, device=device)
+    ws = torch.empty(L.einx_voxel_ws_bytes(B, bins, H, W, int(offs[-1])), dtype=torch.uint8, device=device)
     check(L.einx_voxel_grid(N._ptr(x), N._ptr(y), N._ptr(t), N._ptr(p), offs.ctypes.data_as(ctypes.c_void_p), B, bins, H, W, int(normalize),
-                            N._ptr(grid), N._ptr(ws), N._stream(grid)), "einx_voxel_grid")
+                            N._ptr(grid), N._ptr(ws), ws.numel(), N._stream(grid)), "einx_voxel_grid")
     return grid
 
 

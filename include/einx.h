@@ -261,12 +261,16 @@ int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* de
  * Event representation (the step before the path)
  * events of B samples are concatenated; offsets_host[B+1] (HOST array) delimits the samples.
  * x, y, p: float32 [N]; t: float64 [N] raw timestamps (normalised inside exactly like
- * datasets/representations.py:8-21).  ws: einx_events_ws_bytes.
+ * datasets/representations.py:8-21).
  * ---------------------------------------------------------------------------------------- */
-size_t einx_events_ws_bytes(int B, int H, int W);
-/* events_to_voxel_grid (datasets/representations.py:67-124): grid [B,bins,H,W] */
+size_t einx_events_ws_bytes(int B, int H, int W);                                        /* workspace of einx_events_mask */
+size_t einx_voxel_ws_bytes(int B, int bins, int H, int W, int64_t total_events);         /* workspace of einx_voxel_grid */
+/* events_to_voxel_grid (datasets/representations.py:67-124): grid [B,bins,H,W].  Deterministic: per voxel the contributions
+ * are added in the order of the reference's serial path (corner (dx,dy,dt) major, then event order, :94-114), so two calls give
+ * the same bits and the un-normalised grid is bit-equal to a sequential restatement.  offsets_host[0] must be 0;
+ * ws_bytes >= einx_voxel_ws_bytes(B, bins, H, W, offsets_host[B]) is checked. */
 int einx_voxel_grid(const float* x, const float* y, const double* t, const float* p, const int64_t* offsets_host, int B, int bins, int H,
-                    int W, int normalize, float* grid, void* ws, void* stream);
+                    int W, int normalize, float* grid, void* ws, size_t ws_bytes, void* stream);
 /* draw_events_accumulation_image(...) > 0 (datasets/visualize.py:23-50,
  * test_events-image_same-time.py:137): mask uint8 [B,H,W] */
 int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host, int B, int H, int W, void* ws, uint8_t* mask,

@@ -719,6 +719,9 @@ EVENTS = Golden("events")
 
 
 def test_voxel_grid_and_events_mask(oracle):
+    """Round 4: the voxel grid is DETERMINISTIC -- per voxel the contributions are added in the reference's serial order (corner
+    major, then event order; representations.py:94-114), so the un-normalised grid is bit-equal to the oracle at every size, to
+    the reference's fixture wherever torch itself added serially (< 32768 events), and two runs give the same bits."""
     from importlib import import_module
     from helpers import synth_raw_events
     rep = import_module(pkg.__name__ + ".datasets.representations")
@@ -731,22 +734,55 @@ def test_voxel_grid_and_events_mask(oracle):
         raw = _np(rep.events_to_voxel_grid(ev, size, normalize=False))
         assert all(np.array_equal(ev[k], keep[k]) for k in ev)  # the caller's dict is left alone
         name = c["name"]
-        # fp32 atomics: equal to the reference up to summation order
-        np.testing.assert_allclose(raw, oracle.voxel_grid(ev, size, normalize=False), atol=2e-5, rtol=1e-5)
-        np.testing.assert_allclose(grid, oracle.voxel_grid(ev, size, normalize=True), atol=2e-5, rtol=1e-5)
+        assert np.array_equal(raw, oracle.voxel_grid(ev, size, normalize=False)), name
+        assert np.array_equal(raw, _np(rep.events_to_voxel_grid(ev, size, normalize=False))), "two runs differ"
+        assert np.array_equal(grid, _np(rep.events_to_voxel_grid(ev, size, normalize=True))), "two runs differ"
+        # normalisation: float64 statistics summed slab by slab here, voxel by voxel in the oracle -> equal up to the rounding
+        # of the mean / std to fp32 (bit-equal unless a sum sits on a rounding boundary)
+        close_and_record(f"events.{name}.grid vs oracle", grid, oracle.voxel_grid(ev, size, normalize=True), atol=1e-6)
         if f"{name}.grid" in EVENTS:
-            np.testing.assert_allclose(grid, EVENTS[f"{name}.grid"], atol=2e-5, rtol=1e-5)
-        else:
-            np.testing.assert_allclose(grid.reshape(-1)[::7], EVENTS[f"{name}.grid.stride7"], atol=2e-5, rtol=1e-5)
-        assert (raw != 0).sum() == (oracle.voxel_grid(ev, size, normalize=False) != 0).sum()
+            assert np.array_equal(raw, EVENTS[f"{name}.raw"]), name  # the reference's own bits
+            close_and_record(f"events.{name}.grid vs reference", grid, EVENTS[f"{name}.grid"], atol=2e-5, rtol=1e-5)
+        else:  # 60k events: torch's put_(accumulate=True) adds with unordered atomics there
+            close_and_record(f"events.{name}.raw vs reference", raw.reshape(-1)[::7], EVENTS[f"{name}.raw.stride7"], atol=2e-5, rtol=1e-5)
+            close_and_record(f"events.{name}.grid vs reference", grid.reshape(-1)[::7], EVENTS[f"{name}.grid.stride7"], atol=2e-5, rtol=1e-5)
         mask = _np(rep.events_mask_batch([ev], (c["W"], c["H"])))[0, 0]
         exp = np.unpackbits(EVENTS[f"{name}.mask"])[:c["H"] * c["W"]].astype(bool).reshape(c["H"], c["W"])
         assert np.array_equal(mask, exp)  # integer counts: bit exact
-    # batched call == per-sample calls
-    small = [synth_raw_events(EVENTS.cases["int_p01"]), synth_raw_events(dict(EVENTS.cases["int_p01"], seed=99, n=1000))]
+    # batched call == per-sample calls, bit for bit (one sample is empty)
+    empty = {k: v[:0] for k, v in synth_raw_events(EVENTS.cases["int_p01"]).items()}
+    small = [synth_raw_events(EVENTS.cases["int_p01"]), empty, synth_raw_events(dict(EVENTS.cases["int_p01"], seed=99, n=1000))]
     gb = _np(rep.events_to_voxel_grid_batch(small, (5, 40, 48), normalize=False))
     for b, e in enumerate(small):
-        np.testing.assert_allclose(gb[b], oracle.voxel_grid(e, (5, 40, 48), normalize=False), atol=2e-5, rtol=1e-5)
+        assert np.array_equal(gb[b], oracle.voxel_grid(e, (5, 40, 48), normalize=False))
+
+
+def test_voxel_grid_collisions_and_out_of_range_events(oracle):
+    """The order-sensitive cases: thousands of fractional events on a handful of pixels (every 64-event batch collides, within
+    and across corners), coordinates outside the sensor on every side (x, y in [-3, W+2]), unsorted timestamps, one hot pixel
+    taking a third of all events, and a slab-crossing geometry other than 346x260 -- all bit-equal to the sequential oracle."""
+    from importlib import import_module
+    rep = import_module(pkg.__name__ + ".datasets.representations")
+    cases = [dict(seed=3, n=20000, H=260, W=346, bins=5, box=4), dict(seed=4, n=50000, H=260, W=346, bins=5, box=400),
+             dict(seed=5, n=9000, H=97, W=131, bins=3, box=30), dict(seed=6, n=70000, H=480, W=640, bins=5, box=700)]
+    for c in cases:
+        n, H, W = c["n"], c["H"], c["W"]
+        x = synth.uniform(c["seed"], (n,), -3.0, min(W + 2.0, c["box"]))
+        y = synth.uniform(c["seed"] + 1, (n,), -3.0, min(H + 2.0, c["box"]))
+        hot = synth.uniform01(c["seed"] + 2, (n,)) < np.float32(0.33)
+        x = np.where(hot, np.float32(W // 3) + np.float32(0.25), x).astype(np.float32)
+        y = np.where(hot, np.float32(H // 2) + np.float32(0.5), y).astype(np.float32)
+        t = 1.5e9 + np.cumsum(synth.uniform01(c["seed"] + 3, (n,)).astype(np.float64) * 1e-4 + 1e-6)
+        if c["seed"] == 5:  # unsorted timestamps between the first and the last event
+            t[1:-1] = t[1:-1][np.argsort(synth.uniform01(77, (n - 2,)))]
+        p = np.where(hot | (synth.uniform01(c["seed"] + 4, (n,)) < np.float32(0.5)), np.float32(1), np.float32(-1)).astype(np.float32)
+        ev = {"x": x, "y": y, "t": t, "p": p}
+        size = (c["bins"], H, W)
+        raw = _np(rep.events_to_voxel_grid(ev, size, normalize=False))
+        exp = oracle.voxel_grid(ev, size, normalize=False)
+        assert np.array_equal(raw, exp), (c, int((raw != exp).sum()), float(np.abs(raw - exp).max()))
+        assert np.abs(exp).max() > 100  # the hot pixel really accumulates thousands of contributions
+        assert np.array_equal(raw, _np(rep.events_to_voxel_grid(ev, size, normalize=False)))
 
 
 # ------------------------------------------------------------------ evaluation metrics (next row 8f-1)

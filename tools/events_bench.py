@@ -17,8 +17,9 @@ L = N.lib()
 grid = torch.empty((B, bins, H, W), device="cuda")
 mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device="cuda")
 ws = torch.empty(L.einx_events_ws_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+wsv = torch.empty(L.einx_voxel_ws_bytes(B, bins, H, W, B * n), dtype=torch.uint8, device="cuda")
 def vg():
-    check(L.einx_voxel_grid(N._ptr(x), N._ptr(y), N._ptr(t), N._ptr(p), offs.ctypes.data_as(ctypes.c_void_p), B, bins, H, W, 1, N._ptr(grid), N._ptr(ws), N._stream(grid)), "vg")
+    check(L.einx_voxel_grid(N._ptr(x), N._ptr(y), N._ptr(t), N._ptr(p), offs.ctypes.data_as(ctypes.c_void_p), B, bins, H, W, 1, N._ptr(grid), N._ptr(wsv), wsv.numel(), N._stream(grid)), "vg")
 def mk():
     check(L.einx_events_mask(N._ptr(x), N._ptr(y), offs.ctypes.data_as(ctypes.c_void_p), B, H, W, N._ptr(ws), N._ptr(mask), N._stream(mask)), "mask")
 def timed(f, k=20):
