@@ -164,7 +164,7 @@ class ExtractorEngine:
         self.desc_head = []
         # wide NMS passes enqueued per forward (EINX_NMS_PASSES: tuning).  Measured: 4 instead of 8 at radius 4 leaves real work to
         # nms4_finish_kernel (one workgroup per image walking 54 tiles per pass): B=1 0.84 -> 1.01 ms, B=32 3440 -> 3347 pairs/s
-        self.nms_base = int(os.environ.get("EINX_NMS_PASSES", "8"))
+        self.nms_base = max(1, int(os.environ.get("EINX_NMS_PASSES", "8")))  # 0 or less would disable the retry growth (0 * 4 = 0)
         self.nms_iters = self.nms_base
         self._handle = None
         self._handle_key = None

@@ -63,6 +63,7 @@ class LgWeights(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/einx.h declares
 SIGNATURES = {
     "einx_version": (c_char_p, []),
+    "einx_build_flags": (c_char_p, []),
     "einx_last_error": (c_char_p, []),
     "einx_device_count": (c_int, []),
     "einx_profile_enable": (c_int, [c_int]),
@@ -142,6 +143,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    flags = lib.einx_build_flags().decode()
+    if "timing-only" in flags and os.environ.get("EINX_ALLOW_TIMING_ONLY") != "1":
+        raise ImportError(f"{LIB_PATH} is a timing-only experiment build (einx_build_flags() = {flags!r}): its results are WRONG. "
+                          "Set EINX_ALLOW_TIMING_ONLY=1 only to time it.")
     _lib = lib
     return lib
 

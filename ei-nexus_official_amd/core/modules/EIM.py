@@ -36,7 +36,7 @@ class EIM(nn.Module):
                 logger.log_info(f"Loaded pretrain_stage2 model from {config.pretrain_stage2.model_path}")
 
     overlap_extractors = os.environ.get("EINX_OVERLAP", "1") != "0"  # two (independent) extractors on two HIP streams
-    # Measured and NOT the default (tools/r3_exp15.sh, B=32 full dict): running the event side's dense kernels beside the image
+    # Measured and NOT the default (tools/experiments/r3_exp15.sh, B=32 full dict): running the event side's dense kernels beside the image
     # extractor's convolutions and the image side's beside the matcher is slower (11.69 vs 11.10 ms per step): the store
     # kernel's 248-register workgroups crowd the convolutions off the CUs, and serialising the two extractors gives up
     # the overlap of their latency-bound tails.

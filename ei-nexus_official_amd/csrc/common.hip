@@ -21,6 +21,13 @@ void einx_set_error(const char* fmt, ...) {
 
 EINX_EXPORT const char* einx_version(void) { return "einx-hip 0.1 (gfx950)"; }
 EINX_EXPORT const char* einx_last_error(void) { return g_err; }
+EINX_EXPORT const char* einx_build_flags(void) {
+#ifdef EINX_TIMING_ONLY_BUILD
+  return "timing-only";
+#else
+  return "";
+#endif
+}
 
 // ---- per-kernel-class timing with HIP events on the launch stream (measurement aid: bench.py's
 // roofline_stages).  Off by default: a scope costs one relaxed load when disabled.

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   float* w_tile = lds + IN_LDS;
 
 #if defined(EINX_CONV_STAGGER) && EINX_CONV_STAGGER > 0
-  // experiment (tools/r3_exp9.sh): are the two co-resident workgroups of a CU in lockstep (same start, same length, so their
+  // experiment (tools/experiments/r3_exp9.sh): are the two co-resident workgroups of a CU in lockstep (same start, same length, so their
   // prologues, epilogues and chunk boundaries coincide)?  Delay the second resident round once; later workgroups inherit it.
   {
     const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
 
   // Register image of one chunk in flight (global -> registers -> LDS).  DEPTH chunks are in flight: the loads of chunk
   // c + DEPTH are issued when chunk c has been committed to LDS, i.e. they have DEPTH chunks of MFMAs to land.
-  // Measured (tools/r3_exp10.sh, timing-only ablations): with DEPTH = 1 the per-chunk global loads cost conv1b 10 % (1653 us
+  // Measured (tools/experiments/r3_exp10.sh, timing-only ablations): with DEPTH = 1 the per-chunk global loads cost conv1b 10 % (1653 us
   // against 1485 us with the same commits fed from registers loaded once) although they are issued a whole chunk ahead.
   struct StageRegs {
     float in[IN_PER_THR];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
     __syncthreads();  // previous round's LDS reads are done
     commit_loads(sr);
     __syncthreads();
-#ifdef EINX_CONV_ABL_NOLOADS  // timing-only ablation (wrong results, tools/r3_exp10.sh / r3_exp11.sh): every chunk recommits chunk 0's registers
+#ifdef EINX_CONV_ABL_NOLOADS  // timing-only ablation (wrong results, tools/experiments/r3_exp10.sh / r3_exp11.sh): every chunk recommits chunk 0's registers
     if (false)
 #endif
     if (c + DEPTH < nchunks) issue_loads(c + DEPTH, sr);  // in flight under the MFMAs of the next DEPTH chunks
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
 // Cin must be a multiple of 8, no replicate-pad fold (never the first layer).  POOL: 2x2 max over lanes j^1 (x), j^8 (y).
 // ------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-// CK input channels per LDS round.  Measured at B=1 on the 33x44 128->128 layer (tools/r3_exp12.sh): 27.8 us with the finest
+// CK input channels per LDS round.  Measured at B=1 on the 33x44 128->128 layer (tools/experiments/r3_exp12.sh): 27.8 us with the finest
 // 32x32x2 tile (11x5, one accumulator per wave), 14.5 us here with CK = 8 (2,170 cycles per chunk for 720 of MFMAs: every
 // workgroup streams the layer's whole weight set, 18 KB per chunk, through L2 and LDS for 16 pixels); CK = 16 (half the
 // barriers) 14.6-15.1 us, three chunks of registers in flight 14.5-15.1 us, no LDS at all (every lane loads its own

@@ -218,6 +218,7 @@ constexpr int UP_COLS = 384;  // columns per workgroup: whole 346-pixel rows, so
 #ifndef EINX_UP_ROWS
 #define EINX_UP_ROWS 8
 #endif
+static_assert(EINX_UP_ROWS >= 1 && EINX_UP_ROWS <= 8, "upsample_store_kernel copies a wave's slab out with 2*NIT float4 per lane = 8 rows of 64*NIT floats");
 constexpr int UP_ROWS = EINX_UP_ROWS;    // rows per sweep: a band of the usual 1/8 scale (the first band takes two sweeps)
   // 
 

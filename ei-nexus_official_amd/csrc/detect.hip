@@ -8,6 +8,8 @@
 // (prob_map_to_points_map: quantile threshold), :451-484 (prob_map_to_positions_with_prob),
 // core/modules/event_extractors/EventExtractors.py:544-550,561-562 (mask dilation + apply),
 // core/modules/utils/util.py:52-66 (unpad_positions), EventExtractors.py:496-515 (filter).
+#include <algorithm>
+
 #include "einx_common.h"
 
 namespace {
@@ -467,6 +469,7 @@ constexpr int NMS_FIN_MAXT = 2048;  // tiles tracked individually; larger maps r
 // One workgroup finishes one image, so its time is passes x (tiles it revisits): bounded here (a 264x352 map of 8 score
 // levels needs 25 passes).  Beyond the bound `not_converged` stays raised and the caller's retry (a larger wide-pass budget,
 // then this finisher again) takes over, as for the other radii -- the stream never stalls on one pathological image.
+// The launch passes max(256, Hp + Wp) (round 4), so that only serpentine-like maps ever need the host retry.
 constexpr int kNmsFinishMaxPasses = 256;
 __global__ __launch_bounds__(NMS_THREADS) void nms4_finish_kernel(float* bufA, float* bufB, int Hp, int Wp, int tilesX, int tilesY,
                                                                   int32_t* flags, int nIt, int max_passes) {
@@ -1046,8 +1049,9 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
       float* last = const_cast<float*>(cur);
       float* other = last == buf0 ? buf1 : buf0;
       EINX_PROF("nms4_finish_kernel", s);
+      // bound: realistic slow cases are monotone ramps, whose chain of successive maxima advances >= 5 pixels per pass
       hipLaunchKernelGGL(nms4_finish_kernel, dim3((unsigned)p->B), dim3(NMS_THREADS), 0, s, last, other, p->Hp, p->Wp, tilesX, tilesY, flags, nIt,
-                         kNmsFinishMaxPasses);
+                         std::max(kNmsFinishMaxPasses, p->Hp + p->Wp));
       EINX_CHECK_LAUNCH();
     }
   }

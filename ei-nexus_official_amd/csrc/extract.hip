@@ -15,6 +15,7 @@
 // only sequences them, so a handle-level forward is bit-identical to the op-by-op forward.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <new>
@@ -22,9 +23,28 @@
 
 #include "einx_common.h"
 
+// One library-owned side stream + fork / join events per (device, caller stream) that has forked through this handle:
+// created on first use, owned by the handle, released by einx_extractor_destroy.  `mu` is held while a call enqueues its
+// fork .. join section, so two host threads that enqueue on one stream through one handle cannot interleave on the events.
+struct EinxSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::mutex mu;
+};
+
 struct einx_extractor {
   einx_extractor_desc d;
   std::vector<einx_conv_desc> backbone, det, desc;
+  mutable std::mutex sides_mu;
+  mutable std::map<std::pair<int, hipStream_t>, EinxSide> sides;
+  ~einx_extractor() {
+    for (auto& kv : sides) {
+      EinxSide& sd = kv.second;
+      if (sd.stream) (void)hipStreamDestroy(sd.stream);
+      if (sd.fork) (void)hipEventDestroy(sd.fork);
+      if (sd.join) (void)hipEventDestroy(sd.join);
+    }
+  }
 };
 
 namespace {
@@ -51,25 +71,30 @@ bool fork_heads(const einx_extractor* e, const Plan& pl, int B) {
   return !off && (long)B * pl.hc * pl.wc <= EINX_FORK_MAX_CELLS;
 }
 
-// one side stream + fork/join events per caller stream (created on first use, kept for the life of the process)
-struct Side {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-};
-Side* side_for(hipStream_t caller) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Side> sides;
+// the side of `caller` (keyed on the stream's OWN device, not on the current one)
+EinxSide* side_for(const einx_extractor* e, hipStream_t caller) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  Side& sd = sides[{dev, caller}];
+  if (caller) {
+    if (hipStreamGetDevice(caller, &dev) != hipSuccess) return nullptr;
+  } else if (hipGetDevice(&dev) != hipSuccess) {
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(e->sides_mu);
+  EinxSide& sd = e->sides[{dev, caller}];
   if (!sd.stream) {
-    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
+    int cur = 0;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
+    if (sw) (void)hipSetDevice(dev);
+    const bool ok = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+    if (sw) (void)hipSetDevice(cur);
+    if (!ok) {
       if (sd.stream) (void)hipStreamDestroy(sd.stream);
       if (sd.fork) (void)hipEventDestroy(sd.fork);
-      sd = Side();
+      if (sd.join) (void)hipEventDestroy(sd.join);
+      sd.stream = nullptr;
+      sd.fork = sd.join = nullptr;
       return nullptr;
     }
   }
@@ -272,7 +297,9 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
     if (e->d.cell == 8) r = einx_normalize_map(o->raw, B, D, h * w, e->d.desc_scale, o->coarse, o->raw_cl, st);
     return r;
   };
-  Side* sd = fork ? side_for((hipStream_t)stream) : nullptr;
+  EinxSide* sd = fork ? side_for(e, (hipStream_t)stream) : nullptr;
+  std::unique_lock<std::mutex> side_lock;
+  if (sd) side_lock = std::unique_lock<std::mutex>(sd->mu);
   if (sd) {  // fork: the descriptor branch runs beside the detector branch
     if (hipEventRecord(sd->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->stream, sd->fork, 0) != hipSuccess) {
       einx_set_error("einx_extract: fork failed");

@@ -145,7 +145,7 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
     for (int i = 0; i < STAGE; ++i) st.rb[i] = *reinterpret_cast<const f32x4*>(bk + offb[i]);
   };
 #ifndef EINX_GEMM_ABL
-#define EINX_GEMM_ABL 0  // timing-only ablations (wrong results; tools/r3_exp16.sh): 1 no LDS commit (the loads die with it), 2 also one barrier per slab, 3 also no global loads, 4 loads kept alive but no LDS writes
+#define EINX_GEMM_ABL 0  // timing-only ablations (wrong results; tools/experiments/r3_exp16.sh): 1 no LDS commit (the loads die with it), 2 also one barrier per slab, 3 also no global loads, 4 loads kept alive but no LDS writes
 #endif
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();  // the previous slab's (or tile's) fragment reads are done

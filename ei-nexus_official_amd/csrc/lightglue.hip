@@ -960,7 +960,7 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
 // ffn(cat[x,msg]) + residual, in place on s.x
 int ffn(hipStream_t st, const Side& s, int B, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
         const float* w3, const float* b3) {
-  // Measured (tools/r3_exp8.sh, B=64, one box): LightGlue 46.0 ms with the two launches below, 47.5 ms with the fused
+  // Measured (tools/experiments/r3_exp8.sh, B=64, one box): LightGlue 46.0 ms with the two launches below, 47.5 ms with the fused
   // kernel (bit-identical outputs).  With 512 row groups on 512 resident workgroups every workgroup reaches its LayerNorm
   // tail at the same time, so the tail does not hide under another workgroup's matrix work, and the group-per-workgroup
   // order gives up the XCD-shared operand rows.  The fused kernel stays selectable (EINX_LG_FUSE_LN=1) as the measured record.

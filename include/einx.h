@@ -10,7 +10,11 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
  *   - the caller makes the device of `stream` and of the buffers the current HIP device (hipSetDevice) before a call;
  *   - return 0 on success, negative on error (einx_last_error() gives the text);
- *   - no allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.
+ *   - no device-memory allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.  Two documented pieces of
+ *     library-owned state: (a) an einx_extractor handle lazily creates ONE side stream + two events per caller stream that
+ *     forks through it (small batches, see einx_extract) and releases them in einx_extractor_destroy; (b) einx_voxel_grid /
+ *     einx_events_mask keep a few hundred bytes of pinned staging per host thread for the host offsets array;
+ *   - einx_build_flags() tells a shipped library from a timing-only experiment build (see below).
  * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
  */
 #ifndef EINX_H
@@ -30,6 +34,11 @@ extern "C" {
 
 const char* einx_version(void);
 const char* einx_last_error(void);
+/* Compile-time switches of this binary as a space-separated string ("" for the shipped build).  Experiment builds
+ * (tools/build_variant.sh) that drop work to time what is left produce WRONG results; every such switch only takes effect
+ * under -DEINX_TIMING_ONLY_BUILD, which this string then reports as "timing-only" -- the Python package refuses to load such
+ * a library unless EINX_ALLOW_TIMING_ONLY=1. */
+const char* einx_build_flags(void);
 /* number of visible HIP devices (0 without a GPU); never initialises a context beyond that */
 int einx_device_count(void);
 
@@ -336,7 +345,12 @@ int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shap
  * workspace size depends on it (B x nms_iters convergence flags), so query and call must pass the same value. */
 size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int cap, int nms_iters);
 /* in [B,cin,H,W] (modified in place only when input_div is set); mask [B,1,H,W] uint8 or NULL;
- * ws: device scratch, ws_bytes >= einx_extract_ws_bytes(e, B, H, W, out->cap, nms_iters) (checked) */
+ * ws: device scratch, ws_bytes >= einx_extract_ws_bytes(e, B, H, W, out->cap, nms_iters) (checked).
+ * Small batches (B x head pixels <= 8192) enqueue the descriptor branch on a library-owned side stream between a fork and
+ * a join event of `stream`; every return path has `stream` wait for the join.  The side stream and its two events are created
+ * on the FIRST such call for a (device, stream) pair and belong to the handle -- so make one un-captured call per stream
+ * before capturing einx_extract into a hipGraph (stream / event creation is not capturable), and destroy the handle only
+ * after the streams it served have drained.  Calls through one handle on one stream are serialised on a mutex. */
 int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
                  size_t ws_bytes, const einx_extract_out* out, void* stream);
 

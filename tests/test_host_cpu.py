@@ -190,3 +190,23 @@ def test_entry_points_switch_to_the_inputs_device(monkeypatch):
     assert M().forward(b) == "ran" and len(entered) == 1  # already current: no guard
     assert M().forward(object(), y=a) == "ran" and len(entered) == 2  # found among the keyword arguments
     assert M().forward(torch.zeros(2)) == "ran" and len(entered) == 2  # CPU input: left to the wrappers' own error
+
+
+def test_nms_pass_budget_grows_and_decays(monkeypatch):
+    """ExtractorEngine's wide-pass budget (host logic, no GPU): EINX_NMS_PASSES <= 0 cannot disable the growth,
+    a retry quadruples the budget, 64 converged forwards halve it again, never below the base."""
+    import importlib
+    ex = importlib.import_module(pkg.__name__ + "._extract")
+    for env, base in (("0", 1), ("-3", 1), ("8", 8)):
+        monkeypatch.setenv("EINX_NMS_PASSES", env)
+        eng = ex.ExtractorEngine("vgg", top_k=1024, radius=4, border=4, det_thr=1.0, ordering="yx", cell=8)
+        assert eng.nms_base == base and eng.nms_iters == base
+        assert eng.grow_nms_iters() == 4 * base and eng.grow_nms_iters() == 16 * base
+        for _ in range(63):
+            eng.note_converged()
+        assert eng.nms_iters == 16 * base
+        eng.note_converged()
+        assert eng.nms_iters == 8 * base
+        for _ in range(64 * 8):
+            eng.note_converged()
+        assert eng.nms_iters == base

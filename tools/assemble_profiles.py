@@ -292,7 +292,7 @@ def write_readme(pmc, busy):
         A("")
     tp = os.path.join(PR, f"{R}_pmc_conv_tiles.json")
     if os.path.exists(tp):
-        A(f"## Per-variant conv counters (`{R}_pmc_conv_tiles.json`, `tools/r3_pmc_conv.sh` + `tools/pmc_tiles.py`)")
+        A(f"## Per-variant conv counters (`{R}_pmc_conv_tiles.json`, `tools/experiments/r3_pmc_conv.sh` + `tools/pmc_tiles.py`)")
         A("")
         tj = json.load(open(tp))
         A("| kernel variant | LDS conflicts / idx-active (plain pitch -> shipped) | MFMA busy (plain -> shipped) | effective MHz | mean us (profiled) |")

@@ -9,5 +9,5 @@ for v in cur plainpitch cur plainpitch; do
   if [ $v = cur ]; then L=""; else L="ab_libs/libeinx_$v.so"; fi
   EINX_LIB=$L python bench.py --layer-table 2>/dev/null | sed "s/^/$v: /" | tee -a gpurun_out/r3e1_layers.txt | grep -E "event.bb|image.det0|image.desc1|total"
 done
-OUT=pmc_conv3 bash tools/r3_pmc_conv.sh
-OUT=pmc_conv3_plain EINX_LIB=$GRAFT_REPO_ROOT/ab_libs/libeinx_plainpitch.so bash tools/r3_pmc_conv.sh
+OUT=pmc_conv3 bash tools/experiments/r3_pmc_conv.sh
+OUT=pmc_conv3_plain EINX_LIB=$GRAFT_REPO_ROOT/ab_libs/libeinx_plainpitch.so bash tools/experiments/r3_pmc_conv.sh

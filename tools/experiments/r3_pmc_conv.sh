@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --pmc passes over the conv layers (bench.py --layer-table).  Run on the GPU box from the repo root:
-#   OUT=pmc_conv3 [EINX_LIB=ab_libs/libeinx_X.so] bash tools/r3_pmc_conv.sh
+#   OUT=pmc_conv3 [EINX_LIB=ab_libs/libeinx_X.so] bash tools/experiments/r3_pmc_conv.sh
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=${OUT:-pmc_conv3}

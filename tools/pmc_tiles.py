@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes (one directory per counter set, as tools/r3_pmc_conv.sh writes them) into one
+"""Summarise rocprofv3 --pmc passes (one directory per counter set, as tools/experiments/r3_pmc_conv.sh writes them) into one
 per-kernel-variant table: LDS bank-conflict ratio, LDS issue stalls, MFMA-busy and the effective clock.
 
     python tools/pmc_tiles.py gpurun_out/pmc_conv3 [name-filter] > profiles/r03_pmc_conv_tiles.json
