@@ -34,7 +34,7 @@ class SameTimeEvaluator:
         dev = images.device
         events_rep = events_to_voxel_grid_batch(events_list, (self.bins, H, W), normalize=True, device=dev)
         events_mask = events_mask_batch(events_list, (W, H), device=dev)
-        self.last_inputs = (events_rep, events_mask)  # what the extractors saw (fp32 atomics: run-to-run last-bit noise)
+        self.last_inputs = (events_rep, events_mask)  # what the extractors saw (deterministic since round 4: bit-equal run to run)
         ef, imf, matches = self.model(events_rep, images, events_mask)
         rows = batch_metrics(ef._batched, imf._batched, self.model._last_match, homography, self.mma_thr, self.vdd_thr)
         ok = ~torch.isnan(rows)

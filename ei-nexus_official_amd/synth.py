@@ -125,6 +125,21 @@ def synth_image(seed, batch, height=260, width=346):
     return img
 
 
+def synth_raw_events(seed, n, height=260, width=346, hot=0.3):
+    """raw sensor events {"x","y","t","p"} (integer pixel coordinates, increasing float64 timestamps, polarity +-1) -- what the
+    reference's dataset hands datasets/representations.py::events_to_voxel_grid.  A share `hot` of them clusters in the
+    middle eighth of the sensor so that the accumulation image has a wide count range."""
+    u = uniform01(seed, (n,)).astype(np.float64)
+    t = 1.5e9 + np.cumsum(u * 1e-4 + 1e-6)
+    x = np.floor(uniform01(seed + 1, (n,)) * np.float32(width - 1))
+    y = np.floor(uniform01(seed + 2, (n,)) * np.float32(height - 1))
+    h = uniform01(seed + 4, (n,)) < np.float32(hot)
+    x = np.where(h, np.float32(width // 2) + np.floor(x / 8), x).astype(np.float32)
+    y = np.where(h, np.float32(height // 2) + np.floor(y / 8), y).astype(np.float32)
+    p = np.where(uniform01(seed + 3, (n,)) < np.float32(0.5), np.float32(1.0), np.float32(-1.0)).astype(np.float32)
+    return {"x": x, "y": y, "t": t, "p": p}
+
+
 def synth_unit_descriptors(seed, n, dim, scale=1.0):
     d = normalish(seed, (n, dim), lane=5).astype(np.float64)
     d = d / np.maximum(np.sqrt((d * d).sum(-1, keepdims=True)), 1e-12)

@@ -81,8 +81,10 @@ def nms_fixpoint(score, radius=4):
         score = torch.where(near & ~is_max.reshape(B, 1, H, W), torch.zeros_like(score), score)
 
 
-def extract(kind, sd, x, mask, top_k=1024, border=4, scale=1.0):
-    """-> per-image (positions [n,3] yx+score, descriptors [n,256])"""
+def extract(kind, sd, x, mask, top_k=1024, border=4, scale=1.0, dense=False):
+    """-> per-image (positions [n,3] yx+score, descriptors [n,256]); dense=True also builds the reference's dense outputs
+    (normalized_descriptors: the raw map resized to the padded image size, L2-normalised, x scale -- what dominates the
+    reference's CPU time)"""
     B, _, H, W = x.shape
     ph, pw = (-H) % 8, (-W) % 8
     h0, w0 = ph // 2, pw // 2
@@ -100,6 +102,10 @@ def extract(kind, sd, x, mask, top_k=1024, border=4, scale=1.0):
     score[:, :, -border:] = 0
     score[:, :, :, :border] = 0
     score[:, :, :, -border:] = 0
+    if dense:
+        up = F.normalize(F.interpolate(raw, size=score.shape[-2:], mode="bilinear", align_corners=False), dim=1) * scale
+        up = up[:, :, h0:h0 + H, w0:w0 + W].contiguous()  # un-padded
+        del up
     nms = nms_fixpoint(score)
     flat = nms.reshape(B, -1)
     N = flat.shape[1]
@@ -125,10 +131,10 @@ def mnn(d0, d1):
 
 
 @torch.no_grad()
-def sp_mnn_pairs(sd_event, sd_image, events, mask, image, top_k=1024):
+def sp_mnn_pairs(sd_event, sd_image, events, mask, image, top_k=1024, dense=False):
     """the whole SP+MNN pipeline for a batch; returns the number of mutual matches per pair"""
     te = {k: torch.from_numpy(v) for k, v in sd_event.items()}
     ti = {k: torch.from_numpy(v) for k, v in sd_image.items()}
-    fe = extract("vgg", te, torch.from_numpy(events), torch.from_numpy(mask), top_k)
-    fi = extract("superpointv1", ti, torch.from_numpy(image), None, top_k)
+    fe = extract("vgg", te, torch.from_numpy(events), torch.from_numpy(mask), top_k, dense=dense)
+    fi = extract("superpointv1", ti, torch.from_numpy(image), None, top_k, dense=dense)
     return [int((mnn(a[1], b[1]) > -1).sum()) for a, b in zip(fe, fi)], fe, fi

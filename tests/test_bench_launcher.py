@@ -71,3 +71,45 @@ def test_rank_env_is_honoured_without_relaunch():
     assert r.returncode == 0, r.stderr
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["pairs"] == 64
+
+
+def test_launcher_world_8_on_gloo_shards_512_pairs():
+    """BASELINE configs[4] as the driver launches it (N = 8, 64 pairs per GPU): the launcher, the rendezvous, the accumulator
+    all-reduce, the all-rank leg and the shard arithmetic at world 8 -- on gloo, no GPU (the 8-GPU run itself is the driver's)."""
+    r = _run("--gpus", "8", "--dry-run-gloo", "--steps", "2", "--config", "sp_lg")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 == d["world_env"]
+    assert d["config"]["pairs_per_gpu_per_step"] == 64 and d["config"]["global_batch"] == 512
+    assert d["pairs"] == 8 * 2 * 64
+    assert d["matches"] == 2 * 10 * sum(range(1, 9))
+    assert d["shard_ranges"] == [[64 * k, 64 * (k + 1)] for k in range(8)]  # contiguous, disjoint, covering 0..512
+    r = _run("--gpus", "8", "--dry-run-gloo", "--steps", "1")
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    leg = d["scale_legs"][0]
+    assert leg["n_gpus"] == 8 and leg["global_batch"] == 512 and leg["pairs_per_gpu_per_step"] == 64
+    assert leg["per_rank_pairs_per_s"]["min"] < leg["per_rank_pairs_per_s"]["max"]
+
+
+def test_dead_rank_at_world_8_stops_the_others_quickly():
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["EINX_BENCH_DRYRUN_FAIL_RANK"] = "5"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run-gloo", "--steps", "1"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 7, (r.returncode, r.stderr[-500:])
+    assert "rank 5 exited with status 7" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 120  # the other seven ranks were stopped, nobody waits for the rendezvous timeout
+
+
+def test_gpu_max_hw_queues_defaults_inside_ranks():
+    """RCCL's streams take hardware queues; ranks default GPU_MAX_HW_QUEUES to 8 unless the caller set it."""
+    code = "import os, sys; sys.argv=['bench.py']; import importlib.util as u; s=u.spec_from_file_location('b', %r); m=u.module_from_spec(s); s.loader.exec_module(m); print(os.environ['GPU_MAX_HW_QUEUES'])" % BENCH
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout.strip() == "2"
