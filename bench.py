@@ -155,7 +155,7 @@ def leg_record(config, batch, steps, world, elapsed_max, pairs_total, per_rank_p
     return e
 
 
-def all_rank_leg(pkg, dev, config, batch, steps, rank, world, dist=None, local=0, warmup=3):
+def all_rank_leg(pkg, dev, config, batch, steps, rank, world, dist=None, local=0, warmup=8):
     """Every rank builds the workload on its own shard of the pair index space and times `steps` forwards; returns
     (record on rank 0 | None, workload).  No data-path collective: a barrier on both sides, MAX of the elapsed time, SUM of pairs."""
     import torch
@@ -917,9 +917,11 @@ def run_rank(args):
             del w
             torch.cuda.empty_cache()
             extras.append(harness_leg(pkg, wl, torch))
-            w = leg("sp_mnn", 1, steps=50, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
+            # single pairs: the first ~15 forwards after a weight (re)load can contain one-off host stalls of 30-80 ms (measured:
+            # profiles/r04_notes.md; none in the 285 forwards that follow), so these legs start after 15 un-timed forwards
+            w = leg("sp_mnn", 1, steps=50, init=15, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
             del w
-            w = leg("sp_lg", 1, steps=30, note="single-pair latency with the LightGlue matcher (configs/model/test/EI_SP_LG.yaml evaluated pair by pair): ms_per_step is ms per pair")
+            w = leg("sp_lg", 1, steps=30, init=15, note="single-pair latency with the LightGlue matcher (configs/model/test/EI_SP_LG.yaml evaluated pair by pair): ms_per_step is ms per pair")
             del w
             sec, mm = timed_stream(wl, 20)
             extras.append({"config": "sp_mnn", "workload": f"B{B} " + WORKLOADS["sp_mnn"][2], "pairs_per_step": B,

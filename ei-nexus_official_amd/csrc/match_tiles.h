@@ -2,6 +2,8 @@
 // assignment (lightglue.hip): similarity tiles on the fp32 matrix cores with fused arg-max /
 // softmax statistics / log-assignment epilogues.  See mnn.hip for the design notes.
 #pragma once
+#include <type_traits>
+
 #include "gemm_tile.h"
 
 namespace einx_match {
@@ -82,7 +84,82 @@ __global__ __launch_bounds__(THREADS) void mnn_tile_kernel(const MnnArgs a) {
       }
   }
 
-  if (MODE == 0 || MODE == 5 || MODE == 6) {
+  if ((MODE == 0 || MODE == 5 || MODE == 6) && MT == 1) {
+    // Round 4: the arg-max epilogue as packed 64-bit keys (ordered value << 32 | ~index: the maximum key IS the first maximum).
+    //  * columns: the lane scans its 16 rows, the two lane halves meet once;
+    //  * rows: instead of 16 separate 32-lane reductions of (value, index) pairs (160 cross-lane moves, 16 atomics of 2
+    //    lanes), a butterfly reduce-scatter -- at distance 16, 8, 4, 2 a lane keeps one half of its rows and hands the other
+    //    half to its partner (8 + 4 + 2 + 1 keys move), distance 1 completes the row -- after which every lane pair owns ONE
+    //    row: 30 cross-lane key moves, no LDS address arithmetic (ds_swizzle);
+    //  * the keys of the tile's 128 columns (4 row-waves) and 128 rows (2 column-waves) meet in LDS, so the tile issues
+    //    256 global atomics instead of 768.
+    unsigned long long* kst = reinterpret_cast<unsigned long long*>(lds);  // [4][128] column keys, then [2][128] row keys
+    const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, l = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float bv = NEG;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + row_of(0, r);
+        const float v = f.acc[0][nt][r];
+        if (i < n && (v > bv || bi == 0x7fffffff)) {  // ascending i, strict >: the first maximum
+          bv = v;
+          bi = i;
+        }
+      }
+      unsigned long long key = bi != 0x7fffffff ? pack_key(bv, bi) : 0ull;
+      const unsigned long long ok = ((unsigned long long)(unsigned)__shfl_xor((int)(key >> 32), 32, 64) << 32) | (unsigned)__shfl_xor((int)key, 32, 64);
+      key = ok > key ? ok : key;  // the other lane half holds the interleaved rows of the same column
+      if (half == 0) kst[wm * 128 + wn * 64 + nt * 32 + l] = key;
+    }
+    {
+      unsigned long long key[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ja = j0 + col_of(0), jb = j0 + col_of(1);
+        const float va = f.acc[0][0][r], vb = f.acc[0][1][r];
+        const bool tb = jb < m && (!(ja < m) || vb > va);  // strict >: the lower column wins a tie
+        key[r] = (ja < m || jb < m) ? pack_key(tb ? vb : va, tb ? jb : ja) : 0ull;
+      }
+      auto swz = [](unsigned long long v, auto pat) -> unsigned long long {
+        constexpr int P = decltype(pat)::value;
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_ds_swizzle((int)(v >> 32), P) << 32) | (unsigned)__builtin_amdgcn_ds_swizzle((int)v, P);
+      };
+      auto step = [&](unsigned long long* k, int cnt, bool up, auto pat) {  // k[0..cnt) <- reduce-scatter of k[0..2cnt) with lane ^ distance
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < cnt) {
+            const unsigned long long keep = up ? k[q + cnt] : k[q], send = up ? k[q] : k[q + cnt];
+            const unsigned long long got = swz(send, pat);
+            k[q] = got > keep ? got : keep;
+          }
+      };
+      step(key, 8, (l & 16) != 0, std::integral_constant<int, (16 << 10) | 0x1F>());
+      step(key, 4, (l & 8) != 0, std::integral_constant<int, (8 << 10) | 0x1F>());
+      step(key, 2, (l & 4) != 0, std::integral_constant<int, (4 << 10) | 0x1F>());
+      step(key, 1, (l & 2) != 0, std::integral_constant<int, (2 << 10) | 0x1F>());
+      const unsigned long long o = swz(key[0], std::integral_constant<int, (1 << 10) | 0x1F>());
+      const unsigned long long k = o > key[0] ? o : key[0];
+      const int r = ((l >> 4) & 1) * 8 + ((l >> 3) & 1) * 4 + ((l >> 2) & 1) * 2 + ((l >> 1) & 1);  // the row this lane pair ended up with
+      if ((l & 1) == 0) kst[512 + wn * 128 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = k;
+    }
+    __syncthreads();
+    {
+      const int t = threadIdx.x;
+      if (t < 128) {
+        unsigned long long k = kst[t];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) k = kst[w * 128 + t] > k ? kst[w * 128 + t] : k;
+        if (j0 + t < m && k) atomicMax(&a.colkey[(size_t)b * a.cap1 + j0 + t], k);
+      } else if (t < 256) {
+        const int r = t - 128;
+        const unsigned long long ka = kst[512 + r], kb = kst[512 + 128 + r];
+        const unsigned long long k = kb > ka ? kb : ka;
+        if (i0 + r < n && k) atomicMax(&a.rowkey[(size_t)b * a.cap0 + i0 + r], k);
+      }
+    }
+  } else if (MODE == 0 || MODE == 5 || MODE == 6) {
     // ---- column arg-max over this wave's 64 rows (ascending i, strict > keeps the first) ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
