@@ -74,7 +74,10 @@ constexpr int conv_lds_pitch(int th, int tw) {
 // EXACT: Cin is a whole multiple of CK (every layer but the thin first ones): chunks reload through
 // constant per-thread element offsets from a uniform base pointer that advances with the chunk, with
 // no per-element multiplies, clamps or 64-bit address arithmetic in the steady state.
-template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool EXACT>
+// XTRA (1x1 layers with 64 n + 1 output channels: the detector's 65): the last channel is NOT given a channel tile of its own
+// (63 of 64 rows padding: half of the 256 -> 65 layer's matrix-core time); the workgroups of the last whole tile
+// accumulate it beside their MFMAs, one pixel per lane, as the same k-ordered fmaf chain from +0 (v_fma_f32 on the LDS tile).
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool EXACT, bool XTRA = false>
 #ifndef EINX_THIN_WAVES
 #define EINX_THIN_WAVES 6  // thin first layers: cap registers so three 8-wave workgroups share a CU (their load -> MFMA -> store phases only overlap across workgroups)
 #endif
@@ -233,6 +236,9 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
 
   const int pairs_total = (a.Cin + 1) / 2;
   const int nchunks = (pairs_total * 2 + CK - 1) / CK;
+  static_assert(!XTRA || (KS == 1 && NPIX <= NTHR && !POOL), "the extra channel is a 1x1 feature: one pixel per thread");
+  float xacc = 0.0f;                                                      // XTRA: the extra channel of pixel p0 + tid
+  const bool xtra_wg = XTRA && co0 + kCoutTile == a.CoutPad - kCoutTile;  // the last whole channel tile carries it
 
   // Register image of one chunk in flight (global -> registers -> LDS).  DEPTH chunks are in flight: the loads of chunk
   // c + DEPTH are issued when chunk c has been committed to LDS, i.e. they have DEPTH chunks of MFMAs to land.
@@ -339,6 +345,11 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
 #endif
     if (c + DEPTH < nchunks) issue_loads(c + DEPTH, sr);  // in flight under the MFMAs of the next DEPTH chunks
     mfma_chunk();
+    if (XTRA && xtra_wg && tid < NPIX) {  // rows of a 1x1 layer's native weight image are the input channels in order
+      const float* wx = a.w + (size_t)c * W_ROWS * a.CoutPad + (a.CoutPad - kCoutTile);
+#pragma unroll
+      for (int r = 0; r < CK; ++r) xacc = fmaf(wx[(size_t)r * a.CoutPad], in_tile[r * PLANE + tid], xacc);
+    }
   };
   issue_loads(0, sA);
   if (DEPTH == 2) {
@@ -354,6 +365,13 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store -------------------------
   const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
   float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
+  if (XTRA && xtra_wg && tid < NPIX && p0 + tid < HW) {
+    const int co = a.CoutPad - kCoutTile;  // == Cout - 1
+    float v = xacc + (a.bias ? a.bias[co] : 0.0f);
+    if (a.relu) v = v > 0.0f ? v : 0.0f;
+    if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+    out_b[(size_t)co * HW + p0 + tid] = v;
+  }
   // Pooling happens in registers: a 2x2 window is {lane j, lane j^1} horizontally and, vertically,
   // either the wave's neighbouring N-tile (TW == 32: tiles nt, nt+1 are rows 2k, 2k+1) or lane
   // j^TW inside one N-tile (TW in {8,16}: an N-tile holds 32/TW whole rows).
@@ -723,8 +741,9 @@ struct TileCfg {
 template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
 void launch(const ConvArgs& a, int B, hipStream_t s) {
   // the offset-table reload (EXACT) is used where it measured faster (bench.py --layer-table, B=32): every
-  // 3x3 tile except 11x22, whose 768-workgroup launches on the 256-channel heads ran 20 % slower with it
-  const bool exact = (a.Cin % CK) == 0 && KS == 3 && (!(TH == 11 && TW == 22) || ((conv_exp() & 8) && a.Cin <= 64));
+  // 3x3 tile except 11x22, whose 768-workgroup launches on the 256-channel heads ran 20 % slower with it, and (round 4)
+  // the heads' 1x1 layers (256 -> 65: 42.0 -> 36.2 us, 256 -> 256: 75.7 -> 73.4 us; 64-channel chunks measured slower)
+  const bool exact = (a.Cin % CK) == 0 && (!(TH == 11 && TW == 22) || ((conv_exp() & 8) && a.Cin <= 64));
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
   {
     // name of the instantiation this call launches (einx_conv_last_kernel: measurement provenance)
@@ -840,7 +859,16 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     }
     if (blocks256 < 1024) {
       a.tilesX = einx_cdiv(H * W, 128);
-      launch<1, 1, 128, 1, 4, 2, 1, 32, false>(a, B, s);
+      static const bool no_xtra = getenv("EINX_CONV_NO_XTRA") != nullptr;
+      if (d->cout == a.CoutPad - kCoutTile + 1 && d->cout > kCoutTile && d->cin % 32 == 0 && !no_xtra) {
+        // 64 n + 1 output channels (the detector's 65): n channel tiles, the last one also carries channel 64 n (see XTRA)
+        dim3 grid((unsigned)(a.tilesX * B), (unsigned)(a.CoutPad / kCoutTile - 1));
+        g_last_conv_kernel = "conv_block_kernel<1,1,128,1,4,2,1,32,false,true,xtra>";
+        EINX_PROF("conv_block_kernel 1x1", s);
+        hipLaunchKernelGGL((conv_block_kernel<1, 1, 128, 1, 4, 2, 1, 32, false, true, true>), grid, dim3(256), 0, s, a);
+      } else {
+        launch<1, 1, 128, 1, 4, 2, 1, 32, false>(a, B, s);
+      }
     } else {
       a.tilesX = einx_cdiv(H * W, 256);
       launch<1, 1, 256, 1, 4, 2, 2, 32, false>(a, B, s);
