@@ -288,7 +288,7 @@ class Workload:
             self.sd.update(synth.twin_overrides(self.sd))
         model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()}, strict=False)
         for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
-            ext.dense_outputs = bool(dense)
+            ext.dense_outputs = "lazy" if dense == "lazy" else bool(dense)
         model.matcher.matcher.want_log_assignment = bool(log_assignment)
         # synthetic pairs: each rank gets its own shard of the global pair index space
         self.ev_np, self.mask_np = synth.synth_events(10_000 + rank * B, B, ce)
@@ -916,10 +916,37 @@ def run_rank(args):
             stages.append(dense_stage_roofline(w))
             del w
             torch.cuda.empty_cache()
+            # the package default since round 4: the same dict, its dense entries computed when a caller first reads them
+            w = Workload(pkg, dev, "sp_mnn", 32, dense="lazy", log_assignment=True)
+            sec, mm = w.timed(10, init=4)
+            extras.append({"config": "sp_mnn", "workload": "B32 " + WORKLOADS["sp_mnn"][2], "pairs_per_step": 32, "calibrated_descriptors": True,
+                           "value": round(32 / sec, 2), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10, "mean_matches": round(mm, 1),
+                           "note": "package default (dense_outputs='lazy' + log_assignment): every key of the reference's dict is present; "
+                                   "normalized_descriptors / dense_descriptors / dense_positions are computed by the same kernels when first read "
+                                   "(this leg, like the reference's evaluation scripts, never reads them; the leg above reads nothing either but "
+                                   "computes them in the forward)"})
+            del w
+            torch.cuda.empty_cache()
             extras.append(harness_leg(pkg, wl, torch))
             # single pairs: the first ~15 forwards after a weight (re)load can contain one-off host stalls of 30-80 ms (measured:
             # profiles/r04_notes.md; none in the 285 forwards that follow), so these legs start after 15 un-timed forwards
             w = leg("sp_mnn", 1, steps=50, init=15, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
+            del w
+            # the same single pair through EIM.forward_graph: the device side of the forward captured once into a hipGraph
+            w.model.forward_graph(w.ev, w.img_src, w.mask)
+            for _ in range(15):
+                w.model.forward_graph(w.ev, w.img_src, w.mask)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(100):
+                _, _, mg = w.model.forward_graph(w.ev, w.img_src, w.mask)
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - tg) / 100
+            extras.append({"config": "sp_mnn", "workload": "B1 " + WORKLOADS["sp_mnn"][2], "pairs_per_step": 1, "calibrated_descriptors": True,
+                           "same_scene_pairs": False, "value": round(1 / sec, 2), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 3), "steps": 100,
+                           "mean_matches": float(mg["matched_kpts0"][0].shape[0]),
+                           "note": "single-pair latency through EIM.forward_graph (opt-in latency mode: the ~60 launches of a forward replayed as ONE "
+                                   "hipGraph launch, outputs live in graph-owned buffers until the next call; same kernels and outputs as forward)"})
             del w
             w = leg("sp_lg", 1, steps=30, init=15, note="single-pair latency with the LightGlue matcher (configs/model/test/EI_SP_LG.yaml evaluated pair by pair): ms_per_step is ms per pair")
             del w

@@ -29,10 +29,75 @@ def _size_tensor(H, W, dev):
     return t
 
 
+class _Lazy:
+    """value of a FeatsDict entry that is computed when it is first read"""
+    __slots__ = ("fn",)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __repr__(self):
+        return "<einx: computed on first access>"
+
+
 class FeatsDict(dict):
     """The reference's feature dict plus a handle on the device-side batch (`_batched`) so that the
-    matcher can consume it without re-packing the per-image lists."""
+    matcher can consume it without re-packing the per-image lists.
+
+    Round 4 ("dense outputs on demand"): with `dense_outputs = "lazy"` (the default) the dense by-products --
+    `normalized_descriptors` [B,C,H,W] (2.95 GB per side at B=32), `dense_descriptors`, `dense_positions` -- are dict entries
+    from the start (same keys as the reference's dict) whose VALUES are computed by the same kernels when they are first
+    read, on the stream current at that moment.  A caller that only reads the sparse outputs (the reference's evaluation
+    scripts) never pays for them; a caller that reads them gets the tensors the eager mode would have produced, provided it
+    has not modified `raw_descriptors` / `score` in place in between.  Every read path resolves them: d[k], get, items,
+    values, pop, setdefault, copy, iteration-based copies (`dict(d)`, `{**d}`: __iter__ is overridden so that CPython's
+    merge takes the generic keys() + __getitem__ route)."""
     _batched = None
+
+    def _resolve(self, k, v):
+        if isinstance(v, _Lazy):
+            v = v.fn(self)  # the dict it is read from (EIM.forward_graph re-issues the same lazy entries in a fresh dict per call)
+            dict.__setitem__(self, k, v)
+        return v
+
+    def __getitem__(self, k):
+        return self._resolve(k, dict.__getitem__(self, k))
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+    def pop(self, k, *default):
+        if k in self:
+            v = self[k]
+            dict.__delitem__(self, k)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(k)
+
+    def setdefault(self, k, default=None):
+        if k in self:
+            return self[k]
+        dict.__setitem__(self, k, default)
+        return default
+
+    def copy(self):
+        out = FeatsDict(self.items())
+        out._batched = self._batched
+        return out
+
+    def lazy_keys(self):
+        """keys whose values have not been computed yet (tests / tools)"""
+        return [k for k in dict.keys(self) if isinstance(dict.__getitem__(self, k), _Lazy)]
 
 
 class BatchedFeats:
@@ -53,6 +118,7 @@ class BatchedFeats:
         self.shift = 0.0  # padding=0 networks: keypoints are mapped back by +9 (mapping_positions)
         self.ordering = "yx"
         self.dense = False
+        self.dense_lazy = False
         self._prepared = None
         self._full_lists = None
         self._ns = None
@@ -69,7 +135,7 @@ class BatchedFeats:
     def run_dense(self):
         """The dense by-product (`normalized_descriptors`: upsample + normalise, cropped), enqueued on the CURRENT stream.  Part
         of the extractor call unless the caller deferred it (EIM schedules it beside the other extractor's convolutions)."""
-        if not self.dense or self.normalized is not None:
+        if not (self.dense or self.dense_lazy) or self.normalized is not None:
             return
         w0, w1, h0, h1 = self.pads
         Hp, Wp = self.padded
@@ -100,21 +166,48 @@ class BatchedFeats:
         out["nms"] = None  # filled by materialize (a re-detection replaces it)
         if self.cell == 8:
             out["coarse_descriptors"] = self.coarse
+        def dense_descriptors(d):
+            nd = d["normalized_descriptors"]
+            return [nd[b].permute(1, 2, 0).reshape(-1, nd.shape[1]) for b in range(self.B)]
+
+        def dense_positions(d):
+            with torch.cuda.device(self.score.device):
+                dp = N.dense_positions(dict.__getitem__(d, "score"), self.ordering)
+                if self.shift:
+                    dp[:, :, :2] += self.shift
+            return list(dp.unbind(0))
+
         if self.dense:
             self.run_dense()  # no-op unless a caller deferred it and never ran it
-            nd = self.normalized
-            out["normalized_descriptors"] = nd
-            C = nd.shape[1]
-            out["dense_descriptors"] = [nd[b].permute(1, 2, 0).reshape(-1, C) for b in range(self.B)]
-            dp = N.dense_positions(out["score"], self.ordering)
-            if self.shift:
-                dp[:, :, :2] += self.shift
-            out["dense_positions"] = list(dp.unbind(0))
+            out["normalized_descriptors"] = self.normalized
+            out["dense_descriptors"] = dense_descriptors(out)
+            out["dense_positions"] = dense_positions(out)
+        elif self.dense_lazy:
+            def normalized(d):
+                with torch.cuda.device(self.raw.device):
+                    self.run_dense()
+                return self.normalized
+
+            for k, fn in (("normalized_descriptors", normalized), ("dense_descriptors", dense_descriptors), ("dense_positions", dense_positions)):
+                dict.__setitem__(out, k, _Lazy(fn))
         # speculative per-image lists for the common case that every image fills its top-k quota
         # (checked against the real counts in materialize)
         self._full_lists = (self.det, list(self.sparse_desc.unbind(0)), list(self.det.positions.unbind(0)))
         self._prepared = out
         return out
+
+    def prepared_template(self):
+        """EIM.forward_graph: the count-independent part of the dict as built during capture (its tensors are graph-owned
+        buffers refreshed by every replay); lazy entries stay lazy"""
+        out = self.prepare()
+        return [(k, dict.__getitem__(out, k)) for k in dict.keys(out)]
+
+    def reuse_prepared(self, template):
+        out = FeatsDict()
+        for k, v in template:
+            dict.__setitem__(out, k, v)
+        self._prepared = out
+        self.normalized = None if self.dense_lazy else self.normalized
 
     def materialize(self, counts_host):
         """counts_host: python ints per image (already clamped by the caller's sync)."""
@@ -218,7 +311,8 @@ class ExtractorEngine:
         bf = BatchedFeats()
         bf.kind, bf.cell, bf.B = self.kind, self.cell, B
         bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
-        bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
+        bf.scale, bf.ordering, bf.dense_lazy = float(scale), self.ordering, (isinstance(dense, str) and dense == "lazy")
+        dense = bf.dense = bool(dense) and not bf.dense_lazy
         bf.feats, bf.logits, bf.raw = e(B, sh.feat_channels, hc, wc), e(B, sh.det_channels, hc, wc), e(B, D, hc, wc)
         bf.prob, bf.score = e(B, sh.det_channels, hc, wc), e(B, 1, Hp, Wp)
         if self.cell == 8:
@@ -336,7 +430,8 @@ class ExtractorEngine:
         bf.kind, bf.cell, bf.B = self.kind, self.cell, B
         bf.image_size, bf.pads, bf.padded = (H, W), pads, (Hp, Wp)
         bf.shift = float(crop)
-        bf.scale, bf.ordering, bf.dense = float(scale), self.ordering, dense
+        bf.scale, bf.ordering, bf.dense_lazy = float(scale), self.ordering, (isinstance(dense, str) and dense == "lazy")
+        dense = bf.dense = bool(dense) and not bf.dense_lazy
         # dense by-products first: they depend only on `raw`, so they run under the other stream's
         # convolutions instead of lengthening the latency-bound detection tail at the end of the step
         if self.cell == 8:

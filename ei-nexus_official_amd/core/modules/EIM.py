@@ -60,7 +60,7 @@ class EIM(nn.Module):
         The event and image extractors share nothing, so the event side is enqueued on a second HIP
         stream: its small late layers and its latency-bound NMS/selection kernels overlap the other
         side's convolutions instead of leaving most of the 256 CUs idle."""
-        dense = bool(self.event_extractor.extractor.dense_outputs and self.image_extractor.extractor.dense_outputs)
+        dense = self.event_extractor.extractor.dense_outputs is True and self.image_extractor.extractor.dense_outputs is True
         if dense and self.overlap_extractors and self.dense_schedule and events.device.type == "cuda":
             # Experiment (EINX_DENSE_SCHEDULE=1): event extractor first, then the image extractor on the caller's stream WHILE the
             # event side's dense kernels (an HBM-bound store of 2.95 GB at B=32) run on the side stream; the image side's dense
@@ -93,8 +93,11 @@ class EIM(nn.Module):
                 ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
             im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared)
             cur.wait_stream(side)
-            for t in (ev.feats, ev.logits, ev.raw, ev.raw_cl, ev.prob, ev.score, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
-                      ev.det.indices, ev.det.counts, ev.det.thr, ev.det.not_converged, ev.det.nms):
+            # (under graph capture the allocations come from the graph's private pool and are never recycled, and
+            # record_stream on them makes hipStreamEndCapture crash)
+            for t in (() if torch.cuda.is_current_stream_capturing() else
+                      (ev.feats, ev.logits, ev.raw, ev.raw_cl, ev.prob, ev.score, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
+                       ev.det.indices, ev.det.counts, ev.det.thr, ev.det.not_converged, ev.det.nms)):
                 if t is not None:
                     t.record_stream(cur)  # allocated on the side stream, consumed on the caller's stream
         else:
@@ -145,7 +148,8 @@ class EIM(nn.Module):
     def _finish(self, p):
         """Host side of one forward: wait for the two read-backs, cut the per-pair lists."""
         ev, im, mr, pre = p["ev"], p["im"], p["mr"], p["pre"]
-        p["det_event"].synchronize()
+        if p["det_event"] is not None:  # None: graph mode, the stream has been synchronised
+            p["det_event"].synchronize()
         host = p["det_host"]
         nm_host, nm_event = p.get("nm_host"), p["nm_event"]
         retries = 0
@@ -196,6 +200,59 @@ class EIM(nn.Module):
         runs; the per-pair match counts follow.  Both copies complete before this function returns: from the
         caller's point of view it is one synchronous forward like the reference's."""
         return self._finish(self._enqueue(events, image, events_mask, image_mask))
+
+    # ------------------------------------------------------------------ latency mode: the forward as ONE hipGraph launch
+    def forward_graph(self, events, image, events_mask=None, image_mask=None):
+        """Latency mode for single pairs / small batches (the reference's evaluation loop calls the model pair by pair,
+        test_events-image_same-time.py:130-194): the device side of `forward` -- both extractors, their side streams, the
+        matcher and the two count read-backs, ~60 launches -- is captured ONCE per input geometry into a hipGraph
+        (torch.cuda.CUDAGraph) and replayed with one launch per call; the host then only cuts the per-pair lists.
+        Same kernels, same outputs as `forward`, with the contract of a captured graph:
+          * the returned tensors live in buffers the graph owns: they are valid until the NEXT forward_graph call with the
+            same geometry overwrites them (clone what must survive);
+          * inputs are copied into the graph's input buffers, so SuperPoint's in-place `image /= 255` (reference quirk)
+            happens on that copy, not on the caller's tensor;
+          * a forward whose NMS fix-point needs more passes than the captured budget falls back to the eager `forward`;
+          * weights are read at replay time (edits through load_state_dict need a new capture: call `reset_graphs()`)."""
+        key = (tuple(events.shape), tuple(image.shape), None if events_mask is None else tuple(events_mask.shape),
+               None if image_mask is None else tuple(image_mask.shape), str(events.device))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            g = graphs[key] = self._capture(events, image, events_mask, image_mask)
+        cur = torch.cuda.current_stream(events.device)
+        for dst, src in zip(g["inputs"], (events, image, events_mask, image_mask)):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        g["graph"].replay()
+        cur.synchronize()
+        p = g["p"]
+        host = p["det_host"]
+        if bool(host[2].any()) or bool(host[3].any()):  # rare: pass budget exceeded -> the eager path with its retry
+            return self.forward(events, image, events_mask, image_mask)
+        for bf, tmpl in ((p["ev"], g["prep_ev"]), (p["im"], g["prep_im"])):
+            bf.reuse_prepared(tmpl)
+        return self._finish(dict(p, det_event=None, nm_event=None))
+
+    def reset_graphs(self):
+        self.__dict__.pop("_graphs", None)
+
+    @on_input_device
+    def _capture(self, events, image, events_mask, image_mask):
+        dev = events.device
+        static = [None if t is None else t.clone() for t in (events, image, events_mask, image_mask)]
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            for _ in range(3):  # builds the native weight images, the library's side streams / events for THIS stream, the pinned buffers
+                static[1].copy_(image)
+                self._finish(self._enqueue(*static, slot="g"))
+            static[1].copy_(image)
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            p = self._enqueue(*static, slot="g")
+        return {"graph": graph, "inputs": static, "p": p, "prep_ev": p["ev"].prepared_template(), "prep_im": p["im"].prepared_template()}
 
     def forward_stream(self, batches, depth=2):
         """Throughput mode for evaluation loops (the reference's scripts iterate a DataLoader and call the model once per

@@ -31,7 +31,9 @@ class NativeExtractor(nn.Module):
         self.ordering = ordering
         self.descriptor_scale_factor = nn.parameter.Parameter(torch.tensor(float(descriptor_scale_factor)),
                                                               requires_grad=learnable_descriptor_scale_factor)
-        self.dense_outputs = True  # reference-complete dict; set False to skip the 92 MB/image dense maps
+        # "lazy" (default): the reference-complete dict whose dense maps (92 MB / image) are computed when first read
+        # (_extract.FeatsDict); True: computed in the forward; False: keys absent
+        self.dense_outputs = "lazy"
         self._engine = None
         self._scale_host = None
         self._sig = None

@@ -961,6 +961,12 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
           pick = i;
         }
       }
+      {  // tuning aid: force the candidate (tools only)
+        static const int force_p = getenv("EINX_CONV_SMALL_PICK_P") ? atoi(getenv("EINX_CONV_SMALL_PICK_P")) : -1;
+        static const int force_n = getenv("EINX_CONV_SMALL_PICK_N") ? atoi(getenv("EINX_CONV_SMALL_PICK_N")) : -1;
+        const int f = d->pool ? force_p : force_n;
+        if (f >= 0 && f < nc) pick = f;
+      }
       a.tilesX = einx_cdiv(W, cand[pick].tw);
       a.tilesY = einx_cdiv(H, cand[pick].th);
       if (d->pool) {

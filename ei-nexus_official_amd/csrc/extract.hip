@@ -250,7 +250,11 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
   p += align256(pl.buf_elems[1] * B * sizeof(float));
   float* head = (float*)p;
   p += align256(pl.head_elems * B * sizeof(float));
-  const bool fork = fork_heads(e, pl, B);
+  bool fork = fork_heads(e, pl, B);
+  {  // a fork nested inside a caller's own fork crashes hipStreamEndCapture (ROCm 7.2): under capture the branches stay in line
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (fork && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fork = false;
+  }
   float* head2 = head;  // the descriptor head's own scratch when the two branches run concurrently
   if (fork) {
     head2 = (float*)p;

@@ -350,7 +350,8 @@ size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int c
  * a join event of `stream`; every return path has `stream` wait for the join.  The side stream and its two events are created
  * on the FIRST such call for a (device, stream) pair and belong to the handle -- so make one un-captured call per stream
  * before capturing einx_extract into a hipGraph (stream / event creation is not capturable), and destroy the handle only
- * after the streams it served have drained.  Calls through one handle on one stream are serialised on a mutex. */
+ * after the streams it served have drained.  While `stream` is being captured the branches are enqueued in line (no fork: a
+ * fork nested in a caller's own fork / join makes hipStreamEndCapture of ROCm 7.2 crash).  Calls through one handle on one stream are serialised on a mutex. */
 int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
                  size_t ws_bytes, const einx_extract_out* out, void* stream);
 

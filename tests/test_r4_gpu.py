@@ -64,3 +64,66 @@ def test_nms_slow_converging_maps_finish_on_device_or_through_the_retry(oracle):
 
 def test_shipped_library_is_not_a_timing_only_build():
     assert pkg.native.lib().einx_build_flags() == b""
+
+
+def test_dense_outputs_on_demand_equal_the_eager_ones():
+    """dense_outputs="lazy" (the package default): the dict carries the reference's dense keys from the start; their values
+    are computed on first access -- through d[k], get, items, values, dict(d), {**d} alike -- and equal what the eager mode
+    (dense_outputs=True) computes inside the forward."""
+    from helpers import synth
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    models = []
+    for mode in ("lazy", True):
+        m = pkg.EIM(cfg, device=DEV).eval()
+        sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=21)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert m.event_extractor.extractor.dense_outputs == "lazy"  # default
+        for ext in (m.event_extractor.extractor, m.image_extractor.extractor):
+            ext.dense_outputs = mode
+        models.append(m)
+    ev, mask = synth.synth_events(5, 2, 5, 96, 128)
+    img = synth.synth_image(5, 2, 96, 128)
+    le, li, _ = models[0](_t(ev), _t(img), _t(mask))
+    ee, ei, _ = models[1](_t(ev), _t(img), _t(mask))
+    dense_keys = ["dense_descriptors", "dense_positions", "normalized_descriptors"]
+    for lazy, eager in ((le, ee), (li, ei)):
+        assert sorted(lazy.keys()) == sorted(eager.keys())
+        assert sorted(lazy.lazy_keys()) == dense_keys and eager.lazy_keys() == []
+        assert torch.equal(lazy["sparse_positions"][0], eager["sparse_positions"][0]) and sorted(lazy.lazy_keys()) == dense_keys
+    assert torch.equal(le["normalized_descriptors"], ee["normalized_descriptors"])  # d[k]
+    assert sorted(le.lazy_keys()) == ["dense_descriptors", "dense_positions"]
+    assert all(torch.equal(a, b) for a, b in zip(le.get("dense_descriptors"), ee["dense_descriptors"]))  # get
+    assert all(torch.equal(a, b) for a, b in zip(dict(le.items())["dense_positions"], ee["dense_positions"]))  # items
+    assert le.lazy_keys() == []
+    plain = dict(li)  # CPython's dict() / {**d} merge goes through keys() + __getitem__ for this subclass
+    assert torch.equal(plain["normalized_descriptors"], ei["normalized_descriptors"]) and li.lazy_keys() == []
+    assert all(torch.equal(a, b) for a, b in zip({**li}["dense_positions"], ei["dense_positions"]))
+
+
+@pytest.mark.parametrize("cfg_name,B", [("SP_MNN", 1), ("SP_LG", 1), ("SP_MNN", 3)])
+def test_forward_graph_equals_forward(cfg_name, B):
+    """EIM.forward_graph (one hipGraph launch per forward) returns what EIM.forward returns, call after call, also when the
+    inputs change between calls and when the dense entries are read on demand."""
+    from helpers import synth
+    cfg = pkg.default_config(cfg_name, event_channels=5)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=23)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for it in range(3):
+        ev, mask = synth.synth_events(40 + it, B, 5)
+        img = synth.synth_image(40 + it, B)
+        ef, imf, m = model(_t(ev), _t(img), _t(mask))
+        exp = {"pos": [p.clone() for p in ef["sparse_positions"]], "desc": [d.clone() for d in imf["sparse_descriptors"]],
+               "m0": [t.clone() for t in m["matches0"]], "mk": [t.clone() for t in m["matched_kpts1"]],
+               "nd": ef["normalized_descriptors"].clone() if it == 1 else None, "score": imf["score"].clone()}
+        img_t = _t(img)
+        gf, gi, gm = model.forward_graph(_t(ev), img_t, _t(mask))
+        assert np.array_equal(_np(img_t), img)  # the graph scales its own copy of the image
+        for b in range(B):
+            assert torch.equal(gf["sparse_positions"][b], exp["pos"][b]) and torch.equal(gi["sparse_descriptors"][b], exp["desc"][b])
+            assert torch.equal(gm["matches0"][b], exp["m0"][b]) and torch.equal(gm["matched_kpts1"][b], exp["mk"][b])
+        assert torch.equal(gi["score"], exp["score"])
+        assert sorted(gf.keys()) == sorted(ef.keys())
+        if exp["nd"] is not None:
+            assert torch.equal(gf["normalized_descriptors"], exp["nd"])  # lazy entry resolved against THIS replay's buffers
+    assert len(model._graphs) == 1
