@@ -931,7 +931,6 @@ def run_rank(args):
             # single pairs: the first ~15 forwards after a weight (re)load can contain one-off host stalls of 30-80 ms (measured:
             # profiles/r04_notes.md; none in the 285 forwards that follow), so these legs start after 15 un-timed forwards
             w = leg("sp_mnn", 1, steps=50, init=15, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
-            del w
             # the same single pair through EIM.forward_graph: the device side of the forward captured once into a hipGraph
             w.model.forward_graph(w.ev, w.img_src, w.mask)
             for _ in range(15):
