@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 PR = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def last_json_line(path):
@@ -47,7 +47,8 @@ def main():
                                  "--no-cpu-baseline --no-extras") + "\n")
                 fo.write(open(os.path.join(EV, src + ".err")).read())
                 fo.write(open(os.path.join(EV, src + ".json")).read())
-    for src, dst in (("layer_table.txt", "conv_layer_table.txt"), ("latency_b1.txt", "latency_b1.txt"), ("latency_b1_lg.txt", "latency_b1_sp_lg.txt")):
+    for src, dst in (("layer_table.txt", "conv_layer_table.txt"), ("latency_b1.txt", "latency_b1.txt"), ("latency_b1_lg.txt", "latency_b1_sp_lg.txt"),
+                     ("latency_graph.txt", "latency_graph.txt"), ("events_bench.txt", "events_bench.txt")):
         if os.path.exists(os.path.join(EV, src)):
             txt = "\n".join(ln for ln in open(os.path.join(EV, src)).read().splitlines() if "amdgpu.ids" not in ln)
             open(os.path.join(PR, f"{R}_{dst}"), "w").write(txt + "\n")
@@ -55,7 +56,8 @@ def main():
         shutil.copy(os.path.join(EV, "up_bench.txt"), os.path.join(PR, f"{R}_dense_up_bench.txt"))
     for src, dst in (("prof_overlap", "sp_mnn_b32_kernel_stats.csv"), ("prof_single", "sp_mnn_b32_kernel_stats_single_stream.csv"),
                      ("prof_lg", "sp_lg_b64_kernel_stats.csv"), ("prof_dense", "dense_kernel_stats.csv"),
-                     ("prof_b1_mnn", "sp_mnn_b1_kernel_stats.csv"), ("prof_b1_lg", "sp_lg_b1_kernel_stats.csv")):
+                     ("prof_b1_mnn", "sp_mnn_b1_kernel_stats.csv"), ("prof_b1_lg", "sp_lg_b1_kernel_stats.csv"),
+                     ("prof_events", "events_kernel_stats.csv")):
         ff = glob.glob(os.path.join(EV, src, "**", "*kernel_stats.csv"), recursive=True)
         if not ff:
             continue
