@@ -23,11 +23,12 @@ def _pack(events_list, device):
     return cat(xs, np.float32), cat(ys, np.float32), cat(ts, np.float64), cat(ps, np.float32), np.asarray(offs, np.int64)
 
 
-def events_to_voxel_grid_batch(events_list, input_size, normalize=True, device="cuda"):
-    """list of B event dicts -> voxel grids [B,bins,H,W] (fp32, on `device`)."""
+def events_to_voxel_grid_batch(events_list, input_size, normalize=True, device="cuda", packed=None):
+    """list of B event dicts -> voxel grids [B,bins,H,W] (fp32, on `device`).  packed: the result of `_pack` for these events
+    (a caller that also needs the events mask packs and uploads the arrays once)."""
     bins, H, W = (int(v) for v in input_size)
     B = len(events_list)
-    x, y, t, p, offs = _pack(events_list, device)
+    x, y, t, p, offs = packed if packed is not None else _pack(events_list, device)
     L = N.lib()
     grid = torch.empty((B, bins, H, W), dtype=torch.float32, device=device)
     ws = torch.empty(L.einx_voxel_ws_bytes(B, bins, H, W, int(offs[-1])), dtype=torch.uint8, device=device)
@@ -42,14 +43,23 @@ def events_to_voxel_grid(events, input_size, normalize=True, device="cuda"):
     return events_to_voxel_grid_batch([events], input_size, normalize, device)[0]
 
 
-def events_mask_batch(events_list, resolution, device="cuda"):
+def events_mask_batch(events_list, resolution, device="cuda", packed=None):
     """`draw_events_accumulation_image(events, (W,H)) > 0` for B samples -> bool [B,1,H,W]."""
     W, H = (int(v) for v in resolution)
     B = len(events_list)
-    x, y, _, _, offs = _pack(events_list, device)
+    x, y, _, _, offs = packed if packed is not None else _pack(events_list, device)
     L = N.lib()
     mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=device)
     ws = torch.empty(L.einx_events_ws_bytes(B, H, W), dtype=torch.uint8, device=device)
     check(L.einx_events_mask(N._ptr(x), N._ptr(y), offs.ctypes.data_as(ctypes.c_void_p), B, H, W, N._ptr(ws), N._ptr(mask), N._stream(mask)),
           "einx_events_mask")
     return mask.view(torch.bool)
+
+
+def events_representation_batch(events_list, input_size, normalize=True, device="cuda"):
+    """voxel grids [B,bins,H,W] and events masks [B,1,H,W] of B samples from ONE host-side packing and upload of the raw
+    event arrays (what test_events-image_same-time.py:130-140 builds per sample with two passes over the events)."""
+    bins, H, W = (int(v) for v in input_size)
+    packed = _pack(events_list, device)
+    return (events_to_voxel_grid_batch(events_list, input_size, normalize, device, packed=packed),
+            events_mask_batch(events_list, (W, H), device, packed=packed))

@@ -11,7 +11,7 @@ DifferentTimeEvaluator hands over exactly what the reference passes to them.
 import torch
 
 from .core.metrics._native_metrics import batch_metrics, metric_names
-from .datasets.representations import events_mask_batch, events_to_voxel_grid_batch
+from .datasets.representations import events_representation_batch
 
 
 class SameTimeEvaluator:
@@ -32,8 +32,7 @@ class SameTimeEvaluator:
         (scaled in place by SuperPoint exactly like the reference).  Returns the per-pair metric rows [B,K] (device)."""
         W, H = self.resolution
         dev = images.device
-        events_rep = events_to_voxel_grid_batch(events_list, (self.bins, H, W), normalize=True, device=dev)
-        events_mask = events_mask_batch(events_list, (W, H), device=dev)
+        events_rep, events_mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev)
         self.last_inputs = (events_rep, events_mask)  # what the extractors saw (deterministic since round 4: bit-equal run to run)
         ef, imf, matches = self.model(events_rep, images, events_mask)
         rows = batch_metrics(ef._batched, imf._batched, self.model._last_match, homography, self.mma_thr, self.vdd_thr)
