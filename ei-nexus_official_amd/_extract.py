@@ -119,6 +119,7 @@ class BatchedFeats:
         self.ordering = "yx"
         self.dense = False
         self.dense_lazy = False
+        self.stale = None  # device int32 [1]: raised by the module's content watch when a weight changed under the native images
         self._prepared = None
         self._full_lists = None
         self._ns = None

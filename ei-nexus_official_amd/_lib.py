@@ -64,6 +64,7 @@ class LgWeights(ctypes.Structure):
 SIGNATURES = {
     "einx_version": (c_char_p, []),
     "einx_build_flags": (c_char_p, []),
+    "einx_params_hash": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "einx_last_error": (c_char_p, []),
     "einx_device_count": (c_int, []),
     "einx_profile_enable": (c_int, [c_int]),

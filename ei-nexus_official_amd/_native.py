@@ -275,10 +275,11 @@ def upsample_normalize(raw, padded_size, pads, scale):
 
 # ------------------------------------------------------------------------------ matching
 class MatchResult:
-    __slots__ = ("matches0", "matches1", "scores0", "scores1", "la", "mk0", "mk1", "nmatch", "ref0", "ref1", "mk0_flat", "mk1_flat")
+    __slots__ = ("matches0", "matches1", "scores0", "scores1", "la", "mk0", "mk1", "nmatch", "ref0", "ref1", "mk0_flat", "mk1_flat", "stale")
 
     def __init__(self):
         self.mk0_flat = self.mk1_flat = None
+        self.stale = None  # device int32 [1]: the matcher's weight watch (LightGlue), read back with the match counts
 
 
 def mnn(desc0, n, desc1, m, want_la=True, ratio_thresh=None, distance_thresh=None):
@@ -418,3 +419,30 @@ def linear(x, w, bias, out=None, accumulate=False):
     y = out if out is not None else torch.empty((M, Nn), dtype=F32, device=x.device)
     check(lib().einx_linear(_ptr(x), M, K, _ptr(w), _ptr(bias), Nn, _ptr(y), int(accumulate), _stream(x)), "einx_linear")
     return y
+
+
+class ParamWatch:
+    """Device-side content watch of a module's fp32 parameters / buffers (einx_params_hash): `.data` edits, which no host-side
+    version counter sees, raise `stale` at the next forward.  Built when the module packs its weights; `check()` enqueues one
+    small launch on the current stream; the flag travels to the host with the counts the forward reads back anyway."""
+
+    def __init__(self, tensors):
+        ts = [t.detach() for t in tensors if torch.is_tensor(t) and t.dtype == F32 and t.numel() > 0 and t.device.type == "cuda"
+              and t.is_contiguous()]
+        self.keep = ts
+        self.n = len(ts)
+        self.stale = None
+        if not ts:
+            return
+        dev = ts[0].device
+        self.table = torch.tensor([[t.data_ptr(), t.numel()] for t in ts], dtype=torch.int64).to(dev)
+        self.ref = torch.empty((self.n,), dtype=torch.int64, device=dev)
+        self.scratch = torch.empty((self.n,), dtype=torch.int64, device=dev)
+        self.stale = torch.zeros((1,), dtype=torch.int32, device=dev)
+        check(lib().einx_params_hash(_ptr(self.table), self.n, _ptr(self.ref), None, None, _stream(self.table)), "einx_params_hash")
+
+    def check(self):
+        if self.n:
+            check(lib().einx_params_hash(_ptr(self.table), self.n, _ptr(self.scratch), _ptr(self.ref), _ptr(self.stale), _stream(self.table)),
+                  "einx_params_hash")
+        return self.stale

@@ -119,7 +119,7 @@ class EIM(nn.Module):
         return buf
 
     @on_input_device
-    def _enqueue(self, events, image, events_mask=None, image_mask=None, slot=0):
+    def _enqueue(self, events, image, events_mask=None, image_mask=None, slot=0, prepared=False):
         """Device side of one forward, nothing waits: both extractors, the matcher, the two small count read-backs
         (non-blocking copies into pinned buffers of `slot`, each followed by an event) and every output that does
         not depend on the counts."""
@@ -127,16 +127,19 @@ class EIM(nn.Module):
         p = {"B": B, "slot": slot}
 
         def read_detection(ev, im):
-            rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged])
-            p["det_host"] = self._pinned(f"det{slot}", (4, B)).copy_(rows, non_blocking=True)
+            # rows 4, 5: the extractors' weight watches (`.data` edits since the native images were built)
+            rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged, ev.stale.expand(B), im.stale.expand(B)])
+            p["det_host"] = self._pinned(f"det{slot}", (6, B)).copy_(rows, non_blocking=True)
             p["det_event"] = torch.cuda.Event()
             p["det_event"].record()
 
-        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=read_detection)
+        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=read_detection, prepared=prepared)
         p["ev"], p["im"], p["mr"] = ev, im, mr
+        p["args"] = (events, image, events_mask, image_mask)
         p["nm_event"] = None
         if mr is not None:
-            p["nm_host"] = self._pinned(f"nmatch{slot}", (B,)).copy_(mr.nmatch, non_blocking=True)
+            nm = mr.nmatch if getattr(mr, "stale", None) is None else torch.cat([mr.nmatch, mr.stale])  # + the matcher's weight watch
+            p["nm_host"] = self._pinned(f"nmatch{slot}", (int(nm.shape[0]),)).copy_(nm, non_blocking=True)
             p["nm_event"] = torch.cuda.Event()
             p["nm_event"].record()
         ev.prepare()  # count-independent outputs are built while the device still works on the tail
@@ -152,6 +155,23 @@ class EIM(nn.Module):
             p["det_event"].synchronize()
         host = p["det_host"]
         nm_host, nm_event = p.get("nm_host"), p["nm_event"]
+        stale = bool(host[4].any()) or bool(host[5].any())
+        if not stale and mr is not None and getattr(mr, "stale", None) is not None:
+            if nm_event is not None:
+                nm_event.synchronize()
+                nm_event = None
+            stale = bool(nm_host[host.shape[1]:].any())
+        if stale:
+            # a weight was edited through `.data` after the native images were built (the reference's modules would simply use
+            # the new values): rebuild the images of all three modules and run this forward again.  SuperPointv1's in-place
+            # `image /= 255` has already happened and is not repeated.
+            for mod in (self.event_extractor.extractor, self.image_extractor.extractor, self.matcher.matcher):
+                if hasattr(mod, "refresh"):
+                    mod.refresh()
+            self.reset_graphs()
+            return self._finish(self._enqueue(*p["args"], slot=p["slot"], prepared=True))
+        if mr is not None and getattr(mr, "stale", None) is not None and nm_host is not None:
+            nm_host = nm_host[:host.shape[1]]
         retries = 0
         while bool(host[2].any()) or bool(host[3].any()):
             retries += 1

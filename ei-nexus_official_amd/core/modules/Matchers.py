@@ -136,7 +136,14 @@ class Matcher(nn.Module):
         with torch.no_grad():
             pb0, pb1 = from_feats(feats0), from_feats(feats1)
             r = self.matcher.match_batched(pb0, pb1)
-            nm = r.nmatch.cpu().tolist()
+            if getattr(r, "stale", None) is not None:  # LightGlue: match counts + the weight watch in one read-back
+                nm = torch.cat([r.nmatch, r.stale]).cpu().tolist()
+                if nm.pop():  # a weight was edited through `.data`: rebuild the folded images, match again
+                    self.matcher.refresh()
+                    r = self.matcher.match_batched(pb0, pb1)
+                    nm = r.nmatch.cpu().tolist()
+            else:
+                nm = r.nmatch.cpu().tolist()
             n = pb0.counts_host or pb0.counts.cpu().tolist()
             m = pb1.counts_host or pb1.counts.cpu().tolist()
             return self.materialize(r, n, m, nm)

@@ -64,8 +64,10 @@ class NativeExtractor(nn.Module):
         return tuple((t.data_ptr(), t._version) for t in ts)
 
     def refresh(self):
-        """Drop the kernel-native weight images.  REQUIRED after editing parameters through `.data` or replacing Parameter
-        objects; harmless otherwise (everything else is detected by `_signature`)."""
+        """Drop the kernel-native weight images.  Needed after REPLACING Parameter objects and after `.data` edits that the
+        content watch cannot see (it samples 65 words per tensor: dense edits such as `p.data.copy_(w)` / `p.data.mul_(..)` are
+        caught at the next forward, which rebuilds the images and runs again; a single-element edit may not be); harmless
+        otherwise (everything else is detected by `_signature`)."""
         self._engine = self._scale_host = self._sig_tensors = None
 
     def _layer(self, block, pool=False):
@@ -89,6 +91,7 @@ class NativeExtractor(nn.Module):
             eng.backbone = [self._layer(b, p) for b, p in bb]
             eng.det_head = [self._layer(b) for b in det]
             eng.desc_head = [self._layer(b) for b in desc]
+            eng.watch = N.ParamWatch(self._sig_tensors)  # `.data` edits: seen by content (round 4), see refresh()
             self._engine = eng
         return self._engine
 
@@ -97,24 +100,35 @@ class NativeExtractor(nn.Module):
 
     @on_input_device
     def extract_batched(self, x, score_mask=None, nms_iters=None, dense=None, prepared=False, defer_dense=False):
-        """prepared=True: `x` already went through _prepare_input (retry after an NMS overflow).
+        """prepared=True: an IN-PLACE input scaling (SuperPointv1's `image /= 255`) has already been applied to `x` by an earlier
+        call and must not run twice (redo after a `.data` weight edit); extractors that scale a copy do so again.
         defer_dense=True: the dense descriptor map is left to the caller (`bf.run_dense()` on a stream of its choice)."""
         if self.training and self.uses_batchnorm:
             raise RuntimeError("the native path implements eval-mode BatchNorm (running statistics) only; call .eval() first")
-        if not prepared:
+        if not (prepared and self.input_div):
             x = self._prepare_input(x)
         eng = self.engine()
         if self._scale_host is None:  # one device read per engine build, not one host sync per forward
             self._scale_host = float(self.descriptor_scale_factor.detach())
         scale = self._scale_host
-        return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
-                       nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
+        stale = eng.watch.check()
+        bf = eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
+                     nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
+        bf.stale = stale
+        return bf
 
     @on_input_device
     def forward(self, x, score_mask=None, **kwargs):
         bf = self.extract_batched(x, score_mask)
-        for _ in range(9):
-            host = torch.stack([bf.det.counts, bf.det.not_converged]).cpu()
+        for _ in range(12):
+            rows = [bf.det.counts, bf.det.not_converged] + ([bf.stale.expand(bf.B)] if bf.stale is not None else [])
+            host = torch.stack(rows).cpu()
+            if len(rows) == 3 and bool(host[2].any()):
+                # a weight was edited through `.data` since the native images were built: rebuild them and run again (an input
+                # that was scaled in place -- SuperPointv1's `/= 255` -- is not scaled twice)
+                self.refresh()
+                bf = self.extract_batched(x, score_mask, prepared=True)
+                continue
             if not bool(host[1].any()):
                 self.engine().note_converged()
                 return bf.materialize(host[0].tolist())

@@ -194,6 +194,7 @@ class LightGlue(nn.Module):
         w.n_layers, w.heads, w.d, w.input_dim = c.n_layers, c.num_heads, c.descriptor_dim, c.input_dim
         w.filter_threshold = float(c.filter_threshold)
         w.layers = ctypes.cast(layers, ctypes.POINTER(_lib.LgLayer))
+        self._watch = N.ParamWatch(self._sig_tensors)  # `.data` edits are seen by content at the next forward (round 4)
         self._packed = (w, layers, keep)
         return self._packed
 
@@ -202,7 +203,9 @@ class LightGlue(nn.Module):
         if pb0.desc.shape[-1] != self.conf.input_dim or pb1.desc.shape[-1] != self.conf.input_dim:
             raise AssertionError("descriptor dimension does not match conf.input_dim")
         w = self._pack()[0]
+        stale = self._watch.check()
         r = N.lightglue(w, pb0, pb1, want_la=self.want_log_assignment, want_ref=True, all_layers=all_layers)
+        r.stale = stale
         return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 2)
 
     @torch.no_grad()
@@ -229,11 +232,16 @@ class LightGlue(nn.Module):
         pb0, pb1 = from_feats(feats0), from_feats(feats1)
         all_layers = bool(self.training)
         r = self.match_batched(pb0, pb1, all_layers=all_layers)
+        nm_all = torch.cat([r.nmatch, r.stale]).cpu().tolist()  # match counts + the weight watch in one read-back
+        if nm_all[-1]:  # a weight was edited through `.data`: rebuild the images, match again
+            self.refresh()
+            r = self.match_batched(pb0, pb1, all_layers=all_layers)
+            nm_all = r.nmatch.cpu().tolist() + [0]
         n = pb0.counts_host or pb0.counts.cpu().tolist()
         m = pb1.counts_host or pb1.counts.cpu().tolist()
         L = self.conf.n_layers
         if pb0.B == 1:
-            nm = r.nmatch.cpu().tolist()
+            nm = nm_all[:-1]
             out = {k: v[0] for k, v in materialize_matches(r, n, m, nm, 2).items()}
             if n[0] and m[0]:
                 ref0 = r.ref0 if all_layers else r.ref0[:, None]

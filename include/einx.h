@@ -42,6 +42,12 @@ const char* einx_build_flags(void);
 /* number of visible HIP devices (0 without a GPU); never initialises a context beyond that */
 int einx_device_count(void);
 
+/* Content watch of a module's weights (the reference's nn.Modules see an in-place edit through `p.data` at the next forward,
+ * torch/nn/modules/module.py semantics; here weights are repacked / folded at load time).  table: device [n][2] int64 =
+ * (device pointer, number of 32-bit words) per tensor.  ref == stale == NULL: store the hashes (64 spread words + the last
+ * word per tensor) in hash[n]; otherwise hash[n] is scratch and *stale (device int32) is OR-ed with 1 when any differs. */
+int einx_params_hash(const int64_t* table, int n, uint64_t* hash, const uint64_t* ref, int32_t* stale, void* stream);
+
 /* Measurement aid (no reference counterpart; the reference's scripts time with wall clocks around
  * whole forwards, test_events-image_same-time.py:196-208): while enabled, every kernel launch of
  * this library is bracketed by HIP events recorded on the launch stream.  einx_profile_report

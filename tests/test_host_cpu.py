@@ -210,3 +210,30 @@ def test_nms_pass_budget_grows_and_decays(monkeypatch):
         for _ in range(64 * 8):
             eng.note_converged()
         assert eng.nms_iters == base
+
+
+def test_feats_dict_resolves_lazy_entries_on_every_read_path():
+    """_extract.FeatsDict (dense outputs on demand): a lazy entry is computed once, by whichever read reaches it first --
+    d[k], get, items, values, pop, setdefault, copy, and CPython's own merges dict(d) / {**d} / other.update(d)."""
+    import importlib
+    ex = importlib.import_module(pkg.__name__ + "._extract")
+
+    def fresh():
+        d = ex.FeatsDict()
+        calls = []
+        dict.__setitem__(d, "score", 1)
+        dict.__setitem__(d, "normalized_descriptors", ex._Lazy(lambda dd: calls.append(dd is d) or 42))
+        return d, calls
+
+    for read in (lambda d: d["normalized_descriptors"], lambda d: d.get("normalized_descriptors"), lambda d: dict(d.items())["normalized_descriptors"],
+                 lambda d: list(d.values())[1], lambda d: d.pop("normalized_descriptors"), lambda d: d.setdefault("normalized_descriptors", 7),
+                 lambda d: d.copy()["normalized_descriptors"], lambda d: dict(d)["normalized_descriptors"], lambda d: {**d}["normalized_descriptors"],
+                 lambda d: (lambda o: (o.update(d), o)[1])({})["normalized_descriptors"]):
+        d, calls = fresh()
+        assert sorted(d.keys()) == ["normalized_descriptors", "score"] and "normalized_descriptors" in d and len(d) == 2
+        assert d.lazy_keys() == ["normalized_descriptors"] and calls == []
+        assert read(d) == 42 and calls == [True]
+        if "normalized_descriptors" in d:
+            assert d["normalized_descriptors"] == 42 and calls == [True] and d.lazy_keys() == []  # computed once
+    d, _ = fresh()
+    assert d.get("missing", 5) == 5 and d.pop("missing", 6) == 6

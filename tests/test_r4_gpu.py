@@ -127,3 +127,61 @@ def test_forward_graph_equals_forward(cfg_name, B):
         if exp["nd"] is not None:
             assert torch.equal(gf["normalized_descriptors"], exp["nd"])  # lazy entry resolved against THIS replay's buffers
     assert len(model._graphs) == 1
+
+
+@pytest.mark.parametrize("cfg_name", ["SP_MNN", "SP_LG"])
+def test_data_edits_of_weights_take_effect_at_the_next_forward(cfg_name):
+    """The reference's modules are plain nn.Modules: `p.data.mul_(..)` / `p.data.copy_(..)` change the next forward.  Here weights
+    are repacked / folded into native images and no host-side version counter sees a `.data` edit; the device-side content watch
+    (einx_params_hash: 65 sampled words per tensor, read back with the counts) does, and the forward that notices rebuilds the
+    images and runs again -- the result equals a model built from the edited weights."""
+    from helpers import synth
+    cfg = pkg.default_config(cfg_name, event_channels=5)
+
+    def build(sd):
+        m = pkg.EIM(cfg, device=DEV).eval()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        for ext in (m.event_extractor.extractor, m.image_extractor.extractor):
+            ext.dense_outputs = False
+        return m
+
+    model0 = pkg.EIM(cfg, device=DEV)
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model0.state_dict().items()], seed=31)
+    model = build(sd)
+    ev, mask = synth.synth_events(60, 2, 5)
+    img = synth.synth_image(60, 2)
+    before = model(_t(ev), _t(img), _t(mask))
+    edits = ["event_extractor.extractor.backbone.l1.1.0.weight", "image_extractor.extractor.convDb.bias"]
+    if cfg_name == "SP_LG":
+        edits.append("matcher.matcher.transformers.3.self_attn.ffn.3.weight")
+    params = dict(model.named_parameters())
+    sd2 = dict(sd)
+    for k in edits:
+        new = (sd[k] * np.float32(1.25) + np.float32(0.01)).astype(np.float32)
+        params[k].data.copy_(torch.from_numpy(new).to(DEV))  # the edit no version counter sees
+        sd2[k] = new
+    img_t = _t(img)
+    got = model(_t(ev), img_t, _t(mask))
+    exp = build(sd2)(_t(ev), _t(img), _t(mask))
+    assert np.array_equal(_np(img_t), img / np.float32(255.0))  # scaled in place exactly once although the forward ran twice
+    changed = False
+    for b in range(2):
+        for side in (0, 1):
+            assert torch.equal(got[side]["sparse_positions"][b], exp[side]["sparse_positions"][b])
+            assert torch.equal(got[side]["sparse_descriptors"][b], exp[side]["sparse_descriptors"][b])
+            changed |= not torch.equal(got[side]["sparse_descriptors"][b], before[side]["sparse_descriptors"][b]) \
+                if got[side]["sparse_descriptors"][b].shape == before[side]["sparse_descriptors"][b].shape else True
+        assert torch.equal(got[2]["matches0"][b], exp[2]["matches0"][b])
+        assert torch.equal(got[2]["matching_scores0"][b], exp[2]["matching_scores0"][b])
+    assert changed
+    again = model(_t(ev), _t(img), _t(mask))  # steady state: nothing stale any more, same result
+    assert torch.equal(again[2]["matches0"][0], exp[2]["matches0"][0])
+    # the standalone extractor front-end notices as well
+    ext = model.image_extractor.extractor
+    f0 = ext(_t(img) / 255.0 if False else _t(img))
+    ext.convDb.bias.data.add_(0.5)
+    img2 = _t(img)
+    f1 = ext(img2)
+    assert np.array_equal(_np(img2), img / np.float32(255.0))
+    assert not torch.equal(f1["raw_descriptors"], f0["raw_descriptors"])
+    assert torch.allclose(f1["raw_descriptors"], f0["raw_descriptors"] + 0.5, atol=1e-6)

@@ -171,7 +171,7 @@ def write_readme(pmc, busy):
         A("| config | pairs/step | pairs/s | ms/step | mean matches | note |")
         A("|---|---|---|---|---|---|")
         for e in b["extra_configs"]:
-            A(f"| {e['config']} | {e['pairs_per_step']} | {e['value']:.0f} | {e['ms_per_step']:.3f} | {e['mean_matches']} | {e.get('note', '')[:110]} |")
+            A(f"| {e['config']} | {e['pairs_per_step']} | {e['value']:.0f} | {e['ms_per_step']:.3f} | {e.get('mean_matches')} | {e.get('note', '')[:110]} |")
     if b.get("scale_legs"):
         A("")
         A("`scale_legs` of the headline line (every rank runs them after the headline at EVERY N; at N=1 the SP+LightGlue leg is BASELINE configs[3], "
@@ -310,9 +310,20 @@ def write_readme(pmc, busy):
         A("")
         A("| comparison | measured max abs error | tolerance | largest reference magnitude |")
         A("|---|---|---|---|")
-        for k, v in sorted(json.load(open(pe)).items()):
-            A(f"| {k} | {v['max_abs_err']:.3e} | {v['atol']:.0e} | {v['max_abs_ref']:.3g} |")
+        pj = json.load(open(pe))
+        for k, v in sorted(pj.items()):
+            if k != "assignment_flips":
+                A(f"| {k} | {v['max_abs_err']:.3e} | {v['atol']:.1e} | {v['max_abs_ref']:.3g} |")
         A("")
+        if "assignment_flips" in pj:
+            A("Match-assignment flips per comparison (`helpers.record_flips`; -1 = unmatched counts as an assignment): "
+              "the LightGlue log_assignment bounds are multiples of the reference's own noise floor (`tests/golden/lgcal.npz`, notes below).")
+            A("")
+            A("| comparison | flips | assignments compared | matched in the checker |")
+            A("|---|---|---|---|")
+            for k, v in sorted(pj["assignment_flips"].items()):
+                A(f"| {k} | {v['flips']} | {v['compared']} | {v['matched']} |")
+            A("")
     extra = os.path.join(PR, f"{R}_notes.md")
     if os.path.exists(extra):  # hand-written findings of the round (experiments, A/B runs), kept next to the raw logs
         A(open(extra).read())
