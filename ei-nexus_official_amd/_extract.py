@@ -119,7 +119,6 @@ class BatchedFeats:
         self.ordering = "yx"
         self.dense = False
         self.dense_lazy = False
-        self.stale = None  # device int32 [1]: raised by the module's content watch when a weight changed under the native images
         self._prepared = None
         self._full_lists = None
         self._ns = None
@@ -331,6 +330,9 @@ class ExtractorEngine:
         P = N._ptr
         out = _lib.ExtractOut(P(bf.feats), P(bf.logits), P(bf.raw), P(bf.prob), P(bf.score), P(bf.coarse), P(bf.raw_cl), P(det.nms),
                               P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap)
+        wt = getattr(self, "watch", None)
+        if wt is not None and wt.n:  # `.data` edits of the weights: compared inside the call, bit 1 of not_converged[0]
+            out.watch_n, out.watch_table, out.watch_ref, out.watch_scratch = wt.n, P(wt.table), P(wt.ref), P(wt.scratch)
         _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), nws, ctypes.byref(out), N._stream(x)), "einx_extract")
         if dense and not defer_dense:
             bf.run_dense()
@@ -440,6 +442,9 @@ class ExtractorEngine:
         prob, score = N.score_map(logits, mask, pads, dilate=dilate_mask, border=self.border)
         bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
         self.redetect(bf, nms_iters)
+        wt = getattr(self, "watch", None)
+        if wt is not None and wt.n:  # op-level path (rare configurations): the weight watch as its own launch, same bit
+            bf.det.not_converged[:1].bitwise_or_(wt.check() * 2)
         if dense and not defer_dense:
             bf.run_dense()
         return bf

@@ -39,7 +39,8 @@ class ExtractShapes(ctypes.Structure):
 class ExtractOut(ctypes.Structure):
     _names = ("feats", "logits", "raw", "prob", "score", "coarse", "raw_cl", "nms", "positions", "indices", "counts", "thr", "not_converged",
               "sparse_desc")
-    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32)]
+    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32), ("watch_n", ctypes.c_int32), ("watch_table", c_void_p),
+                                                   ("watch_ref", c_void_p), ("watch_scratch", c_void_p)]
 
 
 class MetricParams(ctypes.Structure):

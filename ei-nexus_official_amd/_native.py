@@ -3,6 +3,7 @@ and workspaces with torch (caching allocator, stream ordered) and enqueues the H
 current stream.  No arithmetic happens here; PyTorch is memory + stream plumbing only.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -429,6 +430,8 @@ class ParamWatch:
     def __init__(self, tensors):
         ts = [t.detach() for t in tensors if torch.is_tensor(t) and t.dtype == F32 and t.numel() > 0 and t.device.type == "cuda"
               and t.is_contiguous()]
+        if os.environ.get("EINX_NO_WATCH") == "1":  # tools: A/B of the watch's cost
+            ts = []
         self.keep = ts
         self.n = len(ts)
         self.stale = None
@@ -442,6 +445,7 @@ class ParamWatch:
         check(lib().einx_params_hash(_ptr(self.table), self.n, _ptr(self.ref), None, None, _stream(self.table)), "einx_params_hash")
 
     def check(self):
+        """enqueue the comparison on the current stream; returns the device flag (int32 [1], 1 = some tensor changed)"""
         if self.n:
             check(lib().einx_params_hash(_ptr(self.table), self.n, _ptr(self.scratch), _ptr(self.ref), _ptr(self.stale), _stream(self.table)),
                   "einx_params_hash")

@@ -127,9 +127,9 @@ class EIM(nn.Module):
         p = {"B": B, "slot": slot}
 
         def read_detection(ev, im):
-            # rows 4, 5: the extractors' weight watches (`.data` edits since the native images were built)
-            rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged, ev.stale.expand(B), im.stale.expand(B)])
-            p["det_host"] = self._pinned(f"det{slot}", (6, B)).copy_(rows, non_blocking=True)
+            # not_converged: bit 0 = the NMS fix-point needs more passes, bit 1 (element 0) = the extractor's weight watch
+            rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged])
+            p["det_host"] = self._pinned(f"det{slot}", (4, B)).copy_(rows, non_blocking=True)
             p["det_event"] = torch.cuda.Event()
             p["det_event"].record()
 
@@ -155,7 +155,7 @@ class EIM(nn.Module):
             p["det_event"].synchronize()
         host = p["det_host"]
         nm_host, nm_event = p.get("nm_host"), p["nm_event"]
-        stale = bool(host[4].any()) or bool(host[5].any())
+        stale = bool(((host[2] | host[3]) & 2).any())
         if not stale and mr is not None and getattr(mr, "stale", None) is not None:
             if nm_event is not None:
                 nm_event.synchronize()
@@ -173,13 +173,13 @@ class EIM(nn.Module):
         if mr is not None and getattr(mr, "stale", None) is not None and nm_host is not None:
             nm_host = nm_host[:host.shape[1]]
         retries = 0
-        while bool(host[2].any()) or bool(host[3].any()):
+        while bool((host[2] & 1).any()) or bool((host[3] & 1).any()):
             retries += 1
             if retries > 8:  # 8 * 4**8 passes: cannot happen on a finite map (each pass removes at least one pixel or stops)
                 raise RuntimeError("einx: the NMS fix-point did not converge within the maximum pass budget")
             # the NMS fix-point of some image needed more passes than were enqueued: redo only the
             # detection tail (and the matcher) with a larger, remembered, pass budget (rare: blocking read-back)
-            for flag, bf, wrapper in ((bool(host[2].any()), ev, self.event_extractor), (bool(host[3].any()), im, self.image_extractor)):
+            for flag, bf, wrapper in ((bool((host[2] & 1).any()), ev, self.event_extractor), (bool((host[3] & 1).any()), im, self.image_extractor)):
                 if flag:
                     eng = wrapper.extractor.engine()
                     eng.redetect(bf, eng.grow_nms_iters())
@@ -248,7 +248,7 @@ class EIM(nn.Module):
         cur.synchronize()
         p = g["p"]
         host = p["det_host"]
-        if bool(host[2].any()) or bool(host[3].any()):  # rare: pass budget exceeded -> the eager path with its retry
+        if bool(((host[2] | host[3]) & 1).any()):  # rare: pass budget exceeded -> the eager path with its retry
             return self.forward(events, image, events_mask, image_mask)
         for bf, tmpl in ((p["ev"], g["prep_ev"]), (p["im"], g["prep_im"])):
             bf.reuse_prepared(tmpl)

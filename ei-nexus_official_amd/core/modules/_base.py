@@ -91,7 +91,7 @@ class NativeExtractor(nn.Module):
             eng.backbone = [self._layer(b, p) for b, p in bb]
             eng.det_head = [self._layer(b) for b in det]
             eng.desc_head = [self._layer(b) for b in desc]
-            eng.watch = N.ParamWatch(self._sig_tensors)  # `.data` edits: seen by content (round 4), see refresh()
+            eng.watch = N.ParamWatch(self._sig_tensors)  # `.data` edits: seen by content (round 4, inside einx_extract), see refresh()
             self._engine = eng
         return self._engine
 
@@ -111,25 +111,22 @@ class NativeExtractor(nn.Module):
         if self._scale_host is None:  # one device read per engine build, not one host sync per forward
             self._scale_host = float(self.descriptor_scale_factor.detach())
         scale = self._scale_host
-        stale = eng.watch.check()
-        bf = eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
-                     nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
-        bf.stale = stale
-        return bf
+        # (the engine's weight watch runs inside the call and reports through bit 1 of det.not_converged[0])
+        return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
+                       nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
 
     @on_input_device
     def forward(self, x, score_mask=None, **kwargs):
         bf = self.extract_batched(x, score_mask)
         for _ in range(12):
-            rows = [bf.det.counts, bf.det.not_converged] + ([bf.stale.expand(bf.B)] if bf.stale is not None else [])
-            host = torch.stack(rows).cpu()
-            if len(rows) == 3 and bool(host[2].any()):
+            host = torch.stack([bf.det.counts, bf.det.not_converged]).cpu()
+            if bool((host[1] & 2).any()):
                 # a weight was edited through `.data` since the native images were built: rebuild them and run again (an input
                 # that was scaled in place -- SuperPointv1's `/= 255` -- is not scaled twice)
                 self.refresh()
                 bf = self.extract_batched(x, score_mask, prepared=True)
                 continue
-            if not bool(host[1].any()):
+            if not bool((host[1] & 1).any()):
                 self.engine().note_converged()
                 return bf.materialize(host[0].tolist())
             self.engine().redetect(bf, self.engine().grow_nms_iters())  # NMS fix-point needs more passes

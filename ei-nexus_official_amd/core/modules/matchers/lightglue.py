@@ -232,7 +232,8 @@ class LightGlue(nn.Module):
         pb0, pb1 = from_feats(feats0), from_feats(feats1)
         all_layers = bool(self.training)
         r = self.match_batched(pb0, pb1, all_layers=all_layers)
-        nm_all = torch.cat([r.nmatch, r.stale]).cpu().tolist()  # match counts + the weight watch in one read-back
+        # match counts + the weight watch in one read-back
+        nm_all = torch.cat([r.nmatch, r.stale]).cpu().tolist() if r.stale is not None else r.nmatch.cpu().tolist() + [0]
         if nm_all[-1]:  # a weight was edited through `.data`: rebuild the images, match again
             self.refresh()
             r = self.match_batched(pb0, pb1, all_layers=all_layers)

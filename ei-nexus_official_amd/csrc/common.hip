@@ -150,31 +150,20 @@ EINX_EXPORT int einx_div_inplace(float* x, size_t n, float divisor, void* stream
 // Best effort by construction: an edit that leaves all 65 sampled words unchanged is not seen (refresh() remains).
 // ------------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(64) void params_hash_kernel(const int64_t* table /*[n][2]: pointer, numel*/, unsigned long long* hash,
-                                                        const unsigned long long* ref, int32_t* stale) {
-  const int t = blockIdx.x, lane = threadIdx.x;
-  const uint32_t* p = reinterpret_cast<const uint32_t*>((uintptr_t)table[2 * t]);
-  const long long n = table[2 * t + 1];
-  unsigned long long h = 0;
-  if (n > 0) {
-    const long long i = (long long)(((__int128)lane * n) / 64);
-    h = (unsigned long long)p[i] * (2ull * (unsigned long long)lane + 1ull) * 0x9E3779B97F4A7C15ull;
-    if (lane == 63) h += (unsigned long long)p[n - 1] * 0xD1342543DE82EF95ull;
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off, 64);  // wrap-around sum: order independent
-  if (lane == 0) {
-    hash[t] = h;
-    if (ref && ref[t] != h) atomicOr(stale, 1);
-  }
-}
+__global__ __launch_bounds__(64) void params_hash_kernel(const EinxWatch w) { einx_watch_tensor(w, (int)blockIdx.x, (int)threadIdx.x); }
 }  // namespace
 
 EINX_EXPORT int einx_params_hash(const int64_t* table, int n, uint64_t* hash, const uint64_t* ref, int32_t* stale, void* stream) {
   EINX_CHECK_ARG(table && hash && n > 0, "null pointer / empty table");
   EINX_CHECK_ARG((ref == nullptr) == (stale == nullptr), "ref and stale go together");
-  hipLaunchKernelGGL(params_hash_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, table, (unsigned long long*)hash,
-                     (const unsigned long long*)ref, stale);
+  EinxWatch w;
+  w.table = table;
+  w.ref = (const unsigned long long*)ref;
+  w.hash = (unsigned long long*)hash;
+  w.flag = stale;
+  w.n = n;
+  w.bit = 1;
+  hipLaunchKernelGGL(params_hash_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, w);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

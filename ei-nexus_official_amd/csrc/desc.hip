@@ -23,10 +23,15 @@ __device__ __forceinline__ float wave_butterfly_sum(float v) {
 template <bool BILINEAR, bool CL = false>
 __global__ __launch_bounds__(256) void desc_sample_kernel(const float* raw, int D, int hc, int wc, int Hp, int Wp,
                                                           const int32_t* indices, const int32_t* counts, int cap, float scale,
-                                                          float* out) {
+                                                          float* out, const EinxWatch watch, int main_blocks) {
   const int b = blockIdx.y;
   const int kp = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x >= main_blocks) {  // spare workgroups of image 0: the extractor's weight watch, four tensors each
+    const int t = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
+    if (b == 0 && t < watch.n) einx_watch_tensor(watch, t, lane);
+    return;
+  }
   int cnt = counts[b];
   cnt = cnt < cap ? cnt : cap;
   if (kp >= cnt) return;
@@ -683,15 +688,28 @@ EINX_EXPORT int einx_desc_sample(const float* raw, int B, int D, int hc, int wc,
   EINX_CHECK_ARG(B > 0 && D > 0 && D <= 512 && hc > 0 && wc > 0 && cap > 0, "bad shape (D must be <= 512)");
   EINX_CHECK_ARG(bilinear || (Hp == hc && Wp == wc), "gather mode needs a full-resolution map");
   EINX_CHECK_ARG(!channels_last || bilinear, "the channels-last layout is implemented for bilinear sampling");
-  dim3 grid((unsigned)einx_cdiv(cap, 4), (unsigned)B);
+  EinxWatch none;
+  none.table = nullptr;
+  none.ref = nullptr;
+  none.hash = nullptr;
+  none.flag = nullptr;
+  none.n = 0;
+  none.bit = 0;
+  return einx_desc_sample_watch(raw, B, D, hc, wc, Hp, Wp, bilinear, channels_last, indices, counts, cap, scale, out, none, stream);
+}
+
+int einx_desc_sample_watch(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last, const int32_t* indices,
+                           const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, void* stream) {
+  const int main_blocks = einx_cdiv(cap, 4);
+  dim3 grid((unsigned)(main_blocks + (watch.n > 0 ? einx_cdiv(watch.n, 4) : 0)), (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
   EINX_PROF("desc_sample_kernel", s);
   if (bilinear && channels_last)
-    hipLaunchKernelGGL((desc_sample_kernel<true, true>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
+    hipLaunchKernelGGL((desc_sample_kernel<true, true>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks);
   else if (bilinear)
-    hipLaunchKernelGGL((desc_sample_kernel<true, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
+    hipLaunchKernelGGL((desc_sample_kernel<true, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks);
   else
-    hipLaunchKernelGGL((desc_sample_kernel<false, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out);
+    hipLaunchKernelGGL((desc_sample_kernel<false, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

@@ -64,6 +64,41 @@ __device__ __forceinline__ int xcd_contiguous(int linear, int total) {
 __device__ __forceinline__ int xcd_contiguous(int linear, int) { return linear; }
 #endif
 
+// Content watch of a module's weights (common.hip::einx_params_hash): one wave hashes 64 evenly spread 32-bit words + the last
+// word of tensor t; with `ref` set a difference raises `bit` in *flag.  Also run by spare workgroups of desc_sample_kernel, so
+// that an extractor's watch costs no launch of its own (einx_extract).
+struct EinxWatch {
+  const int64_t* table;           // device [n][2]: (pointer, number of 32-bit words)
+  const unsigned long long* ref;  // device [n] or null (store mode)
+  unsigned long long* hash;       // device [n]: written in store mode, scratch otherwise
+  int32_t* flag;
+  int n, bit;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int lane) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>((uintptr_t)w.table[2 * t]);
+  const long long n = w.table[2 * t + 1];
+  unsigned long long h = 0;
+  if (n > 0) {
+    const long long i = (long long)lane * (n >> 6) + (((long long)lane * (n & 63)) >> 6);  // floor(lane * n / 64) without 128-bit arithmetic
+    h = (unsigned long long)p[i] * (2ull * (unsigned long long)lane + 1ull) * 0x9E3779B97F4A7C15ull;
+    if (lane == 63) h += (unsigned long long)p[n - 1] * 0xD1342543DE82EF95ull;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off, 64);  // wrap-around sum: order independent
+  if (lane == 0) {
+    if (w.ref) {
+      if (w.ref[t] != h) atomicOr(w.flag, w.bit);
+    } else {
+      w.hash[t] = h;
+    }
+  }
+}
+#endif
+// einx_desc_sample with the extractor's weight watch riding on spare workgroups (einx_extract)
+int einx_desc_sample_watch(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last, const int32_t* indices,
+                           const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, void* stream);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -344,6 +344,14 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
   if (rc) return rc;
   const bool bilinear = e->d.cell == 8;
   const bool use_cl = bilinear && D <= 512;
-  return einx_desc_sample(use_cl ? o->raw_cl : o->raw, B, D, h, w, pl.Hp, pl.Wp, bilinear ? 1 : 0, use_cl ? 1 : 0, o->indices, o->counts,
-                          o->cap, e->d.desc_scale, o->sparse_desc, stream);
+  EinxWatch watch;  // the weight watch rides on spare workgroups of the sampling kernel: no launch of its own
+  const bool on = o->watch_n > 0 && o->watch_table && o->watch_ref && o->watch_scratch;
+  watch.table = on ? o->watch_table : nullptr;
+  watch.ref = (const unsigned long long*)o->watch_ref;
+  watch.hash = (unsigned long long*)o->watch_scratch;
+  watch.flag = o->not_converged;
+  watch.n = on ? o->watch_n : 0;
+  watch.bit = 2;
+  return einx_desc_sample_watch(use_cl ? o->raw_cl : o->raw, B, D, h, w, pl.Hp, pl.Wp, bilinear ? 1 : 0, use_cl ? 1 : 0, o->indices, o->counts,
+                                o->cap, e->d.desc_scale, o->sparse_desc, watch, stream);
 }

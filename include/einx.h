@@ -339,9 +339,15 @@ typedef struct einx_extract_out {
   int32_t* indices; /* [B,cap] */
   int32_t* counts;  /* [B] */
   float* thr;       /* [B] */
-  int32_t* not_converged; /* [B] see einx_detect */
+  int32_t* not_converged; /* [B] bit 0: see einx_detect; bit 1 of element 0: weight watch (below) */
   float* sparse_desc;     /* [B,cap,desc_dim] */
   int32_t cap;
+  /* optional content watch of the network's weights (einx_params_hash; watch_n == 0: off): compared at the end of the call,
+   * a difference raises bit 1 (value 2) of not_converged[0] -- the flag reaches the host with the read-back of that array */
+  int32_t watch_n;
+  const int64_t* watch_table;  /* device [watch_n][2] */
+  const uint64_t* watch_ref;   /* device [watch_n] hashes stored when the native weight images were built */
+  uint64_t* watch_scratch;     /* device [watch_n] */
 } einx_extract_out;
 
 einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
