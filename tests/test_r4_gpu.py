@@ -185,3 +185,32 @@ def test_data_edits_of_weights_take_effect_at_the_next_forward(cfg_name):
     assert np.array_equal(_np(img2), img / np.float32(255.0))
     assert not torch.equal(f1["raw_descriptors"], f0["raw_descriptors"])
     assert torch.allclose(f1["raw_descriptors"], f0["raw_descriptors"] + 0.5, atol=1e-6)
+
+
+def test_lazy_dense_and_forward_graph_on_the_silk_family():
+    """The cell-1 networks (VGG_NP events + SiLK image): dense entries on demand (normalised full-resolution map, cropped) equal
+    the eager ones, and forward_graph (no events mask given to the image side, 128-d descriptors) equals forward."""
+    from helpers import synth
+    cfg = pkg.default_config("SiLK_MNN", event_channels=5)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=29)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ev, mask = synth.synth_events(70, 1, 5, 96, 128)
+    img = synth.synth_image(70, 1, 96, 128)
+    lazy = model(_t(ev), _t(img), _t(mask))
+    assert sorted(lazy[1].lazy_keys()) == ["dense_descriptors", "dense_positions", "normalized_descriptors"]
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = True
+    eager = model(_t(ev), _t(img), _t(mask))
+    for side in (0, 1):
+        assert torch.equal(lazy[side]["normalized_descriptors"], eager[side]["normalized_descriptors"])
+        assert torch.equal(lazy[side]["dense_positions"][0], eager[side]["dense_positions"][0])
+        assert torch.equal(lazy[side]["dense_descriptors"][0], eager[side]["dense_descriptors"][0])
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        ext.dense_outputs = "lazy"
+    for it in range(2):
+        g = model.forward_graph(_t(ev), _t(img), _t(mask))
+        assert torch.equal(g[0]["sparse_descriptors"][0], lazy[0]["sparse_descriptors"][0])
+        assert torch.equal(g[1]["sparse_positions"][0], lazy[1]["sparse_positions"][0])
+        assert torch.equal(g[2]["matches0"][0], lazy[2]["matches0"][0])
+        assert torch.equal(g[1]["normalized_descriptors"], eager[1]["normalized_descriptors"])
