@@ -857,7 +857,8 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         return EINX_OK;
       }
     }
-    if (blocks256 < 1024) {
+    static const long min256 = getenv("EINX_CONV_1X1_MIN256") ? atol(getenv("EINX_CONV_1X1_MIN256")) : 1024;  // tuning aid
+    if (blocks256 < min256) {
       a.tilesX = einx_cdiv(H * W, 128);
       static const bool no_xtra = getenv("EINX_CONV_NO_XTRA") != nullptr;
       if (d->cout == a.CoutPad - kCoutTile + 1 && d->cout > kCoutTile && d->cin % 32 == 0 && !no_xtra) {
