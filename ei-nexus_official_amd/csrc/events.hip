@@ -117,21 +117,37 @@ __global__ __launch_bounds__(1024) void voxel_prep_kernel(const VoxArgs a) {
 }
 
 // Appends up to 64 hits (one per lane, in lane = event order) to the (band, segment) sub-lists they touch.  `curv`: lane v holds
-// the cursor of band v.  ONE copy of this code (noinline): inlined at its call sites and unrolled over the bands, the kernel
-// grew to 72 KB of instructions and no longer fitted the instruction cache.
+// the cursor of band v.  ONE copy of this code (noinline): inlined at its call sites (and, in its first form, unrolled over the
+// 16 bands) the kernel grew to 72 KB of instructions and no longer fitted the instruction cache.
 __device__ __noinline__ void vox_distribute(uint32_t ev, bool valid, const uint32_t* keys, uint32_t* lists, const int* sub_base, int seg,
-                                            int bw, int W, int& curv) {
+                                            int bw, int W, int& curv, volatile int* vcnt /* 16 ints of this wave */) {
   const int lane = threadIdx.x & 63;
   const int x0 = vox_key_x(keys[valid ? ev : 0]);
   const int b0 = (valid && x0 >= 0 && x0 < W) ? x0 / bw : -1;
-  const int b1 = (valid && x0 + 1 >= 0 && x0 + 1 < W) ? (x0 + 1) / bw : -1;
-  for (int v = 0; v < VOX_BANDS; ++v) {
-    const bool own = b0 == v || b1 == v;
-    const unsigned long long m = __ballot(own);
-    if (m == 0) continue;
-    const int cur = __builtin_amdgcn_readlane(curv, v);
-    if (own) lists[sub_base[v * VOX_SEGS + seg] + cur + __popcll(m & ((1ull << lane) - 1ull))] = ev;
-    if (lane == v) curv += __popcll(m);
+  int b1 = (valid && x0 + 1 >= 0 && x0 + 1 < W) ? (x0 + 1) / bw : -1;
+  if (b1 == b0) b1 = -1;
+  // rank of a lane among the lanes of ITS band from four ballots of the band's bits (instead of one ballot per band):
+  // pass 0 the band of x0, pass 1 the band of x0 + 1 where it differs (one column in bw)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bb = pass == 0 ? b0 : b1;
+    const bool act = bb >= 0;
+    unsigned long long same = __ballot(act);
+    if (same == 0) continue;  // wave-uniform
+#pragma unroll
+    for (int bit = 0; bit < 4; ++bit) {
+      const bool one = (bb >> bit) & 1;
+      const unsigned long long m = __ballot(act && one);
+      same &= one ? m : ~m;
+    }
+    const int rank = __popcll(same & ((1ull << lane) - 1ull)), total = __popcll(same);
+    const int cur = __shfl(curv, act ? bb : 0, 64);
+    if (lane < VOX_BANDS) vcnt[lane] = 0;
+    if (act) {
+      lists[sub_base[bb * VOX_SEGS + seg] + cur + rank] = ev;
+      if (rank == total - 1) vcnt[bb] = total;  // the last lane of a band's group reports its size
+    }
+    if (lane < VOX_BANDS) curv += vcnt[lane];
   }
 }
 
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
   __shared__ uint32_t wqueue[16 * 128];
   __shared__ unsigned tags[VOX_BANDS * VOX_TAGS];
   __shared__ int sub_base[VOX_BANDS * VOX_SEGS + 1];  // relative to slab_base
+  __shared__ int vcnt_all[16 * VOX_BANDS];
   __shared__ long long red[16];
   __shared__ int wsum[4];
   const int b = blockIdx.y, sl = blockIdx.x;
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
           if (hit) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
           qn += __popcll(m);
           if (qn >= 64) {  // wave-uniform
-            if (!VOX_EXP_ON(4)) vox_distribute(queue[lane], true, keys, lists, sub_base, wave, a.bw, a.W, curv);
+            if (!VOX_EXP_ON(4)) vox_distribute(queue[lane], true, keys, lists, sub_base, wave, a.bw, a.W, curv, vcnt_all + wave * VOX_BANDS);
             qn -= 64;
             if (lane < qn) {
               const uint32_t v = queue[64 + lane];
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
           }
         }
       }
-      if (qn > 0 && !VOX_EXP_ON(4)) vox_distribute(lane < qn ? queue[lane] : 0u, lane < qn, keys, lists, sub_base, wave, a.bw, a.W, curv);
+      if (qn > 0 && !VOX_EXP_ON(4)) vox_distribute(lane < qn ? queue[lane] : 0u, lane < qn, keys, lists, sub_base, wave, a.bw, a.W, curv, vcnt_all + wave * VOX_BANDS);
     }
     // the lists are read by other waves of this workgroup: same CU, same L1 -> a workgroup-scope release is enough
     if (!VOX_EXP_ON(3)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -289,8 +306,14 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
       // sensors deliver integer pixel coordinates: a corner with dx = 1 (dy = 1) then weighs every event with an exact zero
       // and is skipped for the whole list (the test is exact: such lanes would sit out one by one anyway)
       bool fx = false, fy = false;
+#pragma unroll
+      for (int k = 0; k < VOX_CACHE; ++k) {
+        const bool in = k * 64 + lane < mylen;
+        fx |= in && rc[k].x != (float)(int)rc[k].x;
+        fy |= in && rc[k].y != (float)(int)rc[k].y;
+      }
 #pragma unroll 1
-      for (int c = 0; c < mylen; c += 64) {
+      for (int c = VOX_CACHE * 64; c < mylen; c += 64) {
         const bool in = c + lane < mylen;
         const float4 r = rec[__builtin_nontemporal_load(mylist + (in ? c + lane : 0))];
         fx |= in && r.x != (float)(int)r.x;
