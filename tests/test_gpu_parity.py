@@ -764,7 +764,9 @@ def test_voxel_grid_collisions_and_out_of_range_events(oracle):
     from importlib import import_module
     rep = import_module(pkg.__name__ + ".datasets.representations")
     cases = [dict(seed=3, n=20000, H=260, W=346, bins=5, box=4), dict(seed=4, n=50000, H=260, W=346, bins=5, box=400),
-             dict(seed=5, n=9000, H=97, W=131, bins=3, box=30), dict(seed=6, n=70000, H=480, W=640, bins=5, box=700)]
+             dict(seed=5, n=9000, H=97, W=131, bins=3, box=30), dict(seed=6, n=70000, H=480, W=640, bins=5, box=700),
+             # one image row per slab and more (slab, band) lists than the LDS histogram of the prep kernel holds (global counters)
+             dict(seed=8, n=20000, H=300, W=640, bins=16, box=700)]
     for c in cases:
         n, H, W = c["n"], c["H"], c["W"]
         x = synth.uniform(c["seed"], (n,), -3.0, min(W + 2.0, c["box"]))
