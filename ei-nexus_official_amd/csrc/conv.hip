@@ -332,7 +332,11 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
       for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < kNT; ++nt)
+#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL_NOMFMA)  // timing-only: operands consumed by one VALU op instead of an MFMA
+          acc[mt][nt][0] += av[st % (PF + 1)][mt] * bv[st % (PF + 1)][nt];
+#else
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % (PF + 1)][mt], bv[st % (PF + 1)][nt], acc[mt][nt], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -409,7 +413,11 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
         if (POOL) {
           pv[nt] = v;
         } else {
+#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL_NOSTORE)  // timing-only: the un-pooled layers store one element per lane and channel
+          if (cv && opix[nt] >= 0 && v == 12345.678f) out_b[(size_t)co * HW + opix[nt]] = v;
+#else
           if (cv && opix[nt] >= 0) out_b[(size_t)co * HW + opix[nt]] = v;
+#endif
         }
       }
       if (POOL) {
