@@ -19,6 +19,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "einx_common.h"
 
 namespace {
@@ -58,35 +60,76 @@ constexpr bool pitch_conflict_free(int th, int tw, int pitch) {
   return true;
 }
 constexpr int conv_lds_pitch(int th, int tw) {
-#ifdef EINX_CONV_PLAIN_PITCH
-  return tw + 2;
-#else
   for (int p = tw + 2; p < tw + 2 + 32; ++p)
     if (pitch_conflict_free(th, tw, p)) return p;
   return tw + 2;
-#endif
+}
+
+// lane ^ X exchange without an LDS round trip where the ISA has one: DPP quad_perm (X = 1), DPP row_ror:8 inside rows of 16
+// lanes (X = 8), ds_swizzle SWAP16 (X = 16: crossbar only, no LDS access, no address register)
+template <int X>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  if constexpr (X == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));
+  else if constexpr (X == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x128, 0xF, 0xF, true));
+  else if constexpr (X == 16) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x401F));
+  else return __shfl_xor(v, X, 64);
+}
+
+// max(v, v of lane ^ X) in ONE vector instruction for X = 1 / 8 (v_max_f32 with a DPP operand; the compiler's own sequence is
+// v_mov_dpp + a canonicalising v_max + v_max).  `s_nop 1`: a DPP read of a register needs two wait states after the VALU
+// write of it, and the hazard recogniser does not look inside asm statements.
+template <int X>
+__device__ __forceinline__ float max_lane_xor(float v) {
+  if constexpr (X == 1) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+    return r;
+  } else if constexpr (X == 8) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+    return r;
+  } else {
+    return fmaxf(v, lane_xor<X>(v));
+  }
+}
+
+// raw buffer descriptor over `bytes` bytes at p (wave-uniform arguments only: the four words live in SGPRs).  Accesses whose
+// byte offset is >= bytes are dropped by the hardware: loads return 0, stores write nothing.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// channel groups the staging threads split a chunk into: the most groups of PLANE_E threads that fit the workgroup and divide CK
+constexpr int conv_stage_groups(int nthr, int plane_e, int ck) {
+  int ng = nthr / plane_e;
+  while (ng > 1 && ck % ng != 0) --ng;
+  return ng < 1 ? 1 : ng;
 }
 
 // KS: 1|3.  TH x TW: spatial tile (KS==1: flat run of TH*TW pixels).  Waves are arranged
 // WM (output-channel groups) x WN (pixel groups); each wave owns MT x NT MFMA tiles of 32x32, with
 // WM*MT == 2 (64 output channels per workgroup).  CK: input channels staged per LDS round.
 // POOL: fuse MaxPool2d(2,2).
-// EXACT: Cin is a whole multiple of CK (every layer but the thin first ones): chunks reload through
-// constant per-thread element offsets from a uniform base pointer that advances with the chunk, with
-// no per-element multiplies, clamps or 64-bit address arithmetic in the steady state.
 // XTRA (1x1 layers with 64 n + 1 output channels: the detector's 65): the last channel is NOT given a channel tile of its own
 // (63 of 64 rows padding: half of the 256 -> 65 layer's matrix-core time); the workgroups of the last whole tile
 // accumulate it beside their MFMAs, one pixel per lane, as the same k-ordered fmaf chain from +0 (v_fma_f32 on the LDS tile).
-template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool EXACT, bool XTRA = false>
-#ifndef EINX_THIN_WAVES
-#define EINX_THIN_WAVES 6  // thin first layers: cap registers so three 8-wave workgroups share a CU (their load -> MFMA -> store phases only overlap across workgroups)
-#endif
-#ifndef EINX_CONV_DEPTH
-#define EINX_CONV_DEPTH 1
-#endif
-// minimum waves per SIMD the register allocation must allow: thin first layers see above; with two chunks of staging
-// registers in flight (EINX_CONV_DEPTH 2) the 8-wave kernels are held at two workgroups per CU, the 4-wave ones at three
-__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CONV_DEPTH == 2 ? (WM * WN >= 8 ? 4 : 3) : 1))) void conv_block_kernel(const ConvArgs a) {
+//
+// Round 5 -- every vector instruction outside the MFMA loop is paid in matrix-pipe time.  fp32 MFMA and fp32 VALU share the
+// SIMD's datapath (tools/coexec_ceiling.hip: one wave of each reaches 65.6 + 65.6 TFLOP/s, not 144 + 118), and across the
+// 8-wave variants of round 4 the idle share of the matrix pipe fits ~8 cycles per VALU instruction (conv1b 1.4 VALU per MFMA ->
+// 0.84 busy, event-side first layer 10.9 -> 0.42, 1x1 heads 8.8 -> 0.46; profiles/r03_pmc_conv_tiles.json).  So:
+//   * staging is position-major: a thread owns ONE halo position (one division by the halo width, one bounds / replicate
+//     clamp) and brings in that position of every channel of the chunk.  Channel planes are stepped in the wave-uniform
+//     buffer descriptor (scalar ALU), not in per-element vector address arithmetic: one offset register, no 64-bit adds.
+//   * zero padding costs nothing per chunk: positions outside the image are zeroed in LDS once and their threads sit out the
+//     loads and commits (EXEC mask); channels past Cin fall outside the descriptor and load as 0.  The generic and the
+//     "exact" reload paths of rounds 1-4 are one path now (half the instantiations).
+//   * epilogue: ReLU / affine flags are hoisted into four straight-line bodies; the per-channel constants come as three
+//     ds_read_b128 per 4 rows; the 2x2 pool exchanges lanes by DPP; stores go through a descriptor re-based per output
+//     channel in the scalar ALU, pixels outside the image carry an out-of-range offset (no branches, no 64-bit multiplies).
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool XTRA = false>
+__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : 1)) void conv_block_kernel(const ConvArgs a) {  // thin first layers: registers capped so that three 8-wave workgroups share a CU
   constexpr int kMT = MT, kNT = NT;
   constexpr int NW = WM * WN;
   constexpr int TAPS = KS * KS;
@@ -96,39 +139,29 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   constexpr int PITCH = KS == 1 ? PW : conv_lds_pitch(TH, TW);  // LDS row pitch (bank-conflict-free B reads)
   constexpr int PLANE = PH * PITCH;                             // LDS floats per staged channel
   constexpr int PLANE_E = PH * PW;                              // elements staged per channel
-  constexpr bool PADDED = PITCH != PW;
   constexpr int NTHR = NW * 64;
   constexpr int NPIX = TH * TW;
   static_assert(WM * MT * 32 == kCoutTile, "a workgroup covers 64 output channels");
   static_assert(WN * NT * 32 >= NPIX, "tile does not fit the workgroup's pixel slots");
   static_assert(KS == 1 || NPIX >= 32, "unused slots alias the slot one run earlier");
   static_assert(CK % 2 == 0, "channels are consumed in pairs");
-  constexpr int IN_ELEMS = CK * PLANE_E;
+  static_assert(PLANE_E <= NTHR, "one staging thread per halo position");
+  constexpr int NG = conv_stage_groups(NTHR, PLANE_E, CK);  // channel groups among the staging threads
+  constexpr int CPT = CK / NG;                              // channels a staging thread brings in per chunk
   constexpr int IN_LDS = CK * PLANE;
   static_assert(IN_LDS % 4 == 0, "the weight tile behind the input tile is float4 aligned");
-  constexpr int IN_PER_THR = (IN_ELEMS + NTHR - 1) / NTHR;
   constexpr int W_ROWS = CK * TAPS;
   constexpr int W_F4 = W_ROWS * kCoutTile / 4;
   constexpr int W_PER_THR = (W_F4 + NTHR - 1) / NTHR;
-  constexpr int POOL_ELEMS = 0;  // pooling is done in registers
-  constexpr int LDS_FLOATS = (IN_LDS + W_ROWS * kCoutTile) > POOL_ELEMS ? (IN_LDS + W_ROWS * kCoutTile) : POOL_ELEMS;
+  constexpr int LDS_FLOATS = IN_LDS + W_ROWS * kCoutTile;
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  __shared__ float s_bias[kCoutTile], s_scale[kCoutTile], s_shift[kCoutTile];  // epilogue constants
+  __shared__ __attribute__((aligned(16))) float s_bias[kCoutTile], s_scale[kCoutTile], s_shift[kCoutTile];  // epilogue constants
   float* in_tile = lds;
   float* w_tile = lds + IN_LDS;
 
-#if defined(EINX_CONV_STAGGER) && EINX_CONV_STAGGER > 0
-  // experiment (tools/experiments/r3_exp9.sh): are the two co-resident workgroups of a CU in lockstep (same start, same length, so their
-  // prologues, epilogues and chunk boundaries coincide)?  Delay the second resident round once; later workgroups inherit it.
-  {
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-    if (lin >= 256u && lin < 512u)
-      for (int i = 0; i < EINX_CONV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles = 3.4 us each
-  }
-#endif
   const int tid = threadIdx.x;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and provably so for the compiler (scalar registers)
   const int wm = wave / WN, wn = wave % WN;
   const int lane = tid & 63;
   const int half = lane >> 5;
@@ -145,12 +178,12 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   const int ty_i = bid % a.tilesY;
   const int b = bid / a.tilesY;
 
-  if (threadIdx.x < kCoutTile) {  // visible to everyone after the main loop's first barrier
-    const int co = co0 + threadIdx.x;
+  if (tid < kCoutTile) {  // visible to everyone after the main loop's first barrier
+    const int co = co0 + tid;
     const bool cv = co < a.Cout;
-    s_bias[threadIdx.x] = (cv && a.bias) ? a.bias[co] : 0.0f;
-    s_scale[threadIdx.x] = (cv && a.scale) ? a.scale[co] : 1.0f;
-    s_shift[threadIdx.x] = (cv && a.scale) ? a.shift[co] : 0.0f;
+    s_bias[tid] = (cv && a.bias) ? a.bias[co] : 0.0f;
+    s_scale[tid] = (cv && a.scale) ? a.scale[co] : 1.0f;
+    s_shift[tid] = (cv && a.scale) ? a.shift[co] : 0.0f;
   }
   const int HW = a.H * a.W;
   int y0, x0, p0;
@@ -188,42 +221,44 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   }
   const int aBase = half * kCoutTile + wm * MT * 32 + j;
 
-  // ---- staging plan: which global words this thread brings in each round -----------------
-  const size_t src_plane = (size_t)a.Hs * a.Ws;
+  // ---- staging plan: this thread's halo position, the same in every channel of every chunk -----
+  const unsigned src_plane = (unsigned)(a.Hs * a.Ws);
   const float* in_b = a.in + (size_t)b * a.Cin * src_plane;
-  int g_off[IN_PER_THR];  // offset inside a source channel plane, -1 = structural zero
-  int g_ci[IN_PER_THR];   // (generic path) channel inside the chunk
-  unsigned goff[IN_PER_THR];  // (EXACT path) element offset from the chunk's first channel plane
-  unsigned okmask = 0;        // (EXACT path) bit i: element i is a real pixel (not padding / tail)
-  int lds_off[PADDED ? IN_PER_THR : 1];  // (padded pitch) where element i goes in the LDS tile
+  const int pos = NG == 1 ? tid : tid % PLANE_E;
+  const int grp = NG == 1 ? 0 : tid / PLANE_E;
+  const bool s_active = NG * PLANE_E == NTHR || tid < NG * PLANE_E;
+  int src_off = -1, lds_pos;
+  if (KS == 1) {
+    const int p = p0 + pos;
+    if (p < HW) src_off = p;  // 1x1 layers never carry the replicate fold
+    lds_pos = grp * CPT * PLANE + pos;
+  } else {
+    const int py = pos / PW, px = pos % PW;
+    const int y = y0 - HALO + py, x = x0 - HALO + px;
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+      int sy = y - a.h0, sx = x - a.w0;
+      sy = sy < 0 ? 0 : (sy > a.Hs - 1 ? a.Hs - 1 : sy);
+      sx = sx < 0 ? 0 : (sx > a.Ws - 1 ? a.Ws - 1 : sx);
+      src_off = sy * a.Ws + sx;
+    }
+    lds_pos = grp * CPT * PLANE + py * PITCH + px;
+  }
+  const bool s_ok = s_active && src_off >= 0;
+  // byte offset of this thread's element of channel i (+ CPT grp) of a chunk, from the chunk's first channel plane: the chunk
+  // itself is stepped in the descriptor's base (scalar ALU), so these registers never change
+  unsigned in_voff[CPT];
 #pragma unroll
-  for (int i = 0; i < IN_PER_THR; ++i) {
-    const int e = tid + i * NTHR;
-    int off = -1, cil = 0;
-    if (e < IN_ELEMS) {
-      cil = e / PLANE_E;
-      const int r = e % PLANE_E;
-      if (PADDED) lds_off[i] = cil * PLANE + (r / PW) * PITCH + r % PW;
-      if (KS == 1) {
-        const int p = p0 + r;
-        if (p < HW) off = p;  // 1x1 layers never carry the replicate fold
-      } else {
-        const int y = y0 - HALO + r / PW, x = x0 - HALO + r % PW;
-        if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-          int sy = y - a.h0, sx = x - a.w0;
-          sy = sy < 0 ? 0 : (sy > a.Hs - 1 ? a.Hs - 1 : sy);
-          sx = sx < 0 ? 0 : (sx > a.Ws - 1 ? a.Ws - 1 : sx);
-          off = sy * a.Ws + sx;
-        }
-      }
-    }
-    if (EXACT) {
-      goff[i] = (unsigned)cil * (unsigned)src_plane + (unsigned)(off >= 0 ? off : 0);
-      okmask |= (off >= 0 ? 1u : 0u) << i;
-    } else {
-      g_off[i] = off;
-      g_ci[i] = cil;
-    }
+  for (int i = 0; i < CPT; ++i) in_voff[i] = ((unsigned)(src_off >= 0 ? src_off : 0) + (unsigned)(grp * CPT + i) * src_plane) * 4u;
+  if (s_active && src_off < 0) {  // padding: zero once, never written again
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) in_tile[lds_pos + i * PLANE] = 0.0f;
+  }
+  unsigned woff[W_PER_THR];  // byte offset of this thread's weight float4 inside a chunk's rows
+#pragma unroll
+  for (int i = 0; i < W_PER_THR; ++i) {
+    const int f = tid + i * NTHR;
+    const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
+    woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4) * 4u;
   }
 
   f32x16 acc[kMT][kNT];
@@ -240,73 +275,36 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   float xacc = 0.0f;                                                      // XTRA: the extra channel of pixel p0 + tid
   const bool xtra_wg = XTRA && co0 + kCoutTile == a.CoutPad - kCoutTile;  // the last whole channel tile carries it
 
-  // Register image of one chunk in flight (global -> registers -> LDS).  DEPTH chunks are in flight: the loads of chunk
-  // c + DEPTH are issued when chunk c has been committed to LDS, i.e. they have DEPTH chunks of MFMAs to land.
-  // Measured (tools/experiments/r3_exp10.sh, timing-only ablations): with DEPTH = 1 the per-chunk global loads cost conv1b 10 % (1653 us
-  // against 1485 us with the same commits fed from registers loaded once) although they are issued a whole chunk ahead.
+  // Register image of one chunk in flight (global -> registers -> LDS): the loads of chunk c + 1 are issued when chunk c has
+  // been committed to LDS and land under its MFMAs (issue early, write late).
   struct StageRegs {
-    float in[IN_PER_THR];
+    float in[CPT];
     f32x4 w[W_PER_THR];
-    unsigned pend;  // (generic path) validity bits
   };
-  constexpr int DEPTH = (CK >= 8 && EINX_CONV_DEPTH == 2) ? 2 : 1;
-  StageRegs sA, sB;
-  sA.pend = sB.pend = 0;
-
-  unsigned woff[W_PER_THR];  // (EXACT path) element offset of this thread's weight float4 inside a chunk's rows
-  if (EXACT) {
-#pragma unroll
-    for (int i = 0; i < W_PER_THR; ++i) {
-      const int f = tid + i * NTHR;
-      const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
-      woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4);
-    }
-  }
-  auto issue_loads = [&](int c, StageRegs& sr) {
-    if (EXACT) {
-      const float* ib = in_b + (size_t)c * CK * src_plane;
-#pragma unroll
-      for (int i = 0; i < IN_PER_THR; ++i) sr.in[i] = ib[goff[i]];  // padding is masked at commit time
-      const float* wb = a.w + (size_t)c * W_ROWS * a.CoutPad;
-#pragma unroll
-      for (int i = 0; i < W_PER_THR; ++i) sr.w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
-      return;
-    }
+  StageRegs sA;
+  auto issue_loads = [&](int c) {
     const int ci0 = c * CK;
+    if (s_ok) {
+      // the descriptor spans channels ci0 .. Cin - 1 of this image: channels past Cin lie outside it and load as 0
+      const __amdgpu_buffer_rsrc_t rs = conv_rsrc(in_b + (size_t)ci0 * src_plane, (unsigned)(a.Cin - ci0) * src_plane * 4u);
 #pragma unroll
-    for (int i = 0; i < IN_PER_THR; ++i) {
-      // unconditional load from a clamped (always valid) address, then select: no branches
-      const int ci = ci0 + g_ci[i];
-      const bool ok = g_off[i] >= 0 && ci < a.Cin;
-      sr.in[i] = in_b[(size_t)(ci < a.Cin ? ci : a.Cin - 1) * src_plane + (g_off[i] >= 0 ? g_off[i] : 0)];
-      sr.pend = (sr.pend & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+      for (int i = 0; i < CPT; ++i) sA.in[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, in_voff[i], 0, 0));
     }
-    const int krow0 = c * W_ROWS;
+    // the native weight image is zero-padded to whole 32-channel row groups (einx_conv_repack): every row a chunk names exists
+    const __amdgpu_buffer_rsrc_t rw = conv_rsrc(a.w + (size_t)c * W_ROWS * a.CoutPad, (unsigned)(W_ROWS * a.CoutPad) * 4u);
 #pragma unroll
-    for (int i = 0; i < W_PER_THR; ++i) {
-      const int f = tid + i * NTHR;
-      const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
-      // the native weight image is zero-padded to whole 16-channel row groups (einx_conv_repack),
-      // so every row a chunk can name exists; only the thread-count tail is clamped
-      const int rr = (f < W_F4) ? r : 0;
-      sr.w[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(krow0 + rr) * a.CoutPad + co0 + c4 * 4);
-    }
+    for (int i = 0; i < W_PER_THR; ++i)
+      if ((i + 1) * NTHR <= W_F4 || tid + i * NTHR < W_F4)
+        sA.w[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[i], 0, 0));
   };
-  // The zero for padding / channel-tail elements is selected here, when the value is consumed: a select
-  // right after the load would make the wave wait for the load before it starts the MFMAs the load is
-  // meant to fly under.
-  auto commit_loads = [&](const StageRegs& sr) {
-    const unsigned m = EXACT ? okmask : sr.pend;
+  auto commit_loads = [&]() {
+    if (s_ok) {
 #pragma unroll
-    for (int i = 0; i < IN_PER_THR; ++i) {
-      const int e = tid + i * NTHR;
-      if (e < IN_ELEMS) in_tile[PADDED ? lds_off[i] : e] = ((m >> i) & 1u) ? sr.in[i] : 0.0f;
+      for (int i = 0; i < CPT; ++i) in_tile[lds_pos + i * PLANE] = sA.in[i];
     }
 #pragma unroll
-    for (int i = 0; i < W_PER_THR; ++i) {
-      const int f = tid + i * NTHR;
-      if (f < W_F4) *reinterpret_cast<f32x4*>(w_tile + f * 4) = sr.w[i];
-    }
+    for (int i = 0; i < W_PER_THR; ++i)
+      if ((i + 1) * NTHR <= W_F4 || tid + i * NTHR < W_F4) *reinterpret_cast<f32x4*>(w_tile + (tid + i * NTHR) * 4) = sA.w[i];
   };
   // 36 K-steps (CK/2 channel pairs x taps), software pipelined: the LDS fragments of step t+1
   // are requested before the MFMAs of step t so that no MFMA group waits on a fresh ds_read.
@@ -332,43 +330,28 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
       for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < kNT; ++nt)
-#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL_NOMFMA)  // timing-only: operands consumed by one VALU op instead of an MFMA
-          acc[mt][nt][0] += av[st % (PF + 1)][mt] * bv[st % (PF + 1)][nt];
-#else
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % (PF + 1)][mt], bv[st % (PF + 1)][nt], acc[mt][nt], 0, 0, 0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto round = [&](int c, StageRegs& sr) {
+  issue_loads(0);
+  for (int c = 0; c < nchunks; ++c) {
     __syncthreads();  // previous round's LDS reads are done
-    commit_loads(sr);
+    commit_loads();
     __syncthreads();
-#ifdef EINX_CONV_ABL_NOLOADS  // timing-only ablation (wrong results, tools/experiments/r3_exp10.sh / r3_exp11.sh): every chunk recommits chunk 0's registers
-    if (false)
-#endif
-    if (c + DEPTH < nchunks) issue_loads(c + DEPTH, sr);  // in flight under the MFMAs of the next DEPTH chunks
+    if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under this chunk's MFMAs
     mfma_chunk();
     if (XTRA && xtra_wg && tid < NPIX) {  // rows of a 1x1 layer's native weight image are the input channels in order
       const float* wx = a.w + (size_t)c * W_ROWS * a.CoutPad + (a.CoutPad - kCoutTile);
 #pragma unroll
       for (int r = 0; r < CK; ++r) xacc = fmaf(wx[(size_t)r * a.CoutPad], in_tile[r * PLANE + tid], xacc);
     }
-  };
-  issue_loads(0, sA);
-  if (DEPTH == 2) {
-    if (nchunks > 1) issue_loads(1, sB);
-    for (int c = 0; c < nchunks; c += 2) {
-      round(c, sA);
-      if (c + 1 < nchunks) round(c + 1, sB);
-    }
-  } else {
-    for (int c = 0; c < nchunks; ++c) round(c, sA);
   }
 
   // ---- epilogue: bias -> ReLU -> BN affine -> (pool) -> NCHW store -------------------------
   const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
-  float* out_b = a.out + (size_t)b * a.Cout * Ho * Wo;
+  const unsigned plane_o = (unsigned)(Ho * Wo);
+  float* out_b = a.out + (size_t)b * a.Cout * plane_o;
   if (XTRA && xtra_wg && tid < NPIX && p0 + tid < HW) {
     const int co = a.CoutPad - kCoutTile;  // == Cout - 1
     float v = xacc + (a.bias ? a.bias[co] : 0.0f);
@@ -381,64 +364,84 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? EINX_THIN_WAVES : (EINX_CON
   // j^TW inside one N-tile (TW in {8,16}: an N-tile holds 32/TW whole rows).
   static_assert(!POOL || TW == 32 || TW == 16 || TW == 8, "in-register pooling needs TW in {8,16,32}");
   static_assert(!POOL || TW != 32 || (NT % 2 == 0), "TW == 32 pools across N-tile pairs");
-  int ppix[kNT];  // pooled output offset inside a channel plane (valid on the window's top-left lane)
-  if (POOL) {
+  // Byte offset of each output this lane stores, inside the descriptor of one accumulator row: the row's channel for lanes
+  // 0-31 starts at byte 0, the channel of lanes 32-63 lies four planes up; all ones = nothing to store (dropped by the range check)
+  constexpr int NO = (POOL && TW == 32) ? kNT / 2 : kNT;
+  unsigned ovoff[NO];
 #pragma unroll
-    for (int nt = 0; nt < kNT; ++nt) {
-      ppix[nt] = -1;
-      const int q = qidx[nt];
+  for (int o = 0; o < NO; ++o) {
+    int pix;
+    if (POOL) {
+      pix = -1;
+      const int q = qidx[(TW == 32) ? 2 * o : o];
       if (q >= 0) {
         const int ty = q / TW, tx = q % TW;
         const int yo = (y0 + ty) >> 1, xo = (x0 + tx) >> 1;
-        if (!(ty & 1) && !(tx & 1) && yo < Ho && xo < Wo) ppix[nt] = yo * Wo + xo;
+        if (!(ty & 1) && !(tx & 1) && yo < Ho && xo < Wo) pix = yo * Wo + xo;  // the window's top-left lane stores
       }
+    } else {
+      pix = opix[o];
     }
+    ovoff[o] = pix >= 0 ? ((unsigned)pix + (unsigned)(4 * half) * plane_o) * 4u : 0xFFFFFFFFu;
   }
-  {
+  auto epilogue = [&](auto relu_c, auto aff_c) {
+    constexpr bool RELU = decltype(relu_c)::value, AFF = decltype(aff_c)::value;
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-      const int crow = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int co = co0 + (wm * MT + mt) * 32 + crow;
-      const bool cv = co < a.Cout;
-      const int cl = (wm * MT + mt) * 32 + crow;
-      const float bi = s_bias[cl], sc = s_scale[cl], sh = s_shift[cl];
-      float pv[kNT];
-#pragma unroll
-      for (int nt = 0; nt < kNT; ++nt) {
-        float v = acc[mt][nt][r] + bi;
-        if (a.relu) v = v > 0.0f ? v : 0.0f;
-        if (a.scale) v = fmaf(v, sc, sh);
-        if (POOL) {
-          pv[nt] = v;
-        } else {
-#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL_NOSTORE)  // timing-only: the un-pooled layers store one element per lane and channel
-          if (cv && opix[nt] >= 0 && v == 12345.678f) out_b[(size_t)co * HW + opix[nt]] = v;
-#else
-          if (cv && opix[nt] >= 0) out_b[(size_t)co * HW + opix[nt]] = v;
-#endif
+      for (int g = 0; g < 4; ++g) {
+        // accumulator rows 4g .. 4g+3 are channels cl0 + 4 half + (0..3) of the workgroup's 64
+        const int cl0 = (wm * MT + mt) * 32 + 8 * g;
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(&s_bias[cl0 + 4 * half]);
+        f32x4 sc, sh;
+        if (AFF) {
+          sc = *reinterpret_cast<const f32x4*>(&s_scale[cl0 + 4 * half]);
+          sh = *reinterpret_cast<const f32x4*>(&s_shift[cl0 + 4 * half]);
         }
-      }
-      if (POOL) {
-        if (TW == 32) {
 #pragma unroll
-          for (int nt = 0; nt < kNT; nt += 2) {
-            float m = fmaxf(pv[nt], pv[nt + 1]);        // rows 2k, 2k+1
-            m = fmaxf(m, __shfl_xor(m, 1, 64));          // columns 2c, 2c+1
-            if (cv && ppix[nt] >= 0) out_b[(size_t)co * Ho * Wo + ppix[nt]] = m;
-          }
-        } else {
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          const int co_r = co0 + cl0 + i;  // channel of lanes 0-31; lanes 32-63 hold channel co_r + 4
+          const int nch = a.Cout - co_r > 0 ? a.Cout - co_r : 0;  // channels co_r .. Cout - 1 (none: every store of the row is dropped)
+          const __amdgpu_buffer_rsrc_t ro = conv_rsrc(out_b + (size_t)co_r * plane_o, (unsigned)nch * plane_o * 4u);
+          float pv[kNT];
 #pragma unroll
           for (int nt = 0; nt < kNT; ++nt) {
-            float m = fmaxf(pv[nt], __shfl_xor(pv[nt], TW, 64));
-            m = fmaxf(m, __shfl_xor(m, 1, 64));
-            if (cv && ppix[nt] >= 0) out_b[(size_t)co * Ho * Wo + ppix[nt]] = m;
+            float v = acc[mt][nt][r] + bi[i];
+            if (RELU) v = fmaxf(v, 0.0f);  // v_max_f32: max(-0, +0) = +0 and max(NaN, 0) = 0, as `v > 0 ? v : 0`
+            if (AFF) v = fmaf(v, sc[i], sh[i]);
+            pv[nt] = v;
+          }
+          if (!POOL) {
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[nt]), ro, ovoff[nt], 0, 0);
+          } else if (TW == 32) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+              float m = fmaxf(pv[2 * o], pv[2 * o + 1]);  // rows 2k, 2k+1
+              m = max_lane_xor<1>(m);                     // columns 2c, 2c+1
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ro, ovoff[o], 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+              float m = max_lane_xor<TW>(pv[nt]);  // rows 2k, 2k+1
+              m = max_lane_xor<1>(m);              // columns 2c, 2c+1
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ro, ovoff[nt], 0, 0);
+            }
           }
         }
       }
-      }
     }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  if (a.relu) {
+    if (a.scale) epilogue(T_{}, T_{});
+    else epilogue(T_{}, F_{});
+  } else {
+    if (a.scale) epilogue(F_{}, T_{});
+    else epilogue(F_{}, F_{});
   }
 }
 
@@ -730,16 +733,6 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean
 // channels (the largest chunk any kernel variant stages) so that chunk loads never need bounds
 int native_krows(int cin, int taps) { return einx_cdiv(cin, 32) * 32 * taps; }
 
-// tuning switch (tools only): EINX_CONV_EXP=<bitmask> selects experimental wave layouts, read once per process
-int conv_exp() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("EINX_CONV_EXP");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
 thread_local const char* g_last_conv_kernel = "";
 
 struct TileCfg {
@@ -748,23 +741,15 @@ struct TileCfg {
 
 template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
 void launch(const ConvArgs& a, int B, hipStream_t s) {
-  // the offset-table reload (EXACT) is used where it measured faster (bench.py --layer-table, B=32): every
-  // 3x3 tile except 11x22, whose 768-workgroup launches on the 256-channel heads ran 20 % slower with it, and (round 4)
-  // the heads' 1x1 layers (256 -> 65: 42.0 -> 36.2 us, 256 -> 256: 75.7 -> 73.4 us; 64-channel chunks measured slower)
-  const bool exact = (a.Cin % CK) == 0 && (!(TH == 11 && TW == 22) || ((conv_exp() & 8) && a.Cin <= 64));
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
   {
     // name of the instantiation this call launches (einx_conv_last_kernel: measurement provenance)
-    static char names[2][96] = {{0}, {0}};
-    char* nm = names[exact ? 1 : 0];
-    if (!nm[0])
-      snprintf(nm, sizeof(names[0]), "conv_block_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%s,%s>", KS, TH, TW, WM, WN, MT, NT, CK, POOL ? "true" : "false",
-               exact ? "true" : "false");
+    static char nm[96] = {0};
+    if (!nm[0]) snprintf(nm, sizeof nm, "conv_block_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%s>", KS, TH, TW, WM, WN, MT, NT, CK, POOL ? "true" : "false");
     g_last_conv_kernel = nm;
   }
   EINX_PROF(KS == 1 ? "conv_block_kernel 1x1" : (CK < 8 ? "conv_block_kernel 3x3 first layer" : "conv_block_kernel 3x3"), s);
-  if (exact) hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, true>), grid, dim3(WM * WN * 64), 0, s, a);
-  else hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, false>), grid, dim3(WM * WN * 64), 0, s, a);
+  hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
 // waste = slots launched / pixels useful, for picking a tile shape per layer
@@ -817,7 +802,9 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   EINX_CHECK_ARG(!d->pool || (H % 2 == 0 && W % 2 == 0), "pooling needs even H and W");
   EINX_CHECK_ARG(d->ks == 3 || (Hs == H && Ws == W && h0 == 0 && w0 == 0), "1x1 layers take no padding fold");
   EINX_CHECK_ARG(d->ks == 3 || !d->pool, "pooled 1x1 not supported");
-  EINX_CHECK_ARG((size_t)H * W < (1u << 30) && (size_t)Hs * Ws < (1u << 30), "image too large");
+  // byte offsets inside one image's [C,H,W] tensor are 32-bit (buffer descriptors per image)
+  EINX_CHECK_ARG((size_t)d->cin * Hs * Ws < (1u << 30) && (size_t)d->cout * H * W < (1u << 30) && (size_t)d->cin * H * W < (1u << 30),
+                 "image too large (2^30 elements per image and tensor)");
   hipStream_t s = (hipStream_t)stream;
   ConvArgs a;
   a.in = in;
@@ -843,7 +830,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     const long blocks256 = (long)einx_cdiv(H * W, 256) * B * (a.CoutPad / kCoutTile);
     a.tilesY = 1;
     {  // small grids: one 16x16 accumulator per wave (conv16_1x1_kernel), the widest pixel run that still gives 512 workgroups
-      static const long max_wg128 = getenv("EINX_CONV16_1X1_MAX_WG") ? atol(getenv("EINX_CONV16_1X1_MAX_WG")) : 512;
+      const long max_wg128 = 512;
       const long blocks128 = (long)einx_cdiv(H * W, 128) * B * (a.CoutPad / kCoutTile);
       if (blocks128 < max_wg128 && d->cin % 32 == 0) {
         int npw = 1;
@@ -865,16 +852,15 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         return EINX_OK;
       }
     }
-    static const long min256 = getenv("EINX_CONV_1X1_MIN256") ? atol(getenv("EINX_CONV_1X1_MIN256")) : 1024;  // tuning aid
+    const long min256 = 1024;
     if (blocks256 < min256) {
       a.tilesX = einx_cdiv(H * W, 128);
-      static const bool no_xtra = getenv("EINX_CONV_NO_XTRA") != nullptr;
-      if (d->cout == a.CoutPad - kCoutTile + 1 && d->cout > kCoutTile && d->cin % 32 == 0 && !no_xtra) {
+      if (d->cout == a.CoutPad - kCoutTile + 1 && d->cout > kCoutTile && d->cin % 32 == 0) {
         // 64 n + 1 output channels (the detector's 65): n channel tiles, the last one also carries channel 64 n (see XTRA)
         dim3 grid((unsigned)(a.tilesX * B), (unsigned)(a.CoutPad / kCoutTile - 1));
-        g_last_conv_kernel = "conv_block_kernel<1,1,128,1,4,2,1,32,false,true,xtra>";
+        g_last_conv_kernel = "conv_block_kernel<1,1,128,1,4,2,1,32,false,xtra>";
         EINX_PROF("conv_block_kernel 1x1", s);
-        hipLaunchKernelGGL((conv_block_kernel<1, 1, 128, 1, 4, 2, 1, 32, false, true, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_block_kernel<1, 1, 128, 1, 4, 2, 1, 32, false, true>), grid, dim3(256), 0, s, a);
       } else {
         launch<1, 1, 128, 1, 4, 2, 1, 32, false>(a, B, s);
       }
@@ -918,12 +904,12 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     // the finest grain: one 16x16 accumulator per wave on the 16x16x4 instruction, when even that leaves SIMDs to spare
     // (MFMA tiles = pixels / 16 x channels / 16 <= EINX_CONV16_MAX_TILES) -- see conv16_kernel
     {
-      static const long max_tiles = getenv("EINX_CONV16_MAX_TILES") ? atol(getenv("EINX_CONV16_MAX_TILES")) : 8192;
+      const long max_tiles = 8192;
       const long t16 = (long)einx_cdiv(H, 2) * einx_cdiv(W, 8) * B * (a.CoutPad / 16);
       if (blocks_best < 512 && d->cin % 8 == 0 && Hs == H && Ws == W && h0 == 0 && w0 == 0 && t16 <= max_tiles && (!d->pool || (H % 2 == 0 && W % 2 == 0))) {
         // pixels per workgroup: the widest tile that still leaves every CU two workgroups (weights are re-streamed per
         // workgroup; measured at B=1: 132x176 layers 28 -> 24.5 us with two N-tiles per wave, 29 with one or four)
-        static const long min_wg = getenv("EINX_CONV16_MIN_WG") ? atol(getenv("EINX_CONV16_MIN_WG")) : 512;
+        const long min_wg = 512;
         int npw = 1;
         for (int cand = 4; cand > 1; cand >>= 1)
           if ((long)einx_cdiv(H, 2) * einx_cdiv(W, 8 * cand) * B * (a.CoutPad / kCoutTile) >= min_wg) {
@@ -952,7 +938,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         return EINX_OK;
       }
     }
-    if (blocks_best < 512 && d->cin > 6 && !(conv_exp() & 32)) {
+    if (blocks_best < 512 && d->cin > 6) {
       struct Lat {
         int th, tw, unit;  // unit = waves per SIMD x accumulator tiles per wave
       };
@@ -969,12 +955,6 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
           best_est = est;
           pick = i;
         }
-      }
-      {  // tuning aid: force the candidate (tools only)
-        static const int force_p = getenv("EINX_CONV_SMALL_PICK_P") ? atoi(getenv("EINX_CONV_SMALL_PICK_P")) : -1;
-        static const int force_n = getenv("EINX_CONV_SMALL_PICK_N") ? atoi(getenv("EINX_CONV_SMALL_PICK_N")) : -1;
-        const int f = d->pool ? force_p : force_n;
-        if (f >= 0 && f < nc) pick = f;
       }
       a.tilesX = einx_cdiv(W, cand[pick].tw);
       a.tilesY = einx_cdiv(H, cand[pick].th);
@@ -1008,14 +988,8 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   if (d->pool) {
     switch (best) {
       case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s); break;
-      case 1:
-        if (conv_exp() & 1) launch<3, 12, 16, 2, 6, 1, 1, 8, true>(a, B, s);
-        else launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s);
-        break;
-      default:
-        if (conv_exp() & 2) launch<3, 22, 8, 2, 6, 1, 1, 8, true>(a, B, s);
-        else launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s);
-        break;
+      case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
+      default: launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s); break;
     }
   } else {
     switch (best) {
@@ -1027,10 +1001,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
       case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;
-      case 3:
-        if (conv_exp() & 4) launch<3, 11, 22, 2, 8, 1, 1, 8, false>(a, B, s);
-        else launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s);
-        break;
+      case 3: launch<3, 11, 22, 2, 4, 1, 2, 8, false>(a, B, s); break;
       default: launch<3, 11, 11, 2, 2, 1, 2, 8, false>(a, B, s); break;
     }
   }
