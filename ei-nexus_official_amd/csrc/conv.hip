@@ -129,7 +129,13 @@ constexpr int conv_stage_groups(int nthr, int plane_e, int ck) {
 //     ds_read_b128 per 4 rows; the 2x2 pool exchanges lanes by DPP; stores go through a descriptor re-based per output
 //     channel in the scalar ALU, pixels outside the image carry an out-of-range offset (no branches, no 64-bit multiplies).
 template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool XTRA = false>
-__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : 1)) void conv_block_kernel(const ConvArgs a) {  // thin first layers: registers capped so that three 8-wave workgroups share a CU
+#ifndef EINX_CONV_WPS8
+#define EINX_CONV_WPS8 1
+#endif
+#ifndef EINX_CONV_WPS4
+#define EINX_CONV_WPS4 1
+#endif
+__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : (WM * WN >= 8 ? EINX_CONV_WPS8 : EINX_CONV_WPS4))) void conv_block_kernel(const ConvArgs a) {  // thin first layers: registers capped so that three 8-wave workgroups share a CU
   constexpr int kMT = MT, kNT = NT;
   constexpr int NW = WM * WN;
   constexpr int TAPS = KS * KS;
@@ -891,9 +897,12 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     const long blocks = (long)einx_cdiv(H, cfgs[best].th) * einx_cdiv(W, cfgs[best].tw) * B * (a.CoutPad / kCoutTile);
     if (blocks < 640 && tile_waste(H, W, cfgs[4]) <= bw * 1.05 + 1e-9) best = 4;
   }
-  // an 8-wave 11x22 tile beats the 4-wave 192-slot tiles even at ~6 % more pixel slots (132x176: 3072 workgroups
-  // = six full rounds of two per CU; measured +3 % on that layer)
-  if (!d->pool && (best == 1 || best == 2) && tile_waste(H, W, cfgs[3]) <= bw * 1.06 + 1e-9) best = 3;
+  // (rounds 2-4 preferred the 8-wave 11x22 tile over the 4-wave 192-slot tiles at up to 6 % more pixel slots; with the
+  // round-5 kernel the exact 12x16 tiling of the 132x176 maps is 10 % faster: 455 -> 412 us at B=32)
+  {  // TEMPORARY tuning aid (round 5): force the tile
+    static const int force = (getenv("EINX_CONV_TILE") && *getenv("EINX_CONV_TILE")) ? atoi(getenv("EINX_CONV_TILE")) : -1;
+    if (force >= 0 && force <= 4 && d->cin > 6 && !(d->pool && ((cfgs[force].th & 1) || (cfgs[force].tw & 1)))) best = force;
+  }
   {
     // Small grids (single images: the reference's own call pattern): the launch does not fill the chip, so what counts is the
     // LATENCY of one workgroup = (waves it puts on a SIMD) x (accumulator tiles per wave) x K-steps x 64 cycles -- the k-ordered

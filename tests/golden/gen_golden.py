@@ -479,6 +479,8 @@ EVENT_CASES = [
     dict(name="int_p01", seed=71, n=3000, H=40, W=48, bins=5, frac=False, pneg=False),
     dict(name="frac_pm1", seed=72, n=2500, H=37, W=45, bins=16, frac=True, pneg=True),
     dict(name="full", seed=73, n=60000, H=260, W=346, bins=5, frac=False, pneg=False),
+    # round 5: fractional coordinates and +-1 polarities at the size that matters (all eight corners non-zero)
+    dict(name="full_frac", seed=74, n=60000, H=260, W=346, bins=5, frac=True, pneg=True),
 ]
 
 
@@ -511,22 +513,35 @@ def gen_events():
     sys.modules.setdefault("matplotlib.pyplot", __import__("types").ModuleType("matplotlib.pyplot"))
     ref_rep = _load("representations")
     draw_events_accumulation_image = _load("visualize").draw_events_accumulation_image
-    out = {"meta": meta(cases=EVENT_CASES)}
+    # Round 5: ONE torch thread.  `put_(accumulate=True)` adds serially (corner major, then event order) with one thread at
+    # every size; with 8 threads it switches to unordered atomic adds from 32768 elements on, which made the 60k-event
+    # fixtures of rounds 1-4 order-dependent (they could only be compared with a tolerance).
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    out = {"meta": meta(cases=EVENT_CASES, torch_threads=1)}
     for c in EVENT_CASES:
         ev = synth_raw_events(c)
         grid = ref_rep.events_to_voxel_grid({k: v.copy() for k, v in ev.items()}, (c["bins"], c["H"], c["W"]), normalize=True)
         raw = ref_rep.events_to_voxel_grid({k: v.copy() for k, v in ev.items()}, (c["bins"], c["H"], c["W"]), normalize=False)
+        raw2 = ref_rep.events_to_voxel_grid({k: v.copy() for k, v in ev.items()}, (c["bins"], c["H"], c["W"]), normalize=False)
+        assert torch.equal(raw, raw2), "the reference is not reproducible run to run with one thread"
         img = draw_events_accumulation_image({k: v.copy() for k, v in ev.items()}, (c["W"], c["H"]))
         n = c["name"]
         if grid.numel() <= 70000:
             out[f"{n}.grid"] = grid.numpy()
             out[f"{n}.raw"] = raw.numpy()
         else:
+            # every bit of the un-normalised grid: per (bin, row) the 64-bit sum and the xor of the row's fp32 bit patterns
+            # (the whole tensor would be 1.8 MB per case); plus every 7th value of both grids for a readable comparison
+            bits = raw.numpy().view(np.uint32).reshape(c["bins"] * c["H"], c["W"])
+            out[f"{n}.raw.rowsum"] = bits.astype(np.uint64).sum(1)
+            out[f"{n}.raw.rowxor"] = np.bitwise_xor.reduce(bits, axis=1)
             out[f"{n}.grid.stride7"] = grid.reshape(-1)[::7].numpy()
             out[f"{n}.raw.stride7"] = raw.reshape(-1)[::7].numpy()
         out[f"{n}.mask"] = np.packbits(img > 0)
         out[f"{n}.mask_count"] = np.array([int((img > 0).sum())])
         print(n, float(grid.abs().sum()), int((img > 0).sum()))
+    torch.set_num_threads(threads)
     save("events.npz", **out)
 
 

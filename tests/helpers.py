@@ -301,5 +301,41 @@ def record_flips(tag, got, exp, la=None):
     return int(bad.size)
 
 
+def check_flips_with_margins(tag, got, ref, desc_rows, desc_cols, tol=2e-5, max_flips=2):
+    """`got` vs the reference's `ref` (arg-max match indices of the rows of desc_rows against desc_cols, -1 = unmatched).  The
+    reference accumulates its similarities in MKL's order, the kernels as a k-ordered fmaf chain, so an arg-max may
+    legitimately differ where the two best candidates are closer than the fp32 dot-product noise.  EVERY differing row must
+    be such a near-tie under the EXACT (float64) similarity: best minus second best of its row, or of one of the two candidate
+    columns (the mutual check), below `tol`.  Rows and margins go to the parity record; returns the number of flips."""
+    got, ref = np.asarray(got).reshape(-1), np.asarray(ref).reshape(-1)
+    assert got.shape == ref.shape, (tag, got.shape, ref.shape)
+    bad = np.nonzero(got != ref)[0]
+    rec = _FLIPS.setdefault(tag, {"compared": 0, "matched": 0, "flips": 0, "margins": []})
+    rec["compared"] += int(got.size)
+    rec["matched"] += int((ref > -1).sum())
+    rec["flips"] += int(bad.size)
+    assert bad.size <= max_flips, f"{tag}: {bad.size} match indices differ from the reference"
+    if bad.size:
+        d0, d1 = np.asarray(desc_rows, np.float64), np.asarray(desc_cols, np.float64)
+        for i in bad:
+            row = np.sort(d1 @ d0[i])[::-1]
+            gaps = [float(row[0] - row[1])] if row.size > 1 else []
+            for j in (got[i], ref[i]):
+                if j >= 0:
+                    col = np.sort(d0 @ d1[j])[::-1]
+                    if col.size > 1:
+                        gaps.append(float(col[0] - col[1]))
+            gap = min(gaps) if gaps else None
+            rec["margins"].append({"row": int(i), "got": int(got[i]), "exp": int(ref[i]), "min_gap": gap})
+            assert gap is not None and gap < tol, f"{tag}: row {i} differs from the reference ({got[i]} vs {ref[i]}) with an exact-similarity margin of {gap}"
+    return int(bad.size)
+
+
+def row_checksums(raw):
+    """per (bin, row) the 64-bit sum and the xor of the fp32 bit patterns (tests/golden/gen_golden.py::gen_events)"""
+    bits = np.ascontiguousarray(raw, np.float32).view(np.uint32).reshape(-1, raw.shape[-1])
+    return bits.astype(np.uint64).sum(1), np.bitwise_xor.reduce(bits, axis=1)
+
+
 def recorded_flips():
     return _FLIPS

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (close_and_record, Golden, la_bound, la_bound_e2e, lg_noise, load_pkg, mnn_inputs, record_flips, score_map, split,
+from helpers import (check_flips_with_margins, close_and_record, Golden, la_bound, la_bound_e2e, lg_noise, load_pkg, mnn_inputs, record_flips, score_map, split,
                      state_dict_for, sub_dict, synth, twin_inputs, twin_state_dict_for)
 
 pytestmark = pytest.mark.gpu
@@ -507,9 +507,13 @@ def test_e2e_full_size(oracle, name):
         assert np.array_equal(_np(m["matched_kpts0"][b]), mk0)
         assert np.array_equal(_np(m["matched_kpts1"][b]), mk1)
         np.testing.assert_allclose(_np(m["log_assignment"][b])[0], exp["log_assignment"], atol=1e-5, rtol=0)
-    ref0 = split(E2E[f"{name}.m.matches0"], E2E[f"{name}.m.matches0.lens"])
-    ndiff = sum(int((_np(m["matches0"][b])[0] != ref0[b]).sum()) for b in range(c["B"]))
-    assert ndiff <= 2, f"{ndiff} match indices differ from the reference"
+    # against the reference: equal, or -- per differing row -- an arg-max near-tie whose exact (float64) similarity margin is
+    # below the fp32 dot-product noise (rows and margins are recorded in the parity report)
+    for key, rows, cols in (("matches0", oef, oimf), ("matches1", oimf, oef)):
+        ref = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
+        for b in range(c["B"]):
+            check_flips_with_margins(f"e2e.{name}.{key} vs reference", _np(m[key][b])[0], ref[b], rows["sparse_descriptors"][b],
+                                     cols["sparse_descriptors"][b], tol=2e-5, max_flips=2)
 
 
 # ------------------------------------------------------------------ size-independent properties at bench size
@@ -721,11 +725,12 @@ EVENTS = Golden("events")
 def test_voxel_grid_and_events_mask(oracle):
     """Round 4: the voxel grid is DETERMINISTIC -- per voxel the contributions are added in the reference's serial order (corner
     major, then event order; representations.py:94-114), so the un-normalised grid is bit-equal to the oracle at every size, to
-    the reference's fixture wherever torch itself added serially (< 32768 events), and two runs give the same bits."""
+    the reference's fixtures at every size (round 5: generated with one torch thread, where torch adds serially; 60k events are
+    compared through per-row checksums of the bit patterns), and two runs give the same bits."""
     from importlib import import_module
     from helpers import synth_raw_events
     rep = import_module(pkg.__name__ + ".datasets.representations")
-    cases = [EVENTS.cases[n] for n in ("int_p01", "frac_pm1", "full")]
+    cases = [EVENTS.cases[n] for n in ("int_p01", "frac_pm1", "full", "full_frac")]
     for c in cases:
         ev = synth_raw_events(c)
         size = (c["bins"], c["H"], c["W"])
@@ -743,8 +748,11 @@ def test_voxel_grid_and_events_mask(oracle):
         if f"{name}.grid" in EVENTS:
             assert np.array_equal(raw, EVENTS[f"{name}.raw"]), name  # the reference's own bits
             close_and_record(f"events.{name}.grid vs reference", grid, EVENTS[f"{name}.grid"], atol=2e-5, rtol=1e-5)
-        else:  # 60k events: torch's put_(accumulate=True) adds with unordered atomics there
-            close_and_record(f"events.{name}.raw vs reference", raw.reshape(-1)[::7], EVENTS[f"{name}.raw.stride7"], atol=2e-5, rtol=1e-5)
+        else:  # 60k events: the reference's own bits too (fixture generated with one torch thread = serial adds), via row checksums
+            from helpers import row_checksums
+            assert np.array_equal(raw.reshape(-1)[::7], EVENTS[f"{name}.raw.stride7"]), name
+            rs, rx = row_checksums(raw)
+            assert np.array_equal(rs, EVENTS[f"{name}.raw.rowsum"]) and np.array_equal(rx, EVENTS[f"{name}.raw.rowxor"]), name
             close_and_record(f"events.{name}.grid vs reference", grid.reshape(-1)[::7], EVENTS[f"{name}.grid.stride7"], atol=2e-5, rtol=1e-5)
         mask = _np(rep.events_mask_batch([ev], (c["W"], c["H"])))[0, 0]
         exp = np.unpackbits(EVENTS[f"{name}.mask"])[:c["H"] * c["W"]].astype(bool).reshape(c["H"], c["W"])
