@@ -196,13 +196,16 @@ def all_rank_leg(pkg, dev, config, batch, steps, rank, world, dist=None, local=0
 def dry_run_gloo(args):
     """The N>1 control flow without kernels: same env:// rendezvous, same accumulator all-reduce,
     same barrier + max-over-ranks timing, on the gloo backend (tests/test_bench_launcher.py)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    placement = place_this_rank(rank, int(os.environ.get("LOCAL_RANK", rank)), world)  # before torch is imported
     import torch
     import torch.distributed as dist
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    finish_placement(placement, torch)
     if os.environ.get("EINX_BENCH_DRYRUN_FAIL_RANK") == str(rank):  # tests: one rank dies before the rendezvous completes
         raise SystemExit(7)
     dist.init_process_group(backend="gloo", init_method="env://")
     assert dist.get_world_size() == world, "process group does not span the launched ranks"
+    placements = gather_placements(placement, dist, world)
     pkg_shard = _import_shard_only()
     B = args.batch or WORKLOADS[args.config][1]
     lo, hi = pkg_shard.shard_range(B * world, rank, world)  # the rank's block of the global pair index space
@@ -233,22 +236,61 @@ def dry_run_gloo(args):
         if rank == 0:
             legs.append(leg_record(cfg_, b_, steps_, world, float(tmax.item()), sum(float(g[2]) for g in gathered),
                                    [float(g[2] / g[1]) for g in gathered]))
+    # teardown order, as in run_rank: rank 0's own legs (roofline, extras) run while the others wait in the final barrier;
+    # nobody destroys the process group before every rank has passed it
+    extras_done = 0.0
+    if rank == 0:
+        time.sleep(0.3)  # stands for rank 0's legs
+        extras_done = time.time()
+    dist.barrier()
+    passed = torch.tensor([time.time(), extras_done], dtype=torch.float64)
+    allp = [torch.zeros_like(passed) for _ in range(world)]
+    dist.all_gather(allp, passed)
     if rank == 0:
         print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "steps": args.steps,
                           "pairs": stats["pairs"], "keypoints0": stats["keypoints0"], "matches": stats["matches"],
                           "config": {"workload": WORKLOADS[args.config][2], "pairs_per_gpu_per_step": B, "global_batch": B * world},
                           "shard_ranges": [[int(r[0]), int(r[1])] for r in ranges], "world_env": int(os.environ["WORLD_SIZE"]),
-                          "scale_legs": legs}))
+                          "scale_legs": legs, "placement": placements,
+                          "teardown": {"rank0_legs_done": extras_done, "final_barrier_passed": [float(p[0]) for p in allp],
+                                       "order": "final barrier after rank 0's legs, then destroy_process_group on every rank"}}))
     dist.destroy_process_group()
 
 
-def _import_shard_only():
-    """shard.py without importing the package (which loads the HIP library and is GPU-only)."""
+def _import_shard_only(name="shard"):
+    """shard.py / placement.py without importing the package (which loads the HIP library and is GPU-only)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("einx_shard", os.path.join(ROOT, "ei-nexus_official_amd", "shard.py"))
+    spec = importlib.util.spec_from_file_location("einx_" + name, os.path.join(ROOT, "ei-nexus_official_amd", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def place_this_rank(rank, local, world):
+    """Multi-rank runs: pin the rank to cores of its GPU's NUMA node and size its thread pools to that share -- BEFORE torch is
+    imported and before the first GPU call (ei-nexus_official_amd/placement.py).  One-rank runs keep every core: their CPU
+    baseline legs are timed on all of them."""
+    if world <= 1 or os.environ.get("EINX_BENCH_NO_PLACEMENT") == "1":
+        return None
+    rec = _import_shard_only("placement").place_rank(local, world)
+    rec["rank"] = rank
+    return rec
+
+
+def finish_placement(placement, torch):
+    if placement is not None:
+        torch.set_num_threads(placement["threads"])
+        placement["torch_threads"] = torch.get_num_threads()
+    return placement
+
+
+def gather_placements(placement, dist, world):
+    """every rank's placement record on rank 0 (a collective: all ranks call it)"""
+    if placement is None or world <= 1:
+        return None
+    recs = [None] * world
+    dist.all_gather_object(recs, placement)
+    return sorted(recs, key=lambda r: r["rank"])
 
 
 # ------------------------------------------------------------------------------------ workload
@@ -750,11 +792,12 @@ def cpu_baseline_and_verify(wl, args, gpu_out):
 
 
 def run_rank(args):
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    placement = place_this_rank(rank, local, world)  # affinity + thread-pool sizes, before torch / the first GPU call
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
-
-    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    finish_placement(placement, torch)
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py rank {rank}: needs a HIP device -- the product path has no CPU fallback "
                          "(use --dry-run-gloo to rehearse the launcher and the collective on CPU)")
@@ -779,6 +822,7 @@ def run_rank(args):
         torch.cuda.synchronize()
         rccl = {"backend": dist.get_backend(), "world": world, "allreduce_us": round((time.perf_counter() - t0) / 20 * 1e6, 1),
                 "allreduce_payload_bytes": 64}
+    placements = gather_placements(placement, dist, world) if distributed else None
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -991,11 +1035,16 @@ def run_rank(args):
             out["extra_configs"] = extras
         if rccl is not None:
             out["rccl"] = rccl
+        if placements is not None:
+            out["placement"] = placements  # per rank: GPU, its NUMA node, the cores the rank is pinned to, thread-pool size
         if cpu_torch is not None:
             out["cpu_baseline_torch"] = cpu_torch
         print(json.dumps(out))
         sys.stdout.flush()
     if distributed:
+        # rank 0's own legs (dominant-kernel roofline, extras) ran while the other ranks were already here: nobody tears the
+        # communicator down before every rank has arrived
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

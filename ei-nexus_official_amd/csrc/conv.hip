@@ -128,14 +128,11 @@ constexpr int conv_stage_groups(int nthr, int plane_e, int ck) {
 //   * epilogue: ReLU / affine flags are hoisted into four straight-line bodies; the per-channel constants come as three
 //     ds_read_b128 per 4 rows; the 2x2 pool exchanges lanes by DPP; stores go through a descriptor re-based per output
 //     channel in the scalar ALU, pixels outside the image carry an out-of-range offset (no branches, no 64-bit multiplies).
-template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool XTRA = false>
-#ifndef EINX_CONV_WPS8
-#define EINX_CONV_WPS8 1
-#endif
-#ifndef EINX_CONV_WPS4
-#define EINX_CONV_WPS4 1
-#endif
-__global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : (WM * WN >= 8 ? EINX_CONV_WPS8 : EINX_CONV_WPS4))) void conv_block_kernel(const ConvArgs a) {  // thin first layers: registers capped so that three 8-wave workgroups share a CU
+// WPS: waves per SIMD the register allocation must allow.  6 = three 8-wave workgroups per CU (<= 80 registers): the thin first
+// layers (their load -> MFMA -> store phases only overlap across workgroups) and launches of many rounds (conv1b at B=32:
+// 15.1 rounds of 768 instead of 22.7 of 512, -2.4 %; launches of few rounds lose more to the coarser last round than they gain).
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool XTRA = false, int WPS = (CK < 8 ? 6 : 1)>
+__global__ __launch_bounds__(WM * WN * 64, WPS) void conv_block_kernel(const ConvArgs a) {
   constexpr int kMT = MT, kNT = NT;
   constexpr int NW = WM * WN;
   constexpr int TAPS = KS * KS;
@@ -166,6 +163,21 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : (WM * WN >= 8 ? EINX_CO
   float* in_tile = lds;
   float* w_tile = lds + IN_LDS;
 
+#if defined(EINX_CONV_STAGGER) && EINX_CONV_STAGGER > 0
+  // experiment (round 5): the co-resident workgroups of a CU start together, run equally long and so keep meeting at their
+  // barriers, epilogues and prologues.  Delay one of each first-generation pair once; its successors inherit the offset.
+  {
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID[3:0]: wave slot on its SIMD
+    const unsigned per = 256u * (WM * WN >= 8 ? 2u : 3u);
+#ifndef EINX_CONV_STAGGER_MODE
+#define EINX_CONV_STAGGER_MODE 0
+#endif
+    const bool late = EINX_CONV_STAGGER_MODE == 0 ? (slot & 2u) != 0 : (EINX_CONV_STAGGER_MODE == 1 ? lin >= 256u : (lin & 1u) != 0);
+    if (lin < per && late)
+      for (int i = 0; i < EINX_CONV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles = 3.4 us each
+  }
+#endif
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and provably so for the compiler (scalar registers)
   const int wm = wave / WN, wn = wave % WN;
@@ -342,10 +354,19 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : (WM * WN >= 8 ? EINX_CO
   };
   issue_loads(0);
   for (int c = 0; c < nchunks; ++c) {
+#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL)  // timing-only ablations (wrong results): bit 0 no per-chunk loads, bit 1 no barriers / commits after the first chunk, bit 2 no epilogue
+    if (!(EINX_CONV_ABL & 2) || c == 0) {
+      __syncthreads();
+      commit_loads();
+      __syncthreads();
+    }
+    if (!(EINX_CONV_ABL & 1) && c + 1 < nchunks) issue_loads(c + 1);
+#else
     __syncthreads();  // previous round's LDS reads are done
     commit_loads();
     __syncthreads();
     if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under this chunk's MFMAs
+#endif
     mfma_chunk();
     if (XTRA && xtra_wg && tid < NPIX) {  // rows of a 1x1 layer's native weight image are the input channels in order
       const float* wx = a.w + (size_t)c * W_ROWS * a.CoutPad + (a.CoutPad - kCoutTile);
@@ -442,6 +463,17 @@ __global__ __launch_bounds__(WM * WN * 64, (CK < 8 ? 6 : (WM * WN >= 8 ? EINX_CO
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
+#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL) && (EINX_CONV_ABL & 4)
+  {
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < kNT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][nt][r]));
+    return;
+  }
+#endif
   if (a.relu) {
     if (a.scale) epilogue(T_{}, T_{});
     else epilogue(T_{}, F_{});
@@ -745,16 +777,25 @@ struct TileCfg {
   int th, tw, slots;  // slots = pixel slots a workgroup launches for this tile
 };
 
-template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL>
+template <int KS, int TH, int TW, int WM, int WN, int MT, int NT, int CK, bool POOL, bool DENSE3 = false>
 void launch(const ConvArgs& a, int B, hipStream_t s) {
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), (unsigned)(a.CoutPad / kCoutTile));
+  // DENSE3: launches of at least eight rounds of three workgroups per CU take the instantiation that fits three per CU
+  const bool three = DENSE3 && (long)grid.x * grid.y >= 8L * 768;
   {
     // name of the instantiation this call launches (einx_conv_last_kernel: measurement provenance)
-    static char nm[96] = {0};
-    if (!nm[0]) snprintf(nm, sizeof nm, "conv_block_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%s>", KS, TH, TW, WM, WN, MT, NT, CK, POOL ? "true" : "false");
-    g_last_conv_kernel = nm;
+    static char nm[2][96] = {{0}, {0}};
+    char* n = nm[three ? 1 : 0];
+    if (!n[0]) snprintf(n, sizeof nm[0], "conv_block_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%s>%s", KS, TH, TW, WM, WN, MT, NT, CK, POOL ? "true" : "false", three ? " (3 per CU)" : "");
+    g_last_conv_kernel = n;
   }
   EINX_PROF(KS == 1 ? "conv_block_kernel 1x1" : (CK < 8 ? "conv_block_kernel 3x3 first layer" : "conv_block_kernel 3x3"), s);
+  if constexpr (DENSE3) {
+    if (three) {
+      hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL, false, 6>), grid, dim3(WM * WN * 64), 0, s, a);
+      return;
+    }
+  }
   hipLaunchKernelGGL((conv_block_kernel<KS, TH, TW, WM, WN, MT, NT, CK, POOL>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 
@@ -996,7 +1037,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   // 4 waves for the 1x1 heads.
   if (d->pool) {
     switch (best) {
-      case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true>(a, B, s); break;
+      case 0: launch<3, 8, 32, 2, 4, 1, 2, 8, true, true>(a, B, s); break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, true>(a, B, s); break;
       default: launch<3, 22, 8, 2, 2, 1, 3, 8, true>(a, B, s); break;
     }
@@ -1006,7 +1047,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         // thin first layers (1 / 5 input channels): stage only the channel pairs that exist
         if (d->cin <= 2) launch<3, 8, 32, 2, 4, 1, 2, 2, false>(a, B, s);
         else if (d->cin <= 6) launch<3, 8, 32, 2, 4, 1, 2, 6, false>(a, B, s);
-        else launch<3, 8, 32, 2, 4, 1, 2, 8, false>(a, B, s);
+        else launch<3, 8, 32, 2, 4, 1, 2, 8, false>(a, B, s);  // (the three-per-CU form of the un-pooled tile spills at 80 registers)
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
       case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;

@@ -10,10 +10,9 @@
 
 // Experiment switches that drop work to time what is left (WRONG results) or insert delays only exist in builds that say
 // so: -DEINX_TIMING_ONLY_BUILD, which einx_build_flags() reports and the Python package refuses to load by default.
-#if (defined(EINX_GEMM_ABL) && EINX_GEMM_ABL != 0) || (defined(EINX_UPS_EXP) && EINX_UPS_EXP != 0) || defined(EINX_CONV_ABL_NOLOADS) || \
-    (defined(EINX_CONV_STAGGER) && EINX_CONV_STAGGER != 0) || defined(VOX_EXP) || defined(EINX_CONV_ABL_NOSTORE) || defined(EINX_CONV_ABL_NOMFMA)
+#if (defined(EINX_GEMM_ABL) && EINX_GEMM_ABL != 0) || (defined(EINX_UPS_EXP) && EINX_UPS_EXP != 0) || defined(EINX_CONV_ABL) || defined(VOX_EXP)
 #ifndef EINX_TIMING_ONLY_BUILD
-#error "EINX_GEMM_ABL / EINX_UPS_EXP / EINX_CONV_ABL_NOLOADS / EINX_CONV_STAGGER / VOX_EXP are timing-only ablations: add -DEINX_TIMING_ONLY_BUILD"
+#error "EINX_GEMM_ABL / EINX_UPS_EXP / EINX_CONV_ABL / VOX_EXP are timing-only ablations: add -DEINX_TIMING_ONLY_BUILD"
 #endif
 #endif
 

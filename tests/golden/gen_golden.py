@@ -552,24 +552,49 @@ METRIC_CASES = [
     dict(name="identity", seed=81, n=300, m=280, D=64, hom=None),
     dict(name="homography", seed=82, n=400, m=350, D=256, hom=[1.02, 0.015, -3.0, -0.01, 0.98, 2.5, 1e-5, -2e-5, 1.0]),
     dict(name="nomatch", seed=83, n=50, m=60, D=32, hom=None, M=0),
+    # round 5: the conventions / edge cases of matching_metrics.py:84-156 and keypoints_metrics.py:170-290
+    dict(name="xy_rows", seed=84, n=260, m=300, D=64, hom=[0.99, 0.02, 2.0, -0.015, 1.01, -1.5, 2e-5, 1e-5, 1.0], order="xy"),  # (x, y, score) rows
+    dict(name="two_sizes", seed=85, n=320, m=240, D=128, hom=[0.9, 0.0, 4.0, 0.0, 0.9, 3.0, 0.0, 0.0, 1.0], size0=[260, 346], size1=[240, 320]),
+    dict(name="off_image", seed=86, n=300, m=300, D=64, hom=[1.0, 0.0, 150.0, 0.0, 1.0, -90.0, 0.0, 0.0, 1.0]),  # most points leave the other image
+    dict(name="all_out", seed=87, n=120, m=90, D=32, hom=[1.0, 0.0, 1000.0, 0.0, 1.0, 1000.0, 0.0, 0.0, 1.0]),   # nothing survives the visibility filter
+    dict(name="empty0", seed=88, n=0, m=80, D=32, hom=None, M=0),
+    dict(name="empty1", seed=89, n=70, m=0, D=32, hom=None, M=0),
+    dict(name="thr135", seed=90, n=400, m=380, D=256, hom=[1.01, -0.02, 1.0, 0.02, 0.99, -2.0, -1e-5, 2e-5, 1.0], thr=[1, 3, 5]),
+    dict(name="perspective", seed=91, n=350, m=350, D=64, hom=[0.95, 0.05, 6.0, -0.04, 1.05, -4.0, 3e-4, -2e-4, 1.0], thr=[1, 3, 5]),
+    dict(name="xy_two_sizes", seed=92, n=200, m=260, D=64, hom=[1.1, 0.0, -5.0, 0.0, 1.1, -4.0, 0.0, 0.0, 1.0], order="xy", size0=[180, 240], size1=[260, 346]),
 ]
 
 
 def metric_inputs(c):
     n, m, D = c["n"], c["m"], c["D"]
-    H, W = 260, 346
+    H, W = c.get("size0", [260, 346])
     k0 = np.stack([synth.uniform(c["seed"], (n,), 4, H - 4), synth.uniform(c["seed"] + 1, (n,), 4, W - 4), synth.uniform01(c["seed"] + 2, (n,))], 1)
     # image-1 keypoints: noisy copies of a share of image-0 keypoints (so neighbours within 1-3 px exist) plus random ones
     share = min(n, m) * 2 // 3
     k1 = np.stack([synth.uniform(c["seed"] + 3, (m,), 4, H - 4), synth.uniform(c["seed"] + 4, (m,), 4, W - 4), synth.uniform01(c["seed"] + 5, (m,))], 1)
     k1[:share, :2] = k0[:share, :2] + synth.uniform(c["seed"] + 6, (share, 2), -2.5, 2.5)
+    if c.get("hom") is not None and c["name"] not in ("homography",):
+        # round-5 cases: image-1 copies sit where the homography sends the image-0 keypoints (+ the same noise), so that
+        # MMA / VDD see real correspondences under a non-trivial warp; (y, x) rows -> (x, y) -> warp -> back
+        Hm = np.array(c["hom"], np.float64).reshape(3, 3)
+        xy1 = np.stack([k0[:share, 1], k0[:share, 0], np.ones(share)], 0).astype(np.float64)
+        w = Hm @ xy1
+        k1[:share, 0] = (w[1] / w[2]).astype(np.float32) + (k1[:share, 0] - k0[:share, 0])
+        k1[:share, 1] = (w[0] / w[2]).astype(np.float32) + (k1[:share, 1] - k0[:share, 1])
     d0 = synth.synth_unit_descriptors(c["seed"] + 7, n, D)
     d1 = synth.synth_unit_descriptors(c["seed"] + 8, m, D)
     d1[:share] = d0[:share] * np.float32(0.8) + d1[:share] * np.float32(0.6)
     M = c.get("M", share // 2)
     mk0 = k0[:M].copy()
     mk1 = k1[:M].copy()
-    return [a.astype(np.float32) for a in (k0, k1, d0, d1, mk0, mk1)]
+    if c.get("order", "yx") == "xy":  # rows as (x, y, score)
+        k0, k1, mk0, mk1 = [a[:, [1, 0, 2]] for a in (k0, k1, mk0, mk1)]
+    return [np.ascontiguousarray(a.astype(np.float32)) for a in (k0, k1, d0, d1, mk0, mk1)]
+
+
+def metric_names(c):
+    thr = c.get("thr", [1, 3])
+    return ["MR"] + [f"MMA@{t}" for t in thr] + [f"VDD_{p}@{t}" for t in thr for p in ("Repeatability", "ValidDistance", "Angle")]
 
 
 def gen_metrics():
@@ -579,12 +604,16 @@ def gen_metrics():
     for c in METRIC_CASES:
         k0, k1, d0, d1, mk0, mk1 = [torch.from_numpy(a) for a in metric_inputs(c)]
         Hm = torch.eye(3) if c["hom"] is None else torch.tensor(c["hom"], dtype=torch.float32).reshape(3, 3)
+        thr = c.get("thr", [1, 3])
+        xy = c.get("order", "yx") == "xy"
+        s0, s1 = tuple(c.get("size0", [260, 346])), tuple(c.get("size1", [260, 346]))
         vals = {}
         vals.update(MatchingRatio("MR").update_one(mk0, mk1, k0, k1))
-        for t in (1, 3):
-            vals.update(MeanMatchingAccuracy(f"MMA@{t}", threshold=t).update_one(mk0, mk1, Hm))
-        vals.update(ValidDescriptorsDistance("VDD", [1, 3]).update_one(k0, k1, d0, d1, (260, 346), (260, 346), Hm))
-        names = ["MR", "MMA@1", "MMA@3"] + [f"VDD_{p}@{t}" for t in (1, 3) for p in ("Repeatability", "ValidDistance", "Angle")]
+        for t in thr:
+            vals.update(MeanMatchingAccuracy(f"MMA@{t}", threshold=t, ordering="xy" if xy else "yx").update_one(mk0, mk1, Hm))
+        # ValidDescriptorsDistance's ordering names the OPPOSITE convention (keypoints_metrics.py:193-198): "xy" swaps the columns
+        vals.update(ValidDescriptorsDistance("VDD", thr, ordering="yx" if xy else "xy").update_one(k0, k1, d0, d1, s0, s1, Hm))
+        names = metric_names(c)
         out[f"{c['name']}.values"] = np.array([vals[k] for k in names], np.float64)
         print(c["name"], {k: round(vals[k], 5) for k in names})
     save("metrics.npz", **out)

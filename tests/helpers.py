@@ -196,18 +196,37 @@ def synth_raw_events(c):
 def metric_inputs(c):
     """Same recipe as tests/golden/gen_golden.py::metric_inputs."""
     n, m, D = c["n"], c["m"], c["D"]
-    H, W = 260, 346
+    H, W = c.get("size0", [260, 346])
     k0 = np.stack([synth.uniform(c["seed"], (n,), 4, H - 4), synth.uniform(c["seed"] + 1, (n,), 4, W - 4), synth.uniform01(c["seed"] + 2, (n,))], 1)
     share = min(n, m) * 2 // 3
     k1 = np.stack([synth.uniform(c["seed"] + 3, (m,), 4, H - 4), synth.uniform(c["seed"] + 4, (m,), 4, W - 4), synth.uniform01(c["seed"] + 5, (m,))], 1)
     k1[:share, :2] = k0[:share, :2] + synth.uniform(c["seed"] + 6, (share, 2), -2.5, 2.5)
+    if c.get("hom") is not None and c["name"] not in ("homography",):
+        Hm = np.array(c["hom"], np.float64).reshape(3, 3)
+        xy1 = np.stack([k0[:share, 1], k0[:share, 0], np.ones(share)], 0).astype(np.float64)
+        w = Hm @ xy1
+        k1[:share, 0] = (w[1] / w[2]).astype(np.float32) + (k1[:share, 0] - k0[:share, 0])
+        k1[:share, 1] = (w[0] / w[2]).astype(np.float32) + (k1[:share, 1] - k0[:share, 1])
     d0 = synth.synth_unit_descriptors(c["seed"] + 7, n, D)
     d1 = synth.synth_unit_descriptors(c["seed"] + 8, m, D)
     d1[:share] = d0[:share] * np.float32(0.8) + d1[:share] * np.float32(0.6)
     M = c.get("M", share // 2)
     mk0 = k0[:M].copy()
     mk1 = k1[:M].copy()
-    return [a.astype(np.float32) for a in (k0, k1, d0, d1, mk0, mk1)]
+    if c.get("order", "yx") == "xy":  # rows as (x, y, score)
+        k0, k1, mk0, mk1 = [a[:, [1, 0, 2]] for a in (k0, k1, mk0, mk1)]
+    return [np.ascontiguousarray(a.astype(np.float32)) for a in (k0, k1, d0, d1, mk0, mk1)]
+
+
+def metric_case(c):
+    """thresholds, row convention and image sizes of a metric fixture case + the layout of its value vector:
+    [MR, MMA@t ..., (Repeatability, ValidDistance, Angle)@t ...]"""
+    thr = c.get("thr", [1, 3])
+    nt = len(thr)
+    idx = {"counts": [0] + list(range(1, 1 + nt)) + [1 + nt + 3 * i for i in range(nt)],  # MR, MMA, repeatability: ratios of counts
+           "dist": [2 + nt + 3 * i for i in range(nt)], "angle": [3 + nt + 3 * i for i in range(nt)]}
+    return {"thr": thr, "xy": c.get("order", "yx") == "xy", "size0": tuple(c.get("size0", [260, 346])), "size1": tuple(c.get("size1", [260, 346])),
+            "idx": idx}
 
 
 # ---- round-2 fixture recipes (tests/golden/gen_golden.py::gen_r2) ---------------------------------

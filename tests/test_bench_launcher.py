@@ -94,6 +94,78 @@ def test_launcher_world_8_on_gloo_shards_512_pairs():
     assert leg["per_rank_pairs_per_s"]["min"] < leg["per_rank_pairs_per_s"]["max"]
 
 
+def test_world_8_placement_record_and_teardown_order():
+    """Round 5: every rank is pinned before its first GPU call (cores of its GPU's NUMA node, or an even split of the allowed
+    CPUs where the topology is not readable, as in this container), sizes its thread pools to that share, and the record is
+    in rank 0's line; no rank destroys the process group before rank 0's own legs are done (final barrier)."""
+    r = _run("--gpus", "8", "--dry-run-gloo", "--steps", "1")
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    pl = d["placement"]
+    assert [p["rank"] for p in pl] == list(range(8)) and [p["gpu"] for p in pl] == list(range(8))
+    sys.path.insert(0, os.path.join(ROOT, "ei-nexus_official_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("einx_placement", os.path.join(ROOT, "ei-nexus_official_amd", "placement.py"))
+    plc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(plc)
+    allowed = sorted(os.sched_getaffinity(0))
+    sets = [set(plc.parse_cpulist(p["cpus"])) for p in pl]
+    for p, cs in zip(pl, sets):
+        assert cs and cs <= set(allowed) and p["pinned"] is True
+        assert p["n_cpus"] == len(cs) and 1 <= p["threads"] <= len(cs) and p["torch_threads"] == p["threads"]
+    if len(allowed) >= 8:
+        assert all(not (a & b) for i, a in enumerate(sets) for b in sets[i + 1:]), "ranks share cores"
+    td = d["teardown"]
+    assert len(td["final_barrier_passed"]) == 8
+    assert min(td["final_barrier_passed"]) >= td["rank0_legs_done"] > 0  # everyone left the barrier after rank 0's legs
+    # one rank: no pinning (its CPU baseline legs use every core)
+    r = _run("--gpus", "1", "--dry-run-gloo", "--steps", "1")
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["placement"] is None
+
+
+def test_placement_plan_follows_the_gpu_numa_nodes(tmp_path):
+    """placement.plan on a fake sysfs: 4 GPUs on 2 NUMA nodes x 8 cores x 2 threads -> each rank gets half of its GPU's node,
+    whole cores (SMT siblings together), disjoint from its neighbour's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("einx_placement", os.path.join(ROOT, "ei-nexus_official_amd", "placement.py"))
+    plc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(plc)
+    root = tmp_path
+    ncpu = 32  # cpu c and c + 16 are SMT siblings; node 0: cores 0-7, node 1: cores 8-15
+    for c in range(ncpu):
+        d = root / f"devices/system/cpu/cpu{c}/topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(f"{c % 16},{c % 16 + 16}\n")
+    nodes = {0: "0-7,16-23", 1: "8-15,24-31"}
+    for n, lst in nodes.items():
+        d = root / f"devices/system/node/node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(lst + "\n")
+    (root / "class/kfd/kfd/topology/nodes/0").mkdir(parents=True)
+    (root / "class/kfd/kfd/topology/nodes/0/properties").write_text("cpu_cores_count 16\nsimd_count 0\n")
+    for g in range(4):
+        d = root / f"class/kfd/kfd/topology/nodes/{g + 1}"
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+        dev = root / f"class/drm/renderD{128 + g}/device"
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{g // 2}\n")
+        (dev / "local_cpulist").write_text(nodes[g // 2] + "\n")
+    env = {k: os.environ.pop(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if k in os.environ}
+    try:
+        plans = [plc.plan(g, 4, allowed=list(range(ncpu)), sys_root=str(root)) for g in range(4)]
+    finally:
+        os.environ.update(env)
+    assert [p["numa_node"] for p in plans] == [0, 0, 1, 1]
+    assert [p["cpus"] for p in plans] == ["0-3,16-19", "4-7,20-23", "8-11,24-27", "12-15,28-31"]
+    assert all(p["physical_cores"] == 4 and p["threads"] == 4 for p in plans)
+    # a restricted affinity mask is respected; no topology -> even split
+    p = plc.plan(1, 4, allowed=[0, 1, 2, 3, 4, 5, 16, 17], sys_root=str(root))
+    assert set(plc.parse_cpulist(p["cpus"])) <= {0, 1, 2, 3, 4, 5, 16, 17}
+    q = [plc.plan(g, 4, allowed=list(range(8)), sys_root=str(tmp_path / "nothing")) for g in range(4)]
+    assert [x["cpus"] for x in q] == ["0-1", "2-3", "4-5", "6-7"] and all(x["numa_node"] == -1 for x in q)
+
+
 def test_dead_rank_at_world_8_stops_the_others_quickly():
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}

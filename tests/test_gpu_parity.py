@@ -801,26 +801,32 @@ METRICS = Golden("metrics")
 
 @pytest.mark.parametrize("name", list(METRICS.cases))
 def test_metric_classes_vs_reference(oracle, name):
-    """reference-named metric classes (update_one) -> metrics.hip -> the reference's own numbers."""
+    """reference-named metric classes (update_one) -> metrics.hip -> the reference's own numbers: (y, x) and (x, y) rows, two
+    image sizes, warps that push points off the image / leave nothing visible, an empty side, thresholds 1 / 3 / 5."""
     from importlib import import_module
-    from helpers import metric_inputs
+    from helpers import metric_case, metric_inputs
     mm = import_module(pkg.__name__ + ".core.metrics.matching_metrics")
     km = import_module(pkg.__name__ + ".core.metrics.keypoints_metrics")
     c = METRICS.cases[name]
+    mc = metric_case(c)
     k0, k1, d0, d1, mk0, mk1 = [_t(a) for a in metric_inputs(c)]
     Hm = torch.eye(3) if c["hom"] is None else torch.tensor(c["hom"], dtype=torch.float32).reshape(3, 3)
     vals = {}
     vals.update(mm.MatchingRatio("MR").update_one(mk0, mk1, k0, k1))
-    for t in (1, 3):
-        vals.update(mm.MeanMatchingAccuracy(f"MMA@{t}", threshold=t).update_one(mk0, mk1, Hm.to(DEV)))
-    vals.update(km.ValidDescriptorsDistance("VDD", [1, 3]).update_one(k0, k1, d0, d1, (260, 346), (260, 346), Hm.to(DEV)))
-    names = ["MR", "MMA@1", "MMA@3"] + [f"VDD_{p}@{t}" for t in (1, 3) for p in ("Repeatability", "ValidDistance", "Angle")]
+    for t in mc["thr"]:
+        vals.update(mm.MeanMatchingAccuracy(f"MMA@{t}", threshold=t, ordering="xy" if mc["xy"] else "yx").update_one(mk0, mk1, Hm.to(DEV)))
+    # ValidDescriptorsDistance's `ordering` names the opposite convention (keypoints_metrics.py:193-198), as in the generator
+    vals.update(km.ValidDescriptorsDistance("VDD", mc["thr"], ordering="yx" if mc["xy"] else "xy").update_one(k0, k1, d0, d1, mc["size0"], mc["size1"],
+                                                                                                       Hm.to(DEV)))
+    names = ["MR"] + [f"MMA@{t}" for t in mc["thr"]] + [f"VDD_{p}@{t}" for t in mc["thr"] for p in ("Repeatability", "ValidDistance", "Angle")]
     got = np.array([vals[k] for k in names])
     exp = METRICS[f"{name}.values"]
-    np.testing.assert_allclose(got[[0, 1, 2, 3, 6]], exp[[0, 1, 2, 3, 6]], atol=1e-7, rtol=1e-6)
-    np.testing.assert_allclose(got[[4, 7]], exp[[4, 7]], atol=1e-5, rtol=1e-5)
-    np.testing.assert_allclose(got[[5, 8]], exp[[5, 8]], atol=2e-3, rtol=1e-5)
-    orc = oracle.pair_metrics(*metric_inputs(c), (260, 346), (260, 346), c["hom"])
+    assert got.shape == exp.shape
+    i = mc["idx"]
+    np.testing.assert_allclose(got[i["counts"]], exp[i["counts"]], atol=1e-7, rtol=1e-6)
+    np.testing.assert_allclose(got[i["dist"]], exp[i["dist"]], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(got[i["angle"]], exp[i["angle"]], atol=2e-3, rtol=1e-5)
+    orc = oracle.pair_metrics(*metric_inputs(c), mc["size0"], mc["size1"], c["hom"], mma_thr=mc["thr"], vdd_thr=mc["thr"], kp_yx=not mc["xy"])
     np.testing.assert_allclose(got, orc, atol=1e-6, rtol=1e-6)
 
 

@@ -422,15 +422,18 @@ METRICS = Golden("metrics")
 
 @pytest.mark.parametrize("name", list(METRICS.cases))
 def test_pair_metrics(oracle, name):
-    from helpers import metric_inputs
+    from helpers import metric_case, metric_inputs
     c = METRICS.cases[name]
+    mc = metric_case(c)
     k0, k1, d0, d1, mk0, mk1 = metric_inputs(c)
-    got = oracle.pair_metrics(k0, k1, d0, d1, mk0, mk1, (260, 346), (260, 346), c["hom"])
+    got = oracle.pair_metrics(k0, k1, d0, d1, mk0, mk1, mc["size0"], mc["size1"], c["hom"], mma_thr=mc["thr"], vdd_thr=mc["thr"], kp_yx=not mc["xy"])
     exp = METRICS[f"{name}.values"]
+    assert got.shape == exp.shape
     # MR, MMA, repeatability: counts -> exact up to fp32 division; distances 1e-5; angles 2e-3 deg
-    np.testing.assert_allclose(got[[0, 1, 2, 3, 6]], exp[[0, 1, 2, 3, 6]], atol=1e-7, rtol=1e-6)
-    np.testing.assert_allclose(got[[4, 7]], exp[[4, 7]], atol=1e-5, rtol=1e-5)
-    np.testing.assert_allclose(got[[5, 8]], exp[[5, 8]], atol=2e-3, rtol=1e-5)
+    i = mc["idx"]
+    np.testing.assert_allclose(got[i["counts"]], exp[i["counts"]], atol=1e-7, rtol=1e-6)
+    np.testing.assert_allclose(got[i["dist"]], exp[i["dist"]], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(got[i["angle"]], exp[i["angle"]], atol=2e-3, rtol=1e-5)
 
 
 # ------------------------------------------------------------------ plain-PyTorch CPU expression (second CPU baseline)
