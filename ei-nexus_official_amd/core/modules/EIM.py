@@ -148,7 +148,7 @@ class EIM(nn.Module):
         return p
 
     @on_input_device
-    def _finish(self, p):
+    def _finish(self, p, _rerun=False):
         """Host side of one forward: wait for the two read-backs, cut the per-pair lists."""
         ev, im, mr, pre = p["ev"], p["im"], p["mr"], p["pre"]
         if p["det_event"] is not None:  # None: graph mode, the stream has been synchronised
@@ -165,11 +165,14 @@ class EIM(nn.Module):
             # a weight was edited through `.data` after the native images were built (the reference's modules would simply use
             # the new values): rebuild the images of all three modules and run this forward again.  SuperPointv1's in-place
             # `image /= 255` has already happened and is not repeated.
+            if _rerun:  # the images were rebuilt from the current weights a moment ago: a second alarm is not an edit
+                raise RuntimeError("einx: the weight watch still reports stale native weight images after they were rebuilt "
+                                   "(weights modified concurrently with the forward?)")
             for mod in (self.event_extractor.extractor, self.image_extractor.extractor, self.matcher.matcher):
                 if hasattr(mod, "refresh"):
                     mod.refresh()
             self.reset_graphs()
-            return self._finish(self._enqueue(*p["args"], slot=p["slot"], prepared=True))
+            return self._finish(self._enqueue(*p["args"], slot=p["slot"], prepared=True), _rerun=True)
         if mr is not None and getattr(mr, "stale", None) is not None and nm_host is not None:
             nm_host = nm_host[:host.shape[1]]
         retries = 0
@@ -232,10 +235,20 @@ class EIM(nn.Module):
             same geometry overwrites them (clone what must survive);
           * inputs are copied into the graph's input buffers, so SuperPoint's in-place `image /= 255` (reference quirk)
             happens on that copy, not on the caller's tensor;
-          * a forward whose NMS fix-point needs more passes than the captured budget falls back to the eager `forward`;
-          * weights are read at replay time (edits through load_state_dict need a new capture: call `reset_graphs()`)."""
+          * a forward whose NMS fix-point needs more passes than the captured budget finishes eagerly ON THE GRAPH'S OWN
+            BUFFERS (the detection tail and the matcher are redone with a larger budget, as in `forward`; the caller's tensors
+            are not touched, so the `/= 255` is never applied to them) and the graph is dropped: the next call captures a new
+            one with the grown budget;
+          * weights are read at replay time (edits through load_state_dict need a new capture: call `reset_graphs()`);
+          * one graph per input geometry, dtype AND configuration: the key holds every attribute that changes what is enqueued
+            (`dense_outputs`, `want_log_assignment`, the detector settings, the matcher thresholds), so changing one of them
+            captures a new graph instead of replaying the old configuration;
+          * dicts returned by EARLIER calls alias the buffers the next replay overwrites -- their tensors, and their unresolved
+            lazy entries (`normalized_descriptors`, `dense_*`), which would then be computed from the newer data: read or clone
+            what must survive before the next call."""
         key = (tuple(events.shape), tuple(image.shape), None if events_mask is None else tuple(events_mask.shape),
-               None if image_mask is None else tuple(image_mask.shape), str(events.device))
+               None if image_mask is None else tuple(image_mask.shape), str(events.device),
+               tuple(None if t is None else str(t.dtype) for t in (events, image, events_mask, image_mask)), self._graph_config())
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
         if g is None:
@@ -248,14 +261,26 @@ class EIM(nn.Module):
         cur.synchronize()
         p = g["p"]
         host = p["det_host"]
-        if bool(((host[2] | host[3]) & 1).any()):  # rare: pass budget exceeded -> the eager path with its retry
-            return self.forward(events, image, events_mask, image_mask)
+        if bool(((host[2] | host[3]) & 1).any()):
+            # rare: the captured NMS pass budget was exceeded.  `_finish` redoes the detection tail and the matcher eagerly with
+            # a larger, remembered budget on the graph's buffers (the replay has already scaled its own copy of the image);
+            # this graph keeps the old budget, so it is dropped and the next call captures afresh
+            graphs.pop(key, None)
         for bf, tmpl in ((p["ev"], g["prep_ev"]), (p["im"], g["prep_im"])):
             bf.reuse_prepared(tmpl)
         return self._finish(dict(p, det_event=None, nm_event=None))
 
     def reset_graphs(self):
         self.__dict__.pop("_graphs", None)
+
+    def _graph_config(self):
+        """every attribute that changes what `_enqueue` puts on the stream (part of the graph cache key)"""
+        def ext(e):
+            return tuple(getattr(e, k, None) for k in ("dense_outputs", "detection_top_k", "detection_threshold", "nms_radius", "remove_borders",
+                                                       "ordering", "dilate_mask"))
+        m = self.matcher.matcher
+        mk = None if m is None else (type(m).__name__,) + tuple(repr(getattr(m, k, None)) for k in ("want_log_assignment", "ratio_thresh", "distance_thresh"))
+        return (ext(self.event_extractor.extractor), ext(self.image_extractor.extractor), mk, bool(getattr(self, "overlap_extractors", True)))
 
     @on_input_device
     def _capture(self, events, image, events_mask, image_mask):

@@ -54,9 +54,12 @@ class NativeExtractor(nn.Module):
     def _signature(self):
         """(storage, version) of every parameter and buffer: in-place edits made THROUGH the parameter (`with no_grad():
         p.add_(..)` / `p.copy_(..)`, optimiser steps, `load_state_dict`) bump `p._version`, `.to()` changes the storage.
-        NOT detected: edits through `p.data` (`p.data.copy_(w)`, `p.data.mul_(..)`): `.data` is an alias with its OWN version
-        counter, so `p._version` stays put -- call `refresh()` after those, and after REPLACING a Parameter object
-        (tests/test_host_cpu.py::test_data_alias_edits_need_refresh).  The flat tensor list is cached (walking the module
+        NOT detected HERE: edits through `p.data` (`p.data.copy_(w)`, `p.data.mul_(..)`): `.data` is an alias with its OWN
+        version counter, so `p._version` stays put.  Those are caught by the device-side content watch instead (round 4:
+        65 sampled words per tensor, checked by every forward, which then rebuilds the images and runs again) -- as long as
+        the edit touches a sampled word: dense edits always do, a single-element patch may not, and REPLACING a Parameter
+        object is invisible to both; `refresh()` covers those (tests/test_host_cpu.py::test_data_alias_edits_need_refresh,
+        tests/test_r4_gpu.py::test_data_edits_of_weights_take_effect_at_the_next_forward).  The flat tensor list is cached (walking the module
         tree costs 50-450 us per call); `_apply`, `load_state_dict` and `refresh()` drop it."""
         ts = self._sig_tensors
         if ts is None:

@@ -129,6 +129,55 @@ def test_forward_graph_equals_forward(cfg_name, B):
     assert len(model._graphs) == 1
 
 
+def test_forward_graph_budget_fallback_stays_on_the_graphs_buffers():
+    """when a replay exceeds the captured NMS pass budget the forward is finished eagerly on the graph's OWN buffers
+    (the caller's image is never scaled in place), equals the eager forward, and the graph is dropped so that the next call
+    captures one with the grown budget.  nms_radius 3: the generic pass kernel (radius 4 finishes on the device); the budget
+    is lowered to ONE pass and the graph captured on fully masked inputs (empty score maps converge at once), so an ordinary
+    pair (3 passes) exceeds it."""
+    from helpers import synth
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    cfg.event_extractor.vgg.nms_radius = 3
+    cfg.image_extractor.superpointv1.nms_radius = 3
+
+    def build():
+        m = pkg.EIM(cfg, device=DEV).eval()
+        sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=29)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        for w in (m.event_extractor, m.image_extractor):
+            eng = w.extractor.engine()
+            eng.nms_base = eng.nms_iters = 1
+        return m
+
+    model = build()
+    ev, mask = synth.synth_events(70, 1, 5)
+    img = synth.synth_image(70, 1)
+    none = np.zeros_like(mask)
+    allm = np.ones_like(mask)
+    model.forward_graph(_t(ev), _t(img), _t(none), _t(none))  # capture: nothing to suppress, one pass is enough
+    assert len(model._graphs) == 1
+    assert model.image_extractor.extractor.engine().nms_iters == 1
+    exp = build()(_t(ev), _t(img.copy()), _t(mask), _t(allm))
+    img_t = _t(img)
+    got = model.forward_graph(_t(ev), img_t, _t(mask), _t(allm))  # an ordinary pair: more than one pass
+    assert model.image_extractor.extractor.engine().nms_iters > 1, "the pair did not exceed the captured budget"
+    assert np.array_equal(_np(img_t), img)  # the caller's tensor is untouched (round 4 divided it by 255 on this path)
+    assert len(model._graphs) == 0  # dropped: it holds the old budget
+    for side in (0, 1):
+        assert got[side]["sparse_positions"][0].shape[0] > 100
+        assert torch.equal(got[side]["sparse_positions"][0], exp[side]["sparse_positions"][0])
+        assert torch.equal(got[side]["sparse_descriptors"][0], exp[side]["sparse_descriptors"][0])
+        assert torch.equal(got[side]["nms"], exp[side]["nms"])
+    assert torch.equal(got[2]["matches0"][0], exp[2]["matches0"][0])
+    again = model.forward_graph(_t(ev), _t(img), _t(mask), _t(allm))  # new capture with the grown budget: no fallback now
+    assert len(model._graphs) == 1
+    assert torch.equal(again[1]["sparse_positions"][0], exp[1]["sparse_positions"][0])
+    # a configuration change is part of the cache key: no stale replay
+    model.matcher.matcher.want_log_assignment = False
+    model.forward_graph(_t(ev), _t(img), _t(mask), _t(allm))
+    assert len(model._graphs) == 2
+
+
 @pytest.mark.parametrize("cfg_name", ["SP_MNN", "SP_LG"])
 def test_data_edits_of_weights_take_effect_at_the_next_forward(cfg_name):
     """The reference's modules are plain nn.Modules: `p.data.mul_(..)` / `p.data.copy_(..)` change the next forward.  Here weights
