@@ -658,7 +658,9 @@ def host_info():
     except OSError:
         pass
     physical = len(cores) if cores and (None, None) not in cores else None
-    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": physical}
+    plc = _import_shard_only("placement")
+    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": physical, "cgroup_cpu_quota": plc.cgroup_cpu_quota(),
+            "effective_cpus": plc.effective_cpus()}
 
 
 def cpu_torch_protocol(wl, torch):
@@ -669,9 +671,24 @@ def cpu_torch_protocol(wl, torch):
     from oracle import torch_cpu
     hi = host_info()
     keep = torch.get_num_threads()
-    nthreads = hi["physical_cores"] or keep
-    torch.set_num_threads(nthreads)
     a_ = (wl.sub("event_extractor.extractor."), wl.sub("image_extractor.extractor."))
+    # thread count: the best of a short sweep around the CPUs this process can keep busy (more threads than the cgroup's quota
+    # get the whole process throttled; fewer leave cores idle) -- one pair, 1 warm-up + 3 repeats per candidate
+    eff = hi["effective_cpus"]
+    cands = sorted({max(1, eff // 2), eff, min(max(hi["physical_cores"] or eff, eff), 2 * eff)})
+    sweep = []
+    for nt in cands:
+        torch.set_num_threads(nt)
+        run1 = lambda: torch_cpu.sp_mnn_pairs(*a_, wl.ev_np[:1], wl.mask_np[:1], wl.img_np[:1].copy(), dense=False)  # noqa: E731
+        run1()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run1()
+            ts.append(time.perf_counter() - t0)
+        sweep.append({"threads": nt, "median_s_per_pair": round(statistics.median(ts), 3)})
+    nthreads = min(sweep, key=lambda e: e["median_s_per_pair"])["threads"]
+    torch.set_num_threads(nthreads)
     legs = []
     try:
         for nb, dense, reps in ((1, False, 5), (8, False, 5), (1, True, 5)):
@@ -691,7 +708,8 @@ def cpu_torch_protocol(wl, torch):
         torch.set_num_threads(keep)
     b8 = [l_ for l_ in legs if l_["batch"] == min(8, wl.B) and not l_["dense_outputs"]][0]
     return {"value": b8["median_pairs_per_s"], "unit": "pairs/s", "threads": nthreads, "kind": "plain PyTorch CPU expression (oracle/torch_cpu.py)",
-            "sample": f"B={b8['batch']} sparse outputs, median of {b8['repeats']} after 2 warm-ups (BASELINE.md section 4)", "legs": legs, **hi}
+            "sample": f"B={b8['batch']} sparse outputs, median of {b8['repeats']} after 2 warm-ups (BASELINE.md section 4)", "legs": legs,
+            "thread_sweep": sweep, "thread_choice": "fastest of the sweep (candidates: half / all / twice the CPUs the cgroup's quota and the affinity mask allow)", **hi}
 
 
 def harness_leg(pkg, wl, torch, steps=10, events_per_sample=60000):
@@ -767,7 +785,8 @@ def cpu_baseline_and_verify(wl, args, gpu_out):
             res.append(r)
     cpu_s = time.perf_counter() - tc
     hi = host_info()
-    cores = hi["logical_cpus"]
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    cores = int(omp) if omp.isdigit() else hi["logical_cpus"]  # main() sizes the OpenMP pool to the CPUs the process can keep busy
     # ---- verification of the GPU outputs against the checker (outside every timed region)
     ef, imf, m = gpu_out
     verified, first_bad = 0, None
@@ -782,9 +801,10 @@ def cpu_baseline_and_verify(wl, args, gpu_out):
         if not ok and first_bad is None:
             first_bad = b
     base = {"value": round(nb * passes / cpu_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{nb * passes} pairs of the same workload through oracle/ (C, OpenMP on all host cores), {cpu_s:.1f} s",
-            "cores_are": "logical CPUs available to the process (OpenMP threads used)", "physical_cores": hi["physical_cores"],
-            "cpu_model": hi["cpu_model"], "verified_pairs": verified, "verified_of": nb,
+            "sample": f"{nb * passes} pairs of the same workload through oracle/ (C, OpenMP, {cores} threads), {cpu_s:.1f} s",
+            "cores_are": "OpenMP threads used = CPUs the process can keep busy (affinity mask capped by the cgroup's CPU quota: more threads "
+                         "than that get the whole process throttled)", "logical_cpus": hi["logical_cpus"], "physical_cores": hi["physical_cores"],
+            "cgroup_cpu_quota": hi["cgroup_cpu_quota"], "cpu_model": hi["cpu_model"], "verified_pairs": verified, "verified_of": nb,
             "verified_what": "keypoint positions+scores and descriptors bit-equal, match indices equal, GPU vs oracle on the same pairs"}
     if first_bad is not None:
         base["first_mismatch_pair"] = first_bad
@@ -972,12 +992,12 @@ def run_rank(args):
             del w
             torch.cuda.empty_cache()
             extras.append(harness_leg(pkg, wl, torch))
-            # single pairs: the first ~15 forwards after a weight (re)load can contain one-off host stalls of 30-80 ms (measured:
-            # profiles/r04_notes.md; none in the 285 forwards that follow), so these legs start after 15 un-timed forwards
-            w = leg("sp_mnn", 1, steps=50, init=15, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
+            # single pairs (round 4 started these legs after 15 un-timed forwards because of one-off 30-80 ms host stalls; round 5
+            # found the cause -- CFS throttling of the container by over-sized CPU thread pools, fixed in main() -- and removed that)
+            w = leg("sp_mnn", 1, steps=50, init=2, note="single-pair latency (the reference's own call pattern, test_events-image_same-time.py:130-194): ms_per_step is ms per pair")
             # the same single pair through EIM.forward_graph: the device side of the forward captured once into a hipGraph
             w.model.forward_graph(w.ev, w.img_src, w.mask)
-            for _ in range(15):
+            for _ in range(3):
                 w.model.forward_graph(w.ev, w.img_src, w.mask)
             torch.cuda.synchronize()
             tg = time.perf_counter()
@@ -991,7 +1011,7 @@ def run_rank(args):
                            "note": "single-pair latency through EIM.forward_graph (opt-in latency mode: the ~60 launches of a forward replayed as ONE "
                                    "hipGraph launch, outputs live in graph-owned buffers until the next call; same kernels and outputs as forward)"})
             del w
-            w = leg("sp_lg", 1, steps=30, init=15, note="single-pair latency with the LightGlue matcher (configs/model/test/EI_SP_LG.yaml evaluated pair by pair): ms_per_step is ms per pair")
+            w = leg("sp_lg", 1, steps=30, init=2, note="single-pair latency with the LightGlue matcher (configs/model/test/EI_SP_LG.yaml evaluated pair by pair): ms_per_step is ms per pair")
             del w
             sec, mm = timed_stream(wl, 20)
             extras.append({"config": "sp_mnn", "workload": f"B{B} " + WORKLOADS["sp_mnn"][2], "pairs_per_step": B,
@@ -1051,6 +1071,10 @@ def run_rank(args):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    # before numpy / torch are imported: size the CPU math libraries' thread pools to the CPUs this process can really use
+    # (affinity mask capped by the cgroup's CPU quota).  Pools sized from the visible CPUs froze the whole container for
+    # 30-80 ms at a time on the GPU boxes (CFS throttling; profiles/r05_notes.md), wherever the main thread happened to be.
+    _import_shard_only("placement").cap_thread_pools()
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not under_launcher and (args.gpus > 1 or args.spawn):
         sys.exit(launch_ranks(args, argv))

@@ -48,6 +48,48 @@ def format_cpulist(cpus):
     return ",".join(runs)
 
 
+def cgroup_cpu_quota(sys_root="/sys"):
+    """CPUs' worth of CFS bandwidth this process's cgroup may use per period (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`), or
+    None when unlimited / unreadable.  Round 5: the GPU boxes hand out 16 CPUs of quota while 256 logical CPUs are visible;
+    thread pools sized from the visible CPUs (OpenMP 128, OpenBLAS 64) spin-wait after every parallel region, burn the quota
+    within milliseconds and the kernel then FREEZES EVERY THREAD of the cgroup until the next 100 ms period -- the 30-80 ms
+    "host stalls inside hipLaunchKernel" of round 4 (profiles/r05_notes.md)."""
+    txt = _read(os.path.join(sys_root, "fs/cgroup/cpu.max"))
+    if txt:
+        parts = txt.split()
+        if len(parts) == 2 and parts[0] != "max" and float(parts[1]) > 0:
+            return float(parts[0]) / float(parts[1])
+        return None
+    q, per = _read(os.path.join(sys_root, "fs/cgroup/cpu/cpu.cfs_quota_us")), _read(os.path.join(sys_root, "fs/cgroup/cpu/cpu.cfs_period_us"))
+    if q and per and float(q) > 0 and float(per) > 0:
+        return float(q) / float(per)
+    return None
+
+
+def effective_cpus(sys_root="/sys"):
+    """CPUs this process can actually keep busy: its affinity mask capped by the cgroup's CPU bandwidth quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    q = cgroup_cpu_quota(sys_root)
+    if q is not None:
+        n = min(n, max(1, int(q)))
+    return max(1, n)
+
+
+def cap_thread_pools(n=None):
+    """Size the CPU math libraries' pools (OpenMP / MKL / OpenBLAS: torch's CPU operators, numpy) to `n` threads (default:
+    effective_cpus()) through their environment variables -- call before they are imported.  Existing settings are kept when
+    they are not larger."""
+    n = effective_cpus() if n is None else max(1, int(n))
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        cur = os.environ.get(var)
+        if not (cur and cur.isdigit() and 0 < int(cur) <= n):
+            os.environ[var] = str(n)
+    return n
+
+
 def gpu_topology(sys_root="/sys"):
     """[(numa_node, [cpus of that node])] for every GPU in KFD topology order (the order HIP enumerates devices in);
     [] when the topology is not readable."""
@@ -124,8 +166,12 @@ def plan(local_rank, world, allowed=None, sys_root="/sys"):
         lo, hi = local_rank * len(allowed) // world, (local_rank + 1) * len(allowed) // world
         cpus = allowed[lo:hi] if hi > lo else [allowed[local_rank % len(allowed)]]
     phys = len({_core_of(c, sys_root) for c in cpus})
+    threads = max(1, phys)
+    quota = cgroup_cpu_quota(sys_root)
+    if quota is not None:  # the ranks of this host share the cgroup's CPU bandwidth
+        threads = max(1, min(threads, int(quota) // world))
     return {"gpu": int(local_rank), "numa_node": int(my_node), "cpus": format_cpulist(cpus), "n_cpus": len(cpus), "physical_cores": phys,
-            "threads": max(1, phys), "source": source}
+            "threads": threads, "cgroup_cpu_quota": quota, "source": source}
 
 
 def apply(p):

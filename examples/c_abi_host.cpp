@@ -4,10 +4,14 @@
 // check that no torch type or allocator is needed below the boundary.
 //
 //   hipcc -O2 --offload-arch=gfx950 examples/c_abi_host.cpp -Iinclude -Lei-nexus_official_amd -leinx_hip \
-//         -Wl,-rpath,$PWD/ei-nexus_official_amd -o examples/c_abi_host && examples/c_abi_host [B]
+//         -Wl,-rpath,$PWD/ei-nexus_official_amd -o examples/c_abi_host && examples/c_abi_host [B [IN.bin OUT.bin]]
 //
 // Weights are seeded pseudo-random (the network shape is SuperPointv1's / VGGExtractor's: superpoint_extractor.py:299-314,
 // net/backbone.py:37-103); the program prints keypoint / match counts and a checksum and exits non-zero on any ABI error.
+// With IN.bin / OUT.bin every weight tensor and input is read from IN.bin instead (raw little-endian fp32 / uint8 arrays in
+// exactly the order this program would otherwise draw them: per network, per layer w, b, [gamma, beta, mean, var]; then events,
+// mask, image) and the results are written to OUT.bin (per side counts, positions, sparse descriptors; then matches0 and the
+// match counts): tests/test_r5_gpu.py writes IN.bin from a seeded state dict and compares OUT.bin bit for bit with the oracle.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -35,6 +39,7 @@
     }                                                                               \
   } while (0)
 
+static FILE* g_in = nullptr;  // IN.bin, when given
 static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
 static float urand() {  // splitmix64 -> [0,1)
   uint64_t z = (g_rng += 0x9E3779B97F4A7C15ull);
@@ -42,6 +47,17 @@ static float urand() {  // splitmix64 -> [0,1)
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;
   return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// the next array of the program's fixed drawing order: from IN.bin when given (returns true), else left to the caller's generator
+template <typename T>
+static bool from_file(std::vector<T>& v) {
+  if (!g_in) return false;
+  if (fread(v.data(), sizeof(T), v.size(), g_in) != v.size()) {
+    fprintf(stderr, "IN.bin ends early (array of %zu elements)\n", v.size());
+    exit(2);
+  }
+  return true;
 }
 
 template <typename T>
@@ -65,8 +81,10 @@ struct Layer {
 static Layer make_layer(int cin, int cout, int ks, bool relu, bool bn, bool pool, hipStream_t st) {
   std::vector<float> w((size_t)cout * cin * ks * ks), b(cout);
   const float a = sqrtf(6.0f / (float)(cin * ks * ks));
-  for (auto& v : w) v = (2.0f * urand() - 1.0f) * a;
-  for (auto& v : b) v = (2.0f * urand() - 1.0f) * 0.1f;
+  if (!from_file(w))
+    for (auto& v : w) v = (2.0f * urand() - 1.0f) * a;
+  if (!from_file(b))
+    for (auto& v : b) v = (2.0f * urand() - 1.0f) * 0.1f;
   float* w_oihw = upload(w);
   float* w_native = dalloc<float>(einx_conv_weight_elems(cin, cout, ks));
   EINXCHK(einx_conv_repack(w_oihw, cin, cout, ks, w_native, st));
@@ -80,11 +98,15 @@ static Layer make_layer(int cin, int cout, int ks, bool relu, bool bn, bool pool
   L.d.pool = pool;
   if (bn) {
     std::vector<float> g(cout), be(cout), mu(cout), var(cout);
-    for (int i = 0; i < cout; ++i) {
-      g[i] = 0.5f + urand();
-      be[i] = (2.0f * urand() - 1.0f) * 0.1f;
-      mu[i] = (2.0f * urand() - 1.0f) * 0.3f;
-      var[i] = 0.5f + urand();
+    if (g_in) {
+      from_file(g), from_file(be), from_file(mu), from_file(var);
+    } else {
+      for (int i = 0; i < cout; ++i) {
+        g[i] = 0.5f + urand();
+        be[i] = (2.0f * urand() - 1.0f) * 0.1f;
+        mu[i] = (2.0f * urand() - 1.0f) * 0.3f;
+        var[i] = 0.5f + urand();
+      }
     }
     float* sc = dalloc<float>(cout);
     float* sh = dalloc<float>(cout);
@@ -170,6 +192,11 @@ static Outs make_outs(const Net& n, int B, int H, int W) {
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 2;
   const int H = 260, W = 346, CE = 5;
+  const char* out_path = argc > 3 ? argv[3] : nullptr;
+  if (argc > 3 && !(g_in = fopen(argv[2], "rb"))) {
+    fprintf(stderr, "cannot open %s\n", argv[2]);
+    return 2;
+  }
   printf("%s, %d HIP device(s)\n", einx_version(), einx_device_count());
   if (einx_device_count() < 1) {
     fprintf(stderr, "no HIP device: the library has no CPU path\n");
@@ -182,14 +209,18 @@ int main(int argc, char** argv) {
   // synthetic inputs: sparse event voxels with their support mask, smooth-ish gray image
   std::vector<float> ev((size_t)B * CE * H * W, 0.0f), img((size_t)B * H * W);
   std::vector<uint8_t> mask((size_t)B * H * W, 0);
-  for (int b = 0; b < B; ++b)
-    for (int p = 0; p < H * W; ++p) {
-      if (urand() < 0.1f) {
-        mask[(size_t)b * H * W + p] = 1;
-        for (int c = 0; c < CE; ++c) ev[((size_t)b * CE + c) * H * W + p] = 2.0f * urand() - 1.0f;
+  if (g_in) {
+    from_file(ev), from_file(mask), from_file(img);
+  } else {
+    for (int b = 0; b < B; ++b)
+      for (int p = 0; p < H * W; ++p) {
+        if (urand() < 0.1f) {
+          mask[(size_t)b * H * W + p] = 1;
+          for (int c = 0; c < CE; ++c) ev[((size_t)b * CE + c) * H * W + p] = 2.0f * urand() - 1.0f;
+        }
+        img[(size_t)b * H * W + p] = floorf(urand() * 256.0f);
       }
-      img[(size_t)b * H * W + p] = floorf(urand() * 256.0f);
-    }
+  }
   float* d_ev = upload(ev);
   float* d_img = upload(img);
   uint8_t* d_mask = dalloc<uint8_t>(mask.size());
@@ -233,6 +264,27 @@ int main(int argc, char** argv) {
         if (!(y > py || (y == py && x > px))) rc = 6;
       }
     }
+  }
+  if (out_path) {  // everything a caller of the reference reads from the sparse outputs, as raw arrays
+    FILE* fo = fopen(out_path, "wb");
+    if (!fo) {
+      fprintf(stderr, "cannot write %s\n", out_path);
+      return 2;
+    }
+    auto dump = [&](const void* dptr, size_t bytes) {
+      std::vector<char> h(bytes);
+      HIPCHK(hipMemcpy(h.data(), dptr, bytes, hipMemcpyDeviceToHost));
+      fwrite(h.data(), 1, bytes, fo);
+    };
+    const Outs* sides[2] = {&eo, &io};
+    for (const Outs* o : sides) {
+      dump(o->o.counts, (size_t)B * 4);
+      dump(o->o.positions, (size_t)B * o->sh.cap * 3 * 4);
+      dump(o->o.sparse_desc, (size_t)B * o->sh.cap * o->sh.desc_dim * 4);
+    }
+    dump(m0, (size_t)B * cap0 * 8);
+    dump(nmatch, (size_t)B * 4);
+    fclose(fo);
   }
   double nrm = 0.0;
   for (int c = 0; c < D; ++c) nrm += (double)desc[c] * desc[c];

@@ -9,6 +9,21 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def _cap_thread_pools():
+    """Before numpy / torch / the OpenMP oracle are imported: size their thread pools to the CPUs this process can keep busy
+    (affinity mask capped by the cgroup's CPU quota).  On the GPU boxes 256 logical CPUs are visible under a 16-CPU quota; pools
+    sized from the visible CPUs spin-wait after each parallel region, exhaust the quota and get EVERY thread of the container
+    frozen for up to 100 ms (ei-nexus_official_amd/placement.py::cgroup_cpu_quota, profiles/r05_notes.md)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("einx_placement", os.path.join(ROOT, "ei-nexus_official_amd", "placement.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.cap_thread_pools()
+
+
+HOST_THREADS = _cap_thread_pools()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
