@@ -553,15 +553,15 @@ METRIC_CASES = [
     dict(name="homography", seed=82, n=400, m=350, D=256, hom=[1.02, 0.015, -3.0, -0.01, 0.98, 2.5, 1e-5, -2e-5, 1.0]),
     dict(name="nomatch", seed=83, n=50, m=60, D=32, hom=None, M=0),
     # round 5: the conventions / edge cases of matching_metrics.py:84-156 and keypoints_metrics.py:170-290
-    dict(name="xy_rows", seed=84, n=260, m=300, D=64, hom=[0.99, 0.02, 2.0, -0.015, 1.01, -1.5, 2e-5, 1e-5, 1.0], order="xy"),  # (x, y, score) rows
-    dict(name="two_sizes", seed=85, n=320, m=240, D=128, hom=[0.9, 0.0, 4.0, 0.0, 0.9, 3.0, 0.0, 0.0, 1.0], size0=[260, 346], size1=[240, 320]),
-    dict(name="off_image", seed=86, n=300, m=300, D=64, hom=[1.0, 0.0, 150.0, 0.0, 1.0, -90.0, 0.0, 0.0, 1.0]),  # most points leave the other image
-    dict(name="all_out", seed=87, n=120, m=90, D=32, hom=[1.0, 0.0, 1000.0, 0.0, 1.0, 1000.0, 0.0, 0.0, 1.0]),   # nothing survives the visibility filter
+    dict(name="xy_rows", warped_copies=True, seed=84, n=260, m=300, D=64, hom=[0.99, 0.02, 2.0, -0.015, 1.01, -1.5, 2e-5, 1e-5, 1.0], order="xy"),  # (x, y, score) rows
+    dict(name="two_sizes", warped_copies=True, seed=85, n=320, m=240, D=128, hom=[0.9, 0.0, 4.0, 0.0, 0.9, 3.0, 0.0, 0.0, 1.0], size0=[260, 346], size1=[240, 320]),
+    dict(name="off_image", warped_copies=True, seed=86, n=300, m=300, D=64, hom=[1.0, 0.0, 150.0, 0.0, 1.0, -90.0, 0.0, 0.0, 1.0]),  # most points leave the other image
+    dict(name="all_out", warped_copies=True, seed=87, n=120, m=90, D=32, hom=[1.0, 0.0, 1000.0, 0.0, 1.0, 1000.0, 0.0, 0.0, 1.0]),   # nothing survives the visibility filter
     dict(name="empty0", seed=88, n=0, m=80, D=32, hom=None, M=0),
     dict(name="empty1", seed=89, n=70, m=0, D=32, hom=None, M=0),
-    dict(name="thr135", seed=90, n=400, m=380, D=256, hom=[1.01, -0.02, 1.0, 0.02, 0.99, -2.0, -1e-5, 2e-5, 1.0], thr=[1, 3, 5]),
-    dict(name="perspective", seed=91, n=350, m=350, D=64, hom=[0.95, 0.05, 6.0, -0.04, 1.05, -4.0, 3e-4, -2e-4, 1.0], thr=[1, 3, 5]),
-    dict(name="xy_two_sizes", seed=92, n=200, m=260, D=64, hom=[1.1, 0.0, -5.0, 0.0, 1.1, -4.0, 0.0, 0.0, 1.0], order="xy", size0=[180, 240], size1=[260, 346]),
+    dict(name="thr135", warped_copies=True, seed=90, n=400, m=380, D=256, hom=[1.01, -0.02, 1.0, 0.02, 0.99, -2.0, -1e-5, 2e-5, 1.0], thr=[1, 3, 5]),
+    dict(name="perspective", warped_copies=True, seed=91, n=350, m=350, D=64, hom=[0.95, 0.05, 6.0, -0.04, 1.05, -4.0, 3e-4, -2e-4, 1.0], thr=[1, 3, 5]),
+    dict(name="xy_two_sizes", warped_copies=True, seed=92, n=200, m=260, D=64, hom=[1.1, 0.0, -5.0, 0.0, 1.1, -4.0, 0.0, 0.0, 1.0], order="xy", size0=[180, 240], size1=[260, 346]),
 ]
 
 
@@ -573,8 +573,8 @@ def metric_inputs(c):
     share = min(n, m) * 2 // 3
     k1 = np.stack([synth.uniform(c["seed"] + 3, (m,), 4, H - 4), synth.uniform(c["seed"] + 4, (m,), 4, W - 4), synth.uniform01(c["seed"] + 5, (m,))], 1)
     k1[:share, :2] = k0[:share, :2] + synth.uniform(c["seed"] + 6, (share, 2), -2.5, 2.5)
-    if c.get("hom") is not None and c["name"] not in ("homography",):
-        # round-5 cases: image-1 copies sit where the homography sends the image-0 keypoints (+ the same noise), so that
+    if c.get("hom") is not None and c.get("warped_copies"):
+        # round-5 cases (`warped_copies`): image-1 copies sit where the homography sends the image-0 keypoints (+ the same noise), so that
         # MMA / VDD see real correspondences under a non-trivial warp; (y, x) rows -> (x, y) -> warp -> back
         Hm = np.array(c["hom"], np.float64).reshape(3, 3)
         xy1 = np.stack([k0[:share, 1], k0[:share, 0], np.ones(share)], 0).astype(np.float64)

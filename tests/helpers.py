@@ -224,7 +224,7 @@ def metric_inputs(c):
     share = min(n, m) * 2 // 3
     k1 = np.stack([synth.uniform(c["seed"] + 3, (m,), 4, H - 4), synth.uniform(c["seed"] + 4, (m,), 4, W - 4), synth.uniform01(c["seed"] + 5, (m,))], 1)
     k1[:share, :2] = k0[:share, :2] + synth.uniform(c["seed"] + 6, (share, 2), -2.5, 2.5)
-    if c.get("hom") is not None and c["name"] not in ("homography",):
+    if c.get("hom") is not None and c.get("warped_copies"):
         Hm = np.array(c["hom"], np.float64).reshape(3, 3)
         xy1 = np.stack([k0[:share, 1], k0[:share, 0], np.ones(share)], 0).astype(np.float64)
         w = Hm @ xy1
