@@ -611,10 +611,6 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
 #else
     float* buf = slab + ((4 - head) & 3);                           // ... which then sits on a 16-byte boundary of the slab too
 #endif
-    // LDS byte address of the slab run (wave-uniform): the run is written with ds_write_addtid_b32 (address = M0 + 4 lane,
-    // no address register, 2 instead of 4 cycles of the LDS write path per wave-instruction; round 5: the kernel is bound by
-    // that path -- 48 LDS writes per lane and channel -- not by its ~12 vector instructions per element)
-    const unsigned buf_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)buf);
     const float* rp = rows + cl * 2 * pw;
     bool odd = big;  // some element outside the fast division's range
     float vmin = 0x1p20f;
@@ -639,8 +635,7 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
       }
       if (it < NIT - 1 || xvl) {
 #pragma unroll
-        for (int r = 0; r < UP_ROWS; ++r)  // buf[r * g.W + it * 64 + lane] = q[r]; rows past nrow land in the slab's slack
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" ::"v"(q[r]), "s"(buf_lds + (unsigned)(r * g.W + it * 64) * 4u) : "memory");
+        for (int r = 0; r < UP_ROWS; ++r) buf[r * g.W + it * 64 + lane] = q[r];  // rows past nrow land in the slab's slack
       }
     }
 #if !defined(EINX_UPS_EXP) || EINX_UPS_EXP == 0
