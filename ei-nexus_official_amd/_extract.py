@@ -50,8 +50,9 @@ class FeatsDict(dict):
     read, on the stream current at that moment.  A caller that only reads the sparse outputs (the reference's evaluation
     scripts) never pays for them; a caller that reads them gets the tensors the eager mode would have produced, provided it
     has not modified `raw_descriptors` / `score` in place in between.  Every read path resolves them: d[k], get, items,
-    values, pop, setdefault, copy, iteration-based copies (`dict(d)`, `{**d}`: __iter__ is overridden so that CPython's
-    merge takes the generic keys() + __getitem__ route)."""
+    values, pop, popitem, setdefault, copy, `d | other` / `other | d`, `==` (compared on the resolved values, as plain dicts
+    would be), iteration-based copies (`dict(d)`, `{**d}`: __iter__ is overridden so that CPython's merge takes the generic
+    keys() + __getitem__ route); `reversed(d)` yields keys like any dict."""
     _batched = None
 
     def _resolve(self, k, v):
@@ -89,6 +90,35 @@ class FeatsDict(dict):
             return self[k]
         dict.__setitem__(self, k, default)
         return default
+
+    def popitem(self):
+        k = next(reversed(self))  # dict.popitem's LIFO order
+        return k, self.pop(k)
+
+    def _resolve_all(self):
+        for k in dict.keys(self):
+            self[k]
+        return self
+
+    def __or__(self, other):  # d | other, other | d, ==: plain-dict semantics on the resolved values
+        return dict(self.items()) | (dict(other.items()) if isinstance(other, FeatsDict) else other)
+
+    def __ror__(self, other):
+        return (dict(other.items()) if isinstance(other, FeatsDict) else dict(other)) | dict(self.items())
+
+    def __ior__(self, other):
+        self.update(other.items() if isinstance(other, FeatsDict) else other)
+        return self
+
+    def __eq__(self, other):
+        if isinstance(other, FeatsDict):
+            other._resolve_all()
+        return dict.__eq__(self._resolve_all(), other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
 
     def copy(self):
         out = FeatsDict(self.items())
@@ -246,7 +276,7 @@ def _mask_u8(mask, H, W):
 class ExtractorEngine:
     """Holds the kernel-native layer images of one network and runs the batched forward."""
 
-    use_handle = os.environ.get("EINX_OP_LEVEL", "0") != "1"  # tools: EINX_OP_LEVEL=1 enqueues layer by layer through the op-level ABI
+    use_handle = True  # one einx_extract call per network (tests may set it to False: layer by layer through the op-level ABI)
 
     def __init__(self, kind, *, top_k, radius, border, det_thr, ordering, cell):
         self.kind = kind

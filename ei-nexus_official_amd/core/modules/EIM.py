@@ -36,11 +36,8 @@ class EIM(nn.Module):
                 logger.log_info(f"Loaded pretrain_stage2 model from {config.pretrain_stage2.model_path}")
 
     overlap_extractors = os.environ.get("EINX_OVERLAP", "1") != "0"  # two (independent) extractors on two HIP streams
-    # Measured and NOT the default (tools/experiments/r3_exp15.sh, B=32 full dict): running the event side's dense kernels beside the image
-    # extractor's convolutions and the image side's beside the matcher is slower (11.69 vs 11.10 ms per step): the store
-    # kernel's 248-register workgroups crowd the convolutions off the CUs, and serialising the two extractors gives up
-    # the overlap of their latency-bound tails.
-    dense_schedule = os.environ.get("EINX_DENSE_SCHEDULE", "0") != "0"
+    # (Measured in round 3 and removed in round 5, tools/experiments/r3_exp15.sh: running the event side's dense kernels beside the
+    # image extractor's convolutions and the image side's beside the matcher is slower, 11.69 vs 11.10 ms per step at B=32.)
 
     _side_streams = {}  # one side stream per device for the whole process
 
@@ -51,7 +48,7 @@ class EIM(nn.Module):
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         st = EIM._side_streams.get(key)
         if st is None:
-            st = EIM._side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("EINX_SIDE_PRIO", "0")))
+            st = EIM._side_streams[key] = torch.cuda.Stream(device=device)
         return st
 
     @on_input_device
@@ -60,31 +57,6 @@ class EIM(nn.Module):
         The event and image extractors share nothing, so the event side is enqueued on a second HIP
         stream: its small late layers and its latency-bound NMS/selection kernels overlap the other
         side's convolutions instead of leaving most of the 256 CUs idle."""
-        dense = self.event_extractor.extractor.dense_outputs is True and self.image_extractor.extractor.dense_outputs is True
-        if dense and self.overlap_extractors and self.dense_schedule and events.device.type == "cuda":
-            # Experiment (EINX_DENSE_SCHEDULE=1): event extractor first, then the image extractor on the caller's stream WHILE the
-            # event side's dense kernels (an HBM-bound store of 2.95 GB at B=32) run on the side stream; the image side's dense
-            # kernels run beside the matcher.
-            cur = torch.cuda.current_stream(events.device)
-            side = self._side_stream(events.device)
-            ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared, defer_dense=True)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                ev.run_dense()
-            im = self.image_extractor.extract_batched(image, image_mask, nms_iters=nms_iters, prepared=prepared, defer_dense=True)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                im.run_dense()
-            if before_match is not None:
-                before_match(ev, im)
-            mr = None
-            if self.matcher.matcher is not None and self.matcher.freeze:
-                mr = self.matcher.match_batched(ev, im)
-            cur.wait_stream(side)
-            for t in (ev.normalized, im.normalized):
-                if t is not None:
-                    t.record_stream(cur)  # allocated on the side stream, handed to the caller on its own stream
-            return ev, im, mr
         if self.overlap_extractors and events.device.type == "cuda":
             cur = torch.cuda.current_stream(events.device)
             side = self._side_stream(events.device)

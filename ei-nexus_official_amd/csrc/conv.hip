@@ -163,21 +163,6 @@ __global__ __launch_bounds__(WM * WN * 64, WPS) void conv_block_kernel(const Con
   float* in_tile = lds;
   float* w_tile = lds + IN_LDS;
 
-#if defined(EINX_CONV_STAGGER) && EINX_CONV_STAGGER > 0
-  // experiment (round 5): the co-resident workgroups of a CU start together, run equally long and so keep meeting at their
-  // barriers, epilogues and prologues.  Delay one of each first-generation pair once; its successors inherit the offset.
-  {
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-    const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID[3:0]: wave slot on its SIMD
-    const unsigned per = 256u * (WM * WN >= 8 ? 2u : 3u);
-#ifndef EINX_CONV_STAGGER_MODE
-#define EINX_CONV_STAGGER_MODE 0
-#endif
-    const bool late = EINX_CONV_STAGGER_MODE == 0 ? (slot & 2u) != 0 : (EINX_CONV_STAGGER_MODE == 1 ? lin >= 256u : (lin & 1u) != 0);
-    if (lin < per && late)
-      for (int i = 0; i < EINX_CONV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles = 3.4 us each
-  }
-#endif
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and provably so for the compiler (scalar registers)
   const int wm = wave / WN, wn = wave % WN;
@@ -354,19 +339,10 @@ __global__ __launch_bounds__(WM * WN * 64, WPS) void conv_block_kernel(const Con
   };
   issue_loads(0);
   for (int c = 0; c < nchunks; ++c) {
-#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL)  // timing-only ablations (wrong results): bit 0 no per-chunk loads, bit 1 no barriers / commits after the first chunk, bit 2 no epilogue
-    if (!(EINX_CONV_ABL & 2) || c == 0) {
-      __syncthreads();
-      commit_loads();
-      __syncthreads();
-    }
-    if (!(EINX_CONV_ABL & 1) && c + 1 < nchunks) issue_loads(c + 1);
-#else
     __syncthreads();  // previous round's LDS reads are done
     commit_loads();
     __syncthreads();
     if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under this chunk's MFMAs
-#endif
     mfma_chunk();
     if (XTRA && xtra_wg && tid < NPIX) {  // rows of a 1x1 layer's native weight image are the input channels in order
       const float* wx = a.w + (size_t)c * W_ROWS * a.CoutPad + (a.CoutPad - kCoutTile);
@@ -463,17 +439,6 @@ __global__ __launch_bounds__(WM * WN * 64, WPS) void conv_block_kernel(const Con
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
-#if defined(EINX_TIMING_ONLY_BUILD) && defined(EINX_CONV_ABL) && (EINX_CONV_ABL & 4)
-  {
-#pragma unroll
-    for (int mt = 0; mt < kMT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < kNT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[mt][nt][r]));
-    return;
-  }
-#endif
   if (a.relu) {
     if (a.scale) epilogue(T_{}, T_{});
     else epilogue(T_{}, F_{});
@@ -940,10 +905,6 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
   }
   // (rounds 2-4 preferred the 8-wave 11x22 tile over the 4-wave 192-slot tiles at up to 6 % more pixel slots; with the
   // round-5 kernel the exact 12x16 tiling of the 132x176 maps is 10 % faster: 455 -> 412 us at B=32)
-  {  // TEMPORARY tuning aid (round 5): force the tile
-    static const int force = (getenv("EINX_CONV_TILE") && *getenv("EINX_CONV_TILE")) ? atoi(getenv("EINX_CONV_TILE")) : -1;
-    if (force >= 0 && force <= 4 && d->cin > 6 && !(d->pool && ((cfgs[force].th & 1) || (cfgs[force].tw & 1)))) best = force;
-  }
   {
     // Small grids (single images: the reference's own call pattern): the launch does not fill the chip, so what counts is the
     // LATENCY of one workgroup = (waves it puts on a SIMD) x (accumulator tiles per wave) x K-steps x 64 cycles -- the k-ordered
@@ -952,7 +913,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
     // generic path (they are store-bound).
     const long blocks_best = (long)einx_cdiv(H, cfgs[best].th) * einx_cdiv(W, cfgs[best].tw) * B * (a.CoutPad / kCoutTile);
     // the finest grain: one 16x16 accumulator per wave on the 16x16x4 instruction, when even that leaves SIMDs to spare
-    // (MFMA tiles = pixels / 16 x channels / 16 <= EINX_CONV16_MAX_TILES) -- see conv16_kernel
+    // (MFMA tiles = pixels / 16 x channels / 16 <= 8192) -- see conv16_kernel
     {
       const long max_tiles = 8192;
       const long t16 = (long)einx_cdiv(H, 2) * einx_cdiv(W, 8) * B * (a.CoutPad / 16);

@@ -220,11 +220,7 @@ __global__ void normalize_map_kernel(const float* raw, int B, int D, int P, floa
 // each row of a band is stored as one 256-byte segment per channel.  Pass 1 accumulates the per-pixel
 // squared norm as the sequential fmaf chain c = 0..D-1, pass 2 recomputes and writes scale * v / norm.
 constexpr int UP_COLS = 384;  // columns per workgroup: whole 346-pixel rows, so a band is one contiguous run per channel
-#ifndef EINX_UP_ROWS
-#define EINX_UP_ROWS 8
-#endif
-static_assert(EINX_UP_ROWS >= 1 && EINX_UP_ROWS <= 8, "upsample_store_kernel copies a wave's slab out with 2*NIT float4 per lane = 8 rows of 64*NIT floats");
-constexpr int UP_ROWS = EINX_UP_ROWS;    // rows per sweep: a band of the usual 1/8 scale (the first band takes two sweeps)
+constexpr int UP_ROWS = 8;               // rows per sweep: a band of the usual 1/8 scale (the first band takes two sweeps)
   // 
 
 __global__ __launch_bounds__(UP_COLS) void upsample_band_kernel(const float* raw, int D, int hc, int wc, int Hp, int Wp, int h0, int w0, int H,
@@ -357,30 +353,12 @@ __global__ __launch_bounds__(UP_COLS) void upsample_band_kernel(const float* raw
 // A sweep = up to UP_ROWS consecutive output rows that interpolate between the same two coarse rows (j, y1): unit
 // (j, s) = rows [first row of band j + s UP_ROWS, + UP_ROWS) of band j; units 0..hc-1 are the first sweeps, the few further
 // sweeps of taller bands are listed by the host (UpGeom::extra_*), so every workgroup has work.  Both kernels keep the per-element operation order of orc_upsample_normalize (bit-equal).
-#ifndef EINX_UPS_CC
-#define EINX_UPS_CC 32
-#endif
-constexpr int UPS_CC = EINX_UPS_CC;  // channels per workgroup of the store kernel: 64 (channel, row) pairs = 16 per wave
+constexpr int UPS_CC = 32;  // channels per workgroup of the store kernel: 64 (channel, row) pairs = 16 per wave
 constexpr int UPS_WAVES = 4;
-#ifndef EINX_UPS_EXP
-#define EINX_UPS_EXP 0
-#endif
 constexpr int UP_PAIRS = 16;  // (channel, coarse row) pairs a wave of the store kernel stages (once)
-#ifndef EINX_UPD_PAIRS
-#define EINX_UPD_PAIRS 8
-#endif
-#ifndef EINX_UPD_UNROLL
-#define EINX_UPD_UNROLL 1
-#endif
-#ifndef EINX_UPD_WAVES
-#define EINX_UPD_WAVES 8
-#endif
-constexpr int UPD_PAIRS = EINX_UPD_PAIRS;  // ... and a wave of the den kernel per round (registers: five of its workgroups per CU)
+constexpr int UPD_PAIRS = 8;  // ... and a wave of the den kernel per round (registers: five of its workgroups per CU)
 
-#ifndef EINX_UP_MAX_EXTRA
-#define EINX_UP_MAX_EXTRA 8
-#endif
-constexpr int UP_MAX_EXTRA = EINX_UP_MAX_EXTRA;
+constexpr int UP_MAX_EXTRA = 8;
 struct UpGeom {
   int D, hc, wc, Hp, Wp, h0, w0, H, W;
   int units;  // hc first sweeps + n_extra further sweeps of bands taller than UP_ROWS (band 0 at the shipped size)
@@ -478,7 +456,7 @@ __device__ __forceinline__ void up_stage_commit(const UpStage<PAIRS>& st, const 
 // NW waves per workgroup; blockIdx.z walks the column blocks of 64 NW (two half-width workgroups per sweep at W = 346:
 // twice as many, half as long workgroups load the CUs more evenly than 34 x B whole-row ones)
 template <int NW>
-__global__ __launch_bounds__(64 * NW, EINX_UPD_WAVES) void upsample_den_kernel(const float* raw, UpGeom g, float* den, float* rden) {
+__global__ __launch_bounds__(64 * NW, 8) void upsample_den_kernel(const float* raw, UpGeom g, float* den, float* rden) {
   constexpr int NIT = NW;
   constexpr int CHR = UPD_PAIRS * NIT / 2;  // channels per LDS round: every wave stages UPD_PAIRS (channel, row) pairs
   extern __shared__ float rows[];          // [CHR][2][wc + 1]
@@ -509,7 +487,7 @@ __global__ __launch_bounds__(64 * NW, EINX_UPD_WAVES) void upsample_den_kernel(c
     up_stage_commit(st, g, n, rows, lane, wv, NIT);
     __syncthreads();
     const float* rp = rows + x0;
-#pragma unroll EINX_UPD_UNROLL
+#pragma unroll 1  // (2 / 4 measured the same)
     for (int cl = 0; cl < n; ++cl, rp += 2 * pw) {
       const float t0 = hx * rp[0] + lx * rp[1];
       const float t1 = hx * rp[pw] + lx * rp[pw + 1];
@@ -606,11 +584,7 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
   for (int cl = wave; cl < nc; cl += UPS_WAVES) {
     float* oc = out + ((size_t)b * g.D + c0 + cl) * HW + (size_t)(Y - g.h0) * g.W;
     const int head = (int)(((16 - ((size_t)oc & 15)) & 15) >> 2);  // floats up to the first 16-byte boundary of the run
-#ifdef EINX_UPS_NOSHIFT
-    float* buf = slab;
-#else
     float* buf = slab + ((4 - head) & 3);                           // ... which then sits on a 16-byte boundary of the slab too
-#endif
     const float* rp = rows + cl * 2 * pw;
     bool odd = big;  // some element outside the fast division's range
     float vmin = 0x1p20f;
@@ -622,25 +596,15 @@ __global__ __launch_bounds__(64 * UPS_WAVES) void upsample_store_kernel(const fl
 #pragma unroll
       for (int r = 0; r < UP_ROWS; ++r) {
         const float v = hy[r] * t0 + ly[r] * t1;
-#if EINX_UPS_EXP == 1  // timing experiment (wrong results): no division
-        q[r] = v;
-#elif EINX_UPS_EXP == 2  // timing experiment: one correction step, no range check
-        { const float q0 = v * yr[it][r]; q[r] = scale * fmaf(fmaf(-dn[it][r], q0, v), yr[it][r], q0); }
-#elif EINX_UPS_EXP == 3  // timing experiment: no range check
-        q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
-#else
         vmin = fminf(vmin, fabsf(v));  // lower end of the fast division's range, tested once per channel; the upper end once per sweep on the norms (|v| <= den < 2^20; a NaN element has a NaN norm)
         q[r] = scale * up_div(v, dn[it][r], yr[it][r]);
-#endif
       }
       if (it < NIT - 1 || xvl) {
 #pragma unroll
         for (int r = 0; r < UP_ROWS; ++r) buf[r * g.W + it * 64 + lane] = q[r];  // rows past nrow land in the slab's slack
       }
     }
-#if !defined(EINX_UPS_EXP) || EINX_UPS_EXP == 0
     odd |= !(vmin >= 0x1p-80f);
-#endif
     if (__builtin_expect(__any(odd), 0)) {  // the same values with IEEE divisions
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {  // unrolled: a rolled loop would index the per-sweep register arrays dynamically (scratch)

@@ -164,10 +164,7 @@ __global__ void border_kernel(float* score, int B, int Hp, int Wp, int border) {
 // raises flags[b][it] if it zeroes any non-zero pixel.  When a pass changes nothing src == dst, so
 // skipped passes leave both ping-pong buffers holding the fix-point.
 // ------------------------------------------------------------------------------------------
-#ifndef EINX_NMS_THREADS
-#define EINX_NMS_THREADS 512
-#endif
-constexpr int NMS_TH = 32, NMS_TW = 64, NMS_MAXR = 4, NMS_THREADS = EINX_NMS_THREADS;
+constexpr int NMS_TH = 32, NMS_TW = 64, NMS_MAXR = 4, NMS_THREADS = 512;
 
 template <int R>
 __global__ __launch_bounds__(NMS_THREADS) void nms_pass_kernel(const float* src, float* dst, int Hp, int Wp, int tilesX, int tilesY,

@@ -8,13 +8,9 @@
 
 #define EINX_EXPORT extern "C" __attribute__((visibility("default")))
 
-// Experiment switches that drop work to time what is left (WRONG results) or insert delays only exist in builds that say
-// so: -DEINX_TIMING_ONLY_BUILD, which einx_build_flags() reports and the Python package refuses to load by default.
-#if (defined(EINX_GEMM_ABL) && EINX_GEMM_ABL != 0) || (defined(EINX_UPS_EXP) && EINX_UPS_EXP != 0) || defined(EINX_CONV_ABL) || defined(VOX_EXP)
-#ifndef EINX_TIMING_ONLY_BUILD
-#error "EINX_GEMM_ABL / EINX_UPS_EXP / EINX_CONV_ABL / VOX_EXP are timing-only ablations: add -DEINX_TIMING_ONLY_BUILD"
-#endif
-#endif
+// Timing-only ablations (switches that drop work to time what is left: WRONG results) live as patch files under
+// tools/experiments/, not in these sources (round 5).  A build made from a patched tree must define EINX_TIMING_ONLY_BUILD:
+// einx_build_flags() reports it and the Python package refuses to load such a library by default.
 
 void einx_set_error(const char* fmt, ...);
 
@@ -54,14 +50,10 @@ class EinxProfScope {
 // correctness), each XCD with its own L2.  xcd_contiguous() turns the linear workgroup id into a work-item id such that every
 // XCD walks ONE contiguous range of work items: neighbouring tiles (shared halo rows, shared K/V blocks) then meet in one
 // L2 instead of eight.  A bijection on [0, total) for every total.
-#ifndef EINX_NO_XCD_REMAP
 __device__ __forceinline__ int xcd_contiguous(int linear, int total) {
   const int per = total >> 3;
   return linear < (per << 3) ? (linear & 7) * per + (linear >> 3) : linear;
 }
-#else
-__device__ __forceinline__ int xcd_contiguous(int linear, int) { return linear; }
-#endif
 
 // Content watch of a module's weights (common.hip::einx_params_hash): one wave hashes 64 evenly spread 32-bit words + the last
 // word of tensor t; with `ref` set a difference raises `bit` in *flag.  Also run by spare workgroups of desc_sample_kernel, so

@@ -18,12 +18,6 @@
 
 namespace {
 
-// timing-only ablations (wrong results; never in the shipped library): -DEINX_TIMING_ONLY_BUILD -DVOX_EXP=1..4
-#if defined(EINX_TIMING_ONLY_BUILD) && defined(VOX_EXP)
-#define VOX_EXP_ON(k) (VOX_EXP == (k))
-#else
-#define VOX_EXP_ON(k) 0
-#endif
 constexpr int VOX_BANDS = 16;   // column bands = waves of a scatter workgroup (each voxel column has ONE owner wave)
 constexpr int VOX_SEGS = 16;    // event segments = waves of a scatter workgroup (each wave sweeps one contiguous share)
 constexpr int VOX_TAGS = 128;   // per-wave collision tags
@@ -241,7 +235,7 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
   long long slab_base = 4 * o0;
   for (int w = 0; w < 16; ++w) slab_base += red[w];
   uint32_t* lists = a.lists + slab_base;
-  if (n > 0 && !VOX_EXP_ON(1)) {
+  if (n > 0) {
     {  // ---- 1. sweep segment `wave`
       const long long seg = vox_seg(n), lo = wave * seg, hi = min(n, lo + seg);
       const uint32_t* keys = a.keys + o0;
@@ -264,7 +258,7 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
           if (hit) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
           qn += __popcll(m);
           if (qn >= 64) {  // wave-uniform
-            if (!VOX_EXP_ON(4)) vox_distribute(queue[lane], true, keys, lists, sub_base, wave, a.bw, a.W, curv, vcnt_all + wave * VOX_BANDS);
+            vox_distribute(queue[lane], true, keys, lists, sub_base, wave, a.bw, a.W, curv, vcnt_all + wave * VOX_BANDS);
             qn -= 64;
             if (lane < qn) {
               const uint32_t v = queue[64 + lane];
@@ -273,14 +267,13 @@ __global__ __launch_bounds__(1024, 8) void voxel_scatter_kernel(const VoxArgs a,
           }
         }
       }
-      if (qn > 0 && !VOX_EXP_ON(4)) vox_distribute(lane < qn ? queue[lane] : 0u, lane < qn, keys, lists, sub_base, wave, a.bw, a.W, curv, vcnt_all + wave * VOX_BANDS);
+      if (qn > 0) vox_distribute(lane < qn ? queue[lane] : 0u, lane < qn, keys, lists, sub_base, wave, a.bw, a.W, curv, vcnt_all + wave * VOX_BANDS);
     }
     // the lists are read by other waves of this workgroup: same CU, same L1 -> a workgroup-scope release is enough
-    if (!VOX_EXP_ON(3)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    else __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (an agent-scope __threadfence() here costs ~290 us per launch: L2 write-back)
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (!VOX_EXP_ON(2) && !VOX_EXP_ON(4)) {  // ---- 2. scatter band `wave`
+    {  // ---- 2. scatter band `wave`
       const uint32_t* mylist = lists + sub_base[wave * VOX_SEGS];
       const int mylen = sub_base[(wave + 1) * VOX_SEGS] - sub_base[wave * VOX_SEGS];
       const float4* rec = a.rec + o0;

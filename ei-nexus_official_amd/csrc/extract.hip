@@ -63,13 +63,8 @@ struct Plan {
 // normalisation) does not depend on the detector branch (head convs, score map, NMS passes, selection) until the sparse
 // sampling, so it is enqueued on a second, library-owned stream between a fork and a join event: at B=1 ~90 us of ~540 per
 // network leave the critical path.  The rule depends only on the arguments that size the workspace (a second head scratch).
-#ifndef EINX_FORK_MAX_CELLS
-#define EINX_FORK_MAX_CELLS 8192  // B x head pixels up to which the two head branches run concurrently (B <= 5 at 33x44)
-#endif
-bool fork_heads(const einx_extractor* e, const Plan& pl, int B) {
-  static const int off = getenv("EINX_NO_FORK") ? 1 : 0;
-  return !off && (long)B * pl.hc * pl.wc <= EINX_FORK_MAX_CELLS;
-}
+constexpr long kForkMaxCells = 8192;  // B x head pixels up to which the two head branches run concurrently (B <= 5 at 33x44)
+bool fork_heads(const einx_extractor* e, const Plan& pl, int B) { return (long)B * pl.hc * pl.wc <= kForkMaxCells; }
 
 // the side of `caller` (keyed on the stream's OWN device, not on the current one)
 EinxSide* side_for(const einx_extractor* e, hipStream_t caller) {

@@ -11,29 +11,17 @@
 
 namespace einx_gemm {
 
-#ifndef EINX_GEMM_WAVES
-#define EINX_GEMM_WAVES 8
-#endif
-#ifndef EINX_GEMM_BK
-#define EINX_GEMM_BK 32
-#endif
-#ifndef EINX_GEMM_B64
-#define EINX_GEMM_B64 0
-#endif
-// EINX_GEMM_B64: fragments of TWO K-steps per ds_read_b64.  Each group of four k is stored as (k, k+2, k+1, k+3), so the lane
-// half that feeds k = 2 kk + half finds its operands of steps 2j and 2j+1 side by side; the K order of the MFMAs (hence every
-// result bit) is unchanged.  Row pitch 34: 8-byte aligned rows, and 34 r mod 64 is a permutation of the even banks, so the
-// 32 rows of a lane group hit 64 distinct banks.
-constexpr int BM = 128, BN = 128, BK = EINX_GEMM_BK, PITCH = EINX_GEMM_B64 ? BK + 2 : BK + 1;
+// (measured alternatives that are no longer in the source: 4 waves of 2x2 tiles, BK = 64, fragments of two K-steps per
+// ds_read_b64, prefetch distances 2-3, staging ablations -- profiles/r03_notes.md 7-9, tools/experiments/r5_removed_switches.patch)
+constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 1;
 constexpr int LDS_FLOATS = (BM + BN) * PITCH;
-constexpr int WAVES = EINX_GEMM_WAVES;   // waves are arranged (WAVES/2) along M x 2 along N
+constexpr int WAVES = 8;   // waves are arranged (WAVES/2) along M x 2 along N
 constexpr int THREADS = WAVES * 64;
 constexpr int MT = BM / ((WAVES / 2) * 32);  // 32x32 MFMA tiles per wave along M (4 waves: 2, 8 waves: 1)
 constexpr int NT = 2;                        // ... along N (a wave always spans 64 columns)
 constexpr int WROWS = MT * 32;               // rows a wave owns
 constexpr int C4 = BK / 4;                   // float4 per operand row per K-slab
 constexpr int STAGE = 128 * C4 / THREADS;    // float4 per thread per operand per K-slab
-static_assert(WAVES == 4 || WAVES == 8, "tile engine is written for 4 or 8 waves");
 
 struct Frag {
   f32x16 acc[MT][NT];
@@ -95,20 +83,10 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
     for (int i = 0; i < STAGE; ++i) {
       const int fidx = tid + i * THREADS;
       const int r = fidx / C4, c4 = fidx % C4;
-      if (EINX_GEMM_B64) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2* pa = reinterpret_cast<f32x2*>(As + r * PITCH + c4 * 4);
-        f32x2* pb = reinterpret_cast<f32x2*>(Bs + r * PITCH + c4 * 4);
-        pa[0] = f32x2{st.ra[i][0], st.ra[i][2]};
-        pa[1] = f32x2{st.ra[i][1], st.ra[i][3]};
-        pb[0] = f32x2{st.rb[i][0], st.rb[i][2]};
-        pb[1] = f32x2{st.rb[i][1], st.rb[i][3]};
-      } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          As[r * PITCH + c4 * 4 + t] = st.ra[i][t];
-          Bs[r * PITCH + c4 * 4 + t] = st.rb[i][t];
-        }
+      for (int t = 0; t < 4; ++t) {
+        As[r * PITCH + c4 * 4 + t] = st.ra[i][t];
+        Bs[r * PITCH + c4 * 4 + t] = st.rb[i][t];
       }
     }
   };
@@ -144,19 +122,10 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
 #pragma unroll
     for (int i = 0; i < STAGE; ++i) st.rb[i] = *reinterpret_cast<const f32x4*>(bk + offb[i]);
   };
-#ifndef EINX_GEMM_ABL
-#define EINX_GEMM_ABL 0  // timing-only ablations (wrong results; tools/experiments/r3_exp16.sh): 1 no LDS commit (the loads die with it), 2 also one barrier per slab, 3 also no global loads, 4 loads kept alive but no LDS writes
-#endif
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();  // the previous slab's (or tile's) fragment reads are done
-    if (EINX_GEMM_ABL == 0) commit();
-    if (EINX_GEMM_ABL == 4) {
-#pragma unroll
-      for (int i = 0; i < STAGE; ++i) asm volatile("" ::"v"(st.ra[i]), "v"(st.rb[i]));
-    }
-    if (EINX_GEMM_ABL < 2) __syncthreads();
-    if (EINX_GEMM_ABL == 3) {
-    } else
+    commit();
+    __syncthreads();
     if (k0 + BK < K) {  // in flight under the MFMAs below
       if (whole) issue_whole(k0 + BK);
       else issue_slab(cur, k0 + BK, K, Ksplit, st);
@@ -164,57 +133,26 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
       issue_slab(next, 0, K, Ksplit, st);
     }
     // software-pipelined fragment reads: step kk+1's operands are requested before step kk's MFMAs
-#ifndef EINX_GEMM_PF
-#define EINX_GEMM_PF 1
-#endif
-    if (EINX_GEMM_B64) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      const int aoff2 = (wm * WROWS + l31) * PITCH + 2 * half;
-      const int boff2 = (wn * 64 + l31) * PITCH + 2 * half;
-      constexpr int NP = BK / 4;  // pairs of K-steps per slab
-      f32x2 av2[2][MT], bv2[2][NT];
-      auto load_pair = [&](int j, int buf) {
+    constexpr int PF = 1;  // fragment prefetch distance in K-steps
+    float av[PF + 1][MT], bv[PF + 1][NT];
+    auto load_frag = [&](int kk, int buf) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av2[buf][mt] = *reinterpret_cast<const f32x2*>(As + aoff2 + mt * 32 * PITCH + j * 4);
+      for (int mt = 0; mt < MT; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv2[buf][nt] = *reinterpret_cast<const f32x2*>(Bs + boff2 + nt * 32 * PITCH + j * 4);
-      };
-      load_pair(0, 0);
+      for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
+    };
 #pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        if (j + 1 < NP) load_pair(j + 1, (j + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int kk = 0; kk < PF; ++kk) load_frag(kk, kk % (PF + 1));
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      if (kk + PF < BK / 2) load_frag(kk + PF, (kk + PF) % (PF + 1));
+      __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[j & 1][mt][h2], bv2[j & 1][nt][h2], f.acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      constexpr int PF = EINX_GEMM_PF;  // fragment prefetch distance in K-steps
-      float av[PF + 1][MT], bv[PF + 1][NT];
-      auto load_frag = [&](int kk, int buf) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[buf][mt] = As[aoff + mt * 32 * PITCH + kk * 2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = Bs[boff + nt * 32 * PITCH + kk * 2];
-      };
-#pragma unroll
-      for (int kk = 0; kk < PF; ++kk) load_frag(kk, kk % (PF + 1));
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        if (kk + PF < BK / 2) load_frag(kk + PF, (kk + PF) % (PF + 1));
-        __builtin_amdgcn_sched_barrier(0);  // hipcc would otherwise sink the prefetch next to its use
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % (PF + 1)][mt], bv[kk % (PF + 1)][nt], f.acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int nt = 0; nt < NT; ++nt)
+          f.acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % (PF + 1)][mt], bv[kk % (PF + 1)][nt], f.acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }

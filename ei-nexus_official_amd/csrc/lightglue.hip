@@ -82,11 +82,8 @@ struct GemmArgs {
 // the same 128 rows of X are computed on one XCD at about the same time and X is fetched into that
 // L2 once.  The next tile's first K-slab is requested during the current tile's last K-slab, so its
 // latency and the epilogue's stores overlap instead of serialising per tile.
-#ifndef EINX_GEMM_WG_PER_CU
-#define EINX_GEMM_WG_PER_CU 2  // resident workgroups per CU the register budget is set for
-#endif
 template <int EPI>
-__global__ __launch_bounds__(THREADS, EINX_GEMM_WG_PER_CU * THREADS / 256) void lg_gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(const GemmArgs g) {  // registers for two resident workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tilesN = einx_cdiv(g.N, BN), tilesM = einx_cdiv(g.cap, BM);
   const int groups = tilesM * g.B;                       // A-row groups
@@ -379,129 +376,6 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// FFN first half in ONE launch (round 3): h = GELU(LayerNorm(cat(x, msg) @ W0^T + b0)), lightglue.py:247-249 / :297-299.
-// LayerNorm needs whole 512-wide rows, which span four 128-column tiles.  Here a workgroup owns a GROUP of 128 rows: it
-// runs the group's four tiles back to back (same tile engine, the next tile's first K-slab prefetched as before), writes
-// the pre-activation rows, and then -- once its own stores are complete -- normalises and activates those 128 rows in
-// place, one wave per row, with exactly the arithmetic of lg_ln_gelu_kernel (sum -> mean -> sum of squared deviations ->
-// rstd -> gelu(fma)), so results are bit-identical to the two-launch form.  The rows it re-reads were written a few
-// microseconds earlier by this workgroup and come from L2 (loads bypass L1): the 2 x 134 MB HBM round trip and 18
-// launches of the stand-alone LayerNorm+GELU kernel per forward (B=64) are gone; the other workgroup of the CU keeps the
-// matrix cores busy during the tail.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_ffn0_ln_gelu_kernel(const GemmArgs g, const float* ln_g, const float* ln_b) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  constexpr int TN = 4;  // 512 output columns = 4 tiles
-  const int tilesM = einx_cdiv(g.cap, BM);
-  const int groups = tilesM * g.B;
-  auto locate = [&](int L, Src& s, int& bb, int& nn) {  // L = group * TN + tile
-    const int grp = L / TN;
-    if (grp >= groups) return false;
-    const int b = grp / tilesM, ti = grp % tilesM;
-    const int n = g.cnt ? min(g.cnt[b], g.cap) : g.cap;
-    if (ti * BM >= n) return false;
-    s.A = g.X + (size_t)b * g.cap * g.ldx;
-    s.A2 = g.X2 + (size_t)b * g.cap * g.ldx2;
-    s.lda = g.ldx;
-    s.lda2 = g.ldx2;
-    s.i0 = ti * BM;
-    s.Mvalid = n;
-    s.B = g.W;
-    s.ldb = g.K;
-    s.j0 = (L % TN) * BN;
-    s.Nvalid = g.N;
-    bb = b;
-    nn = n;
-    return true;
-  };
-  const int total = groups * TN, step = (int)gridDim.x * TN;
-  Src cur, nxt;
-  int b = 0, n = 0, nb = 0, nn = 0;
-  int L = (int)blockIdx.x * TN;
-  while (L < total && !locate(L, cur, b, n)) L += step;
-  if (L >= total) return;
-  Stage st;
-  issue_slab(cur, 0, g.K, g.Ksplit, st);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (;;) {
-    // next tile: the same group's next column tile, else the first tile of this workgroup's next group
-    int Ln = L + 1;
-    if (Ln % TN == 0) {
-      Ln = L - (TN - 1) + step;
-      while (Ln < total && !locate(Ln, nxt, nb, nn)) Ln += step;
-    } else {
-      locate(Ln, nxt, nb, nn);
-    }
-    const bool more = Ln < total;
-    Frag f;
-    tile_nt_run(cur, g.K, g.Ksplit, lds, f, st, nxt, more);
-    const int i0 = cur.i0, j0 = cur.j0;
-    float* Y = g.Y + (size_t)b * g.cap * g.ldy;
-    float bj[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bj[nt] = g.bias[j0 + col_of(nt)];
-    if (i0 + BM <= n) {
-      float* ytile = Y + (size_t)i0 * g.ldy + j0;
-      const unsigned lane_off = (unsigned)(row_base() * g.ldy + col_of(0));
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* yrow = ytile + (size_t)row_step(mt, r) * g.ldy;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) yrow[lane_off + nt * 32] = f.acc[mt][nt][r] + bj[nt];
-        }
-    } else {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = i0 + row_of(mt, r);
-          if (i >= n) continue;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) Y[(size_t)i * g.ldy + j0 + col_of(nt)] = f.acc[mt][nt][r] + bj[nt];
-        }
-    }
-    if (L % TN == TN - 1) {
-      // ---- tail: LayerNorm + GELU over this group's rows.  Every wave drains its stores, the barrier orders all of the
-      // workgroup's stores before any of its re-reads, and the re-reads bypass L1 (agent-scope relaxed loads).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      for (int rr = wave; rr < BM; rr += WAVES) {
-        const int i = i0 + rr;
-        if (i >= n) break;
-        float* row = Y + (size_t)i * g.ldy;
-        float v[8];
-        float sum = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          v[t] = __hip_atomic_load(row + lane + 64 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sum += v[t];
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        const float mean = sum / 512.0f;
-        float q = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) q = fmaf(v[t] - mean, v[t] - mean, q);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-        const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int c = lane + 64 * t;
-          row[c] = einx_geluf(fmaf((v[t] - mean) * rstd, ln_g[c], ln_b[c]));
-        }
-      }
-    }
-    if (!more) break;
-    cur = nxt;
-    b = nb;
-    n = nn;
-    L = Ln;
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // fused attention: out[b,q,h*64:(h+1)*64] = softmax_j(scale * Q_h[q] . K_h[j]) V_h[j]
@@ -518,10 +392,7 @@ struct AttnArgs {
   int kv_shift, Btot;  // keys / values of batch entry b come from entry (b + kv_shift) % Btot (cross attention over the two sides stacked in one buffer)
 };
 
-#ifndef EINX_AKB
-#define EINX_AKB 32
-#endif
-constexpr int AKB = EINX_AKB;   // keys staged per round (32: 124 VGPRs -> three workgroups per CU; 64: 151 -> two)
+constexpr int AKB = 32;   // keys staged per round (32: 124 VGPRs -> three workgroups per CU; 64: 151 -> two)
 constexpr int KPITCH = 68;  // K rows padded to 68 floats: 16-byte aligned for ds_read_b128, and the 32 rows a
                             // half-wave reads start on 16 distinct 4-bank groups (conflict-free)
 
@@ -856,7 +727,6 @@ unsigned gemm_grid(int tiles) {
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lg_gemm_kernel<EPI_BIAS>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     }
-    if (const char* e = getenv("EINX_GEMM_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // experiments: cap the resident workgroups per CU
     resident = (cus * per_cu) & ~7;
     if (resident < 8) resident = 8;
   }
@@ -866,7 +736,7 @@ unsigned gemm_grid(int tiles) {
 
 // fewer 128x128 tiles than CUs (and shapes the small kernel takes): 64x64 tiles, one per workgroup
 bool small_grid(int N, int cap, int B, int K, int Ksplit) {
-  static const long max_tiles = getenv("EINX_LG_SMALL_MAX_TILES") ? atol(getenv("EINX_LG_SMALL_MAX_TILES")) : 256;
+  const long max_tiles = 256;
   const long tiles = (long)einx_cdiv(N, BN) * einx_cdiv(cap, BM) * B;
   return tiles < max_tiles && K % SBK == 0 && N % SBN == 0 && (Ksplit >= K || Ksplit % SBK == 0);
 }
@@ -960,41 +830,13 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
 // ffn(cat[x,msg]) + residual, in place on s.x
 int ffn(hipStream_t st, const Side& s, int B, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
         const float* w3, const float* b3) {
-  // Measured (tools/experiments/r3_exp8.sh, B=64, one box): LightGlue 46.0 ms with the two launches below, 47.5 ms with the fused
-  // kernel (bit-identical outputs).  With 512 row groups on 512 resident workgroups every workgroup reaches its LayerNorm
-  // tail at the same time, so the tail does not hide under another workgroup's matrix work, and the group-per-workgroup
-  // order gives up the XCD-shared operand rows.  The fused kernel stays selectable (EINX_LG_FUSE_LN=1) as the measured record.
-  static const bool fuse = getenv("EINX_LG_FUSE_LN") != nullptr;
-  if (fuse) {
-    GemmArgs a{};
-    a.X = s.x;
-    a.X2 = msg;
-    a.W = w0;
-    a.bias = b0;
-    a.Y = s.h;
-    a.cnt = s.cnt;
-    a.cap = s.cap;
-    a.ldx = D;
-    a.ldx2 = D;
-    a.Ksplit = D;
-    a.K = 2 * D;
-    a.N = 2 * D;
-    a.ldy = 2 * D;
-    a.div = 1.0f;
-    a.B = B;
-    const int groups = einx_cdiv(s.cap, BM) * B;
-    const unsigned res = gemm_grid(groups * 4);
-    EINX_PROF("lg_ffn0_ln_gelu_kernel", st);
-    hipLaunchKernelGGL(lg_ffn0_ln_gelu_kernel, dim3((unsigned)groups < res ? (unsigned)groups : res), dim3(THREADS), 0, st, a, g, be);
-    if (hipGetLastError() != hipSuccess) return -1;
-  } else {
-    if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
-    {
-      EINX_PROF("lg_ln_gelu_kernel", st);
-      hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
-    }
-    if (hipGetLastError() != hipSuccess) return -1;
+  // (one fused launch for ffn.0 + LayerNorm + GELU was measured in round 3 and is slower: tools/experiments/lg_ffn0_ln_gelu_kernel.hip.txt)
+  if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
+  {
+    EINX_PROF("lg_ln_gelu_kernel", st);
+    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
   }
+  if (hipGetLastError() != hipSuccess) return -1;
   return gemm(st, EPI_RESID, s, B, s.h, 2 * D, nullptr, 0, 0x7fffffff, 2 * D, w3, b3, D, s.x, D);
 }
 
@@ -1067,8 +909,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   char* p = (char*)ws;
   // equal capacities (every shipped configuration): the two sides are stacked and every layer runs ONCE over 2B entries --
   // half the launches, and at small batch twice the workgroups per launch (a single pair: 8.0 -> see profiles/r03_notes.md)
-  static const bool no_stack = getenv("EINX_LG_NO_STACK") != nullptr;
-  const bool stacked = cap0 == cap1 && !no_stack;
+  const bool stacked = cap0 == cap1;
   Side sb{};
   if (stacked) {
     p = carve_stacked(s0, s1, p, B, cap0);

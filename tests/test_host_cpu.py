@@ -215,7 +215,7 @@ def test_nms_pass_budget_grows_and_decays(monkeypatch):
 
 def test_feats_dict_resolves_lazy_entries_on_every_read_path():
     """_extract.FeatsDict (dense outputs on demand): a lazy entry is computed once, by whichever read reaches it first --
-    d[k], get, items, values, pop, setdefault, copy, and CPython's own merges dict(d) / {**d} / other.update(d)."""
+    d[k], get, items, values, pop, popitem, setdefault, copy, `|`, `==`, and CPython's own merges dict(d) / {**d} / other.update(d)."""
     import importlib
     ex = importlib.import_module(pkg.__name__ + "._extract")
 
@@ -229,7 +229,11 @@ def test_feats_dict_resolves_lazy_entries_on_every_read_path():
     for read in (lambda d: d["normalized_descriptors"], lambda d: d.get("normalized_descriptors"), lambda d: dict(d.items())["normalized_descriptors"],
                  lambda d: list(d.values())[1], lambda d: d.pop("normalized_descriptors"), lambda d: d.setdefault("normalized_descriptors", 7),
                  lambda d: d.copy()["normalized_descriptors"], lambda d: dict(d)["normalized_descriptors"], lambda d: {**d}["normalized_descriptors"],
-                 lambda d: (lambda o: (o.update(d), o)[1])({})["normalized_descriptors"]):
+                 lambda d: (lambda o: (o.update(d), o)[1])({})["normalized_descriptors"],
+                 # the remaining dict entry points no longer leak the sentinel
+                 lambda d: d.popitem()[1], lambda d: (d | {"x": 0})["normalized_descriptors"], lambda d: ({"x": 0} | d)["normalized_descriptors"],
+                 lambda d: 42 if d == {"score": 1, "normalized_descriptors": 42} else None,
+                 lambda d: 42 if not (d != {"score": 1, "normalized_descriptors": 42}) else None):
         d, calls = fresh()
         assert sorted(d.keys()) == ["normalized_descriptors", "score"] and "normalized_descriptors" in d and len(d) == 2
         assert d.lazy_keys() == ["normalized_descriptors"] and calls == []

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-pair latency of EIM.forward (the reference's own call pattern, test_events-image_same-time.py:130-194):
 wall time per forward, host enqueue time (forward_batched returns before the device is done) and device time.
-    python tools/latency_b1.py [B [SP_MNN|SP_LG|SiLK_MNN|SiLK_LG]]          (EINX_OP_LEVEL=1: layer-by-layer op-level ABI instead of einx_extract)"""
+    python tools/latency_b1.py [B [SP_MNN|SP_LG|SiLK_MNN|SiLK_LG]]"""
 import importlib
 import os
 import sys
@@ -58,7 +58,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     dev_ms = e0.elapsed_time(e1) / n
-    mode = "op-level ABI" if os.environ.get("EINX_OP_LEVEL") == "1" else "einx_extract (handle-level ABI)"
+    mode = "einx_extract (handle-level ABI)"
     print(f"B={B} {name} {mode}: forward wall {t_wall / n * 1e3:.3f} ms, host enqueue {t_enq / n * 1e3:.3f} ms, "
           f"back-to-back device+enqueue {dev_ms:.3f} ms per forward, overlap={model.overlap_extractors}")
 
