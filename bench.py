@@ -770,7 +770,7 @@ def cpu_baseline_and_verify(wl, args, gpu_out):
     nb = max(1, min(nb, B))
     et, it = cfg.event_extractor.type, cfg.image_extractor.type
     escale, iscale = cfg.event_extractor[et].descriptor_scale_factor, cfg.image_extractor[it].descriptor_scale_factor
-    passes = 2 if (wl.config == "sp_mnn" and not args.cpu_pairs) else 1  # the headline sample: ~10-20 s of host work
+    passes = 4 if (wl.config == "sp_mnn" and not args.cpu_pairs) else 1  # the headline sample: ~10-20 s of host work (128 pairs at 16 threads)
     tc = time.perf_counter()
     for _ in range(passes):
         oe = orc.extractor_forward(et, wl.sub("event_extractor.extractor."), wl.ev_np[:nb].copy(), wl.mask_np[:nb], top_k=1024, scale=escale)
