@@ -1008,7 +1008,7 @@ EINX_EXPORT int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, 
         // thin first layers (1 / 5 input channels): stage only the channel pairs that exist
         if (d->cin <= 2) launch<3, 8, 32, 2, 4, 1, 2, 2, false>(a, B, s);
         else if (d->cin <= 6) launch<3, 8, 32, 2, 4, 1, 2, 6, false>(a, B, s);
-        else launch<3, 8, 32, 2, 4, 1, 2, 8, false>(a, B, s);  // (the three-per-CU form of the un-pooled tile spills at 80 registers)
+        else launch<3, 8, 32, 2, 4, 1, 2, 8, false, true>(a, B, s);
         break;
       case 1: launch<3, 12, 16, 2, 2, 1, 3, 8, false>(a, B, s); break;
       case 2: launch<3, 22, 8, 2, 2, 1, 3, 8, false>(a, B, s); break;
