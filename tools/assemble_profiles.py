@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 PR = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def last_json_line(path):
@@ -83,7 +83,7 @@ def main():
     k1b = [k for k in fetch if "conv_block_kernel<3, 8, 32, 2, 4, 1, 2, 8, true" in k][0]
     k1a = [k for k in fetch if "conv_block_kernel<3, 8, 32, 2, 4, 1, 2, 2, false" in k][0]
     fk, wk = fetch[k1b]["FETCH_SIZE"], write[k1b]["WRITE_SIZE"]
-    out["kernel"] = "conv_block_kernel<3,8,32,2,4,1,2,8,true,true> (conv1b 64->64 @264x352, B=32)"
+    out["kernel"] = "conv_block_kernel<3,8,32,2,4,1,2,8,true> (3 per CU) (conv1b 64->64 @264x352, B=32)"
     out["FETCH_SIZE_KB"] = sum(fk) / len(fk)
     out["WRITE_SIZE_KB"] = sum(wk) / len(wk)
     out["launches_averaged"] = len(fk)
@@ -216,7 +216,7 @@ def write_readme(pmc, busy):
             else:
                 A(f"| {st['stage']} | | | | {json.dumps(st.get('kernels_ms'))} |")
     A("")
-    A("## Dominant kernel: `conv_block_kernel<3,8,32,2,4,1,2,8,true,true>` (conv1b, 64->64 3x3 @264x352 + ReLU + 2x2 max-pool, B=32)")
+    A("## Dominant kernel: `conv_block_kernel<3,8,32,2,4,1,2,8,true>` (three workgroups per CU; conv1b, 64->64 3x3 @264x352 + ReLU + 2x2 max-pool, B=32)")
     A("")
     A(f"* algorithmic work per launch: {flop / 1e9:.1f} GFLOP (2 x 64 x 64 x 9 x 264 x 352 x 32); algorithmic bytes {pmc['algorithmic_bytes_per_launch'] / 1e6:.1f} MB.")
     A(f"* `roofline` in the bench line (mean of {rf.get('launches_timed', 10)} per-launch HIP-event pairs on the launch stream): {rf['launch_ms']:.3f} ms -> "
