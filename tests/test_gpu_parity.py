@@ -85,6 +85,26 @@ def test_conv_block_bit_exact(oracle, shape):
     assert np.array_equal(_np(got), exp)
 
 
+@pytest.mark.parametrize("pool", [True, False])
+def test_conv_block_three_per_cu_instantiation_bit_exact(oracle, pool):
+    """Round 5: launches of at least eight rounds of the 8x32 tiles (>= 6144 workgroups) take the instantiation that fits three
+    workgroups per CU (<= 80 registers; the un-pooled one spills three dwords).  256 small images reach that count."""
+    B, cin, cout, H, W = 256, 8, 64, 64, 96
+    x = synth.normalish(77, (B, cin, H, W))
+    w = synth.synth_param("c.weight", (cout, cin, 3, 3), 78)
+    b = synth.uniform(79, (cout,), -0.5, 0.5)
+    g, be = synth.uniform(80, (cout,), 0.5, 1.5), synth.uniform(81, (cout,), -0.3, 0.3)
+    mu, var = synth.uniform(82, (cout,), -0.3, 0.3), synth.uniform(83, (cout,), 0.5, 1.5)
+    g[3] = -g[3]
+    scale, shift = oracle.bn_fold(g, be, mu, var)
+    exp = oracle.conv_block(x, w, b, scale, shift, relu=True, pool=pool)
+    layer = pkg.native.ConvLayer(_t(w), _t(b), (_t(g), _t(be), _t(mu), _t(var), 1e-5), relu=True, pool=pool)
+    got = layer(_t(x))
+    name = pkg.native.lib().einx_conv_last_kernel().decode()
+    assert name == f"conv_block_kernel<3,8,32,2,4,1,2,8,{'true' if pool else 'false'}> (3 per CU)", name
+    assert np.array_equal(_np(got), exp)
+
+
 CONV16_SHAPES = [
     # B, cin, cout, H, W, relu, bn, pool, expected N-tiles per wave
     (1, 128, 128, 33, 44, True, True, False, 1),   # the single-pair 33x44 layers
