@@ -15,6 +15,14 @@ from .Matchers import Matcher
 from .matchers._batched import full_batch_lists
 
 
+def _or_all(values):
+    """bitwise OR of a list of Python ints (the per-image flag words of one read-back row)"""
+    acc = 0
+    for v in values:
+        acc |= v
+    return acc
+
+
 class EIM(nn.Module):
     def __init__(self, config, device="cuda", logger=None):
         super().__init__()
@@ -105,11 +113,25 @@ class EIM(nn.Module):
             p["det_event"] = torch.cuda.Event()
             p["det_event"].record()
 
-        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=read_detection, prepared=prepared)
+        # graph mode waits for the whole stream anyway: ONE gather + ONE copy node at the end instead of the early detection
+        # read-back (which lets `forward` build the feature lists while the matcher still runs) and the match-count read-back
+        one_readback = slot == "g"
+        ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=None if one_readback else read_detection,
+                                          prepared=prepared)
         p["ev"], p["im"], p["mr"] = ev, im, mr
         p["args"] = (events, image, events_mask, image_mask)
         p["nm_event"] = None
-        if mr is not None:
+        if one_readback:
+            parts = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
+            if mr is not None:
+                parts += [mr.nmatch] + ([] if getattr(mr, "stale", None) is None else [mr.stale])
+            rows = torch.cat(parts)
+            host = self._pinned(f"all{slot}", (int(rows.shape[0]),)).copy_(rows, non_blocking=True)
+            p["det_host"], p["det_event"] = host[:4 * B].view(4, B), torch.cuda.Event()
+            if mr is not None:
+                p["nm_host"] = host[4 * B:]
+            p["det_event"].record()
+        elif mr is not None:
             nm = mr.nmatch if getattr(mr, "stale", None) is None else torch.cat([mr.nmatch, mr.stale])  # + the matcher's weight watch
             p["nm_host"] = self._pinned(f"nmatch{slot}", (int(nm.shape[0]),)).copy_(nm, non_blocking=True)
             p["nm_event"] = torch.cuda.Event()
@@ -125,14 +147,19 @@ class EIM(nn.Module):
         ev, im, mr, pre = p["ev"], p["im"], p["mr"], p["pre"]
         if p["det_event"] is not None:  # None: graph mode, the stream has been synchronised
             p["det_event"].synchronize()
-        host = p["det_host"]
+        # (the pinned rows are read with ONE tolist() each and tested in Python: every torch operator on a 4 x B host tensor costs
+        # 2-4 us, a dozen of them were a tenth of a single-pair forward_graph call)
+        host = p.get("det_rows") or p["det_host"].tolist()
+        B = len(host[0])
         nm_host, nm_event = p.get("nm_host"), p["nm_event"]
-        stale = bool(((host[2] | host[3]) & 2).any())
+        flags_ev, flags_im = _or_all(host[2]), _or_all(host[3])
+        stale = bool((flags_ev | flags_im) & 2)
         if not stale and mr is not None and getattr(mr, "stale", None) is not None:
             if nm_event is not None:
                 nm_event.synchronize()
                 nm_event = None
-            stale = bool(nm_host[host.shape[1]:].any())
+            nm_host = nm_host.tolist()
+            stale = any(nm_host[B:])
         if stale:
             # a weight was edited through `.data` after the native images were built (the reference's modules would simply use
             # the new values): rebuild the images of all three modules and run this forward again.  SuperPointv1's in-place
@@ -145,42 +172,43 @@ class EIM(nn.Module):
                     mod.refresh()
             self.reset_graphs()
             return self._finish(self._enqueue(*p["args"], slot=p["slot"], prepared=True), _rerun=True)
-        if mr is not None and getattr(mr, "stale", None) is not None and nm_host is not None:
-            nm_host = nm_host[:host.shape[1]]
         retries = 0
-        while bool((host[2] & 1).any()) or bool((host[3] & 1).any()):
+        while (flags_ev | flags_im) & 1:
             retries += 1
             if retries > 8:  # 8 * 4**8 passes: cannot happen on a finite map (each pass removes at least one pixel or stops)
                 raise RuntimeError("einx: the NMS fix-point did not converge within the maximum pass budget")
             # the NMS fix-point of some image needed more passes than were enqueued: redo only the
             # detection tail (and the matcher) with a larger, remembered, pass budget (rare: blocking read-back)
-            for flag, bf, wrapper in ((bool((host[2] & 1).any()), ev, self.event_extractor), (bool((host[3] & 1).any()), im, self.image_extractor)):
-                if flag:
+            for flags, bf, wrapper in ((flags_ev, ev, self.event_extractor), (flags_im, im, self.image_extractor)):
+                if flags & 1:
                     eng = wrapper.extractor.engine()
                     eng.redetect(bf, eng.grow_nms_iters())
             if mr is not None:
                 mr = self.matcher.match_batched(ev, im)
                 pre = None
-            host = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]).cpu()
+            host = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]).tolist()
+            flags_ev, flags_im = _or_all(host[2]), _or_all(host[3])
             if mr is not None:
-                nm_host = mr.nmatch.cpu()
+                nm_host = mr.nmatch.tolist()
                 nm_event = None
         if retries == 0:
             for wrapper in (self.event_extractor, self.image_extractor):
                 eng = getattr(wrapper.extractor, "_engine", None)
                 if eng is not None:
                     eng.note_converged()
-        n, m = host[0].tolist(), host[1].tolist()
+        n, m = host[0], host[1]
         events_feats = ev.materialize(n)
         image_feats = im.materialize(m)
         if nm_event is not None:
             nm_event.synchronize()
+        if nm_host is not None and not isinstance(nm_host, list):
+            nm_host = nm_host.tolist()
         self._last_match = mr  # device-side MatchResult of this call (consumed by core.metrics batch_metrics)
         matches = None
         if mr is not None:
             n = [min(v, ev.det.cap) for v in n]
             m = [min(v, im.det.cap) for v in m]
-            matches = self.matcher.materialize(mr, n, m, nm_host.tolist(), prebuilt=pre)
+            matches = self.matcher.materialize(mr, n, m, nm_host[:B], prebuilt=pre)
         elif self.matcher.matcher is not None:
             # un-frozen matcher (EIM.py:92-95 -> Matchers.py:204-222): random padding to max_points_num and
             # one stacked call; like the reference it rewrites sparse_positions / sparse_descriptors of
@@ -218,9 +246,9 @@ class EIM(nn.Module):
           * dicts returned by EARLIER calls alias the buffers the next replay overwrites -- their tensors, and their unresolved
             lazy entries (`normalized_descriptors`, `dense_*`), which would then be computed from the newer data: read or clone
             what must survive before the next call."""
-        key = (tuple(events.shape), tuple(image.shape), None if events_mask is None else tuple(events_mask.shape),
-               None if image_mask is None else tuple(image_mask.shape), str(events.device),
-               tuple(None if t is None else str(t.dtype) for t in (events, image, events_mask, image_mask)), self._graph_config())
+        key = (events.shape, image.shape, None if events_mask is None else events_mask.shape,
+               None if image_mask is None else image_mask.shape, events.device, events.dtype, image.dtype,
+               None if events_mask is None else events_mask.dtype, None if image_mask is None else image_mask.dtype, self._graph_config())
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
         if g is None:
@@ -232,15 +260,16 @@ class EIM(nn.Module):
         g["graph"].replay()
         cur.synchronize()
         p = g["p"]
-        host = p["det_host"]
-        if bool(((host[2] | host[3]) & 1).any()):
+        rows = p["det_host"].tolist()
+        if (_or_all(rows[2]) | _or_all(rows[3])) & 1:
             # rare: the captured NMS pass budget was exceeded.  `_finish` redoes the detection tail and the matcher eagerly with
             # a larger, remembered budget on the graph's buffers (the replay has already scaled its own copy of the image);
             # this graph keeps the old budget, so it is dropped and the next call captures afresh
             graphs.pop(key, None)
         for bf, tmpl in ((p["ev"], g["prep_ev"]), (p["im"], g["prep_im"])):
             bf.reuse_prepared(tmpl)
-        return self._finish(dict(p, det_event=None, nm_event=None))
+        finish = self._finish if events.device.index not in (None, torch.cuda.current_device()) else EIM._finish.__wrapped__.__get__(self)
+        return finish(dict(p, det_event=None, nm_event=None, det_rows=rows))
 
     def reset_graphs(self):
         self.__dict__.pop("_graphs", None)

@@ -96,31 +96,35 @@ __device__ __forceinline__ void tile_nt_run(const Src& cur, int K, int Ksplit, f
   // advances with k0 (scalar registers) plus a per-thread element offset that never changes, so a
   // K-slab costs the loads themselves and no vector address arithmetic, compares or selects.
   const bool whole = cur.i0 + BM <= cur.Mvalid && cur.j0 + BN <= cur.Nvalid && K % BK == 0 && (cur.A2 == nullptr || Ksplit % BK == 0);
+  // byte offsets of this thread's float4s from the tile's first element (constant over the K loop); the K position is stepped in
+  // the wave-uniform buffer descriptor's base (scalar ALU): a slab's loads are `buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`
+  // with no vector address arithmetic at all (round 5: vector instructions displace fp32 MFMA issue, profiles/r05_notes.md 1)
   unsigned offa[STAGE], offa2[STAGE], offb[STAGE];
 #pragma unroll
   for (int i = 0; i < STAGE; ++i) {
     const int fidx = tid + i * THREADS;
     const int r = fidx / C4, c4 = fidx % C4;
-    offa[i] = (unsigned)(r * cur.lda + c4 * 4);
-    offa2[i] = (unsigned)(r * cur.lda2 + c4 * 4);
-    offb[i] = (unsigned)(r * cur.ldb + c4 * 4);
+    offa[i] = (unsigned)(r * cur.lda + c4 * 4) * 4u;
+    offa2[i] = (unsigned)(r * cur.lda2 + c4 * 4) * 4u;
+    offb[i] = (unsigned)(r * cur.ldb + c4 * 4) * 4u;
   }
   const float* a_tile = cur.A + (size_t)cur.i0 * cur.lda;
   const float* a2_tile = cur.A2 ? cur.A2 + (size_t)cur.i0 * cur.lda2 : nullptr;
   const float* b_tile = cur.B + (size_t)cur.j0 * cur.ldb;
+  auto rsrc = [](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7FFFFFFF, 0x00020000); };  // whole tiles: every offset is in range
   auto issue_whole = [&](int k) {
-    const float* bk = b_tile + k;
+    const __amdgpu_buffer_rsrc_t rb = rsrc(b_tile + k);
     if (k < Ksplit) {
-      const float* ak = a_tile + k;
+      const __amdgpu_buffer_rsrc_t ra = rsrc(a_tile + k);
 #pragma unroll
-      for (int i = 0; i < STAGE; ++i) st.ra[i] = *reinterpret_cast<const f32x4*>(ak + offa[i]);
+      for (int i = 0; i < STAGE; ++i) st.ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, offa[i], 0, 0));
     } else {
-      const float* ak = a2_tile + (k - Ksplit);
+      const __amdgpu_buffer_rsrc_t ra = rsrc(a2_tile + (k - Ksplit));
 #pragma unroll
-      for (int i = 0; i < STAGE; ++i) st.ra[i] = *reinterpret_cast<const f32x4*>(ak + offa2[i]);
+      for (int i = 0; i < STAGE; ++i) st.ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, offa2[i], 0, 0));
     }
 #pragma unroll
-    for (int i = 0; i < STAGE; ++i) st.rb[i] = *reinterpret_cast<const f32x4*>(bk + offb[i]);
+    for (int i = 0; i < STAGE; ++i) st.rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, offb[i], 0, 0));
   };
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();  // the previous slab's (or tile's) fragment reads are done

@@ -78,11 +78,24 @@ def effective_cpus(sys_root="/sys"):
     return max(1, n)
 
 
+def pool_threads(sys_root="/sys"):
+    """Default size of the CPU math libraries' pools: effective_cpus() minus two when the limit is a cgroup quota.  The quota is
+    bandwidth, not cores: a pool of exactly quota threads that spin-wait after a parallel region plus the Python thread and the
+    HIP runtime's helper threads still overdraws it, and the container is frozen for the rest of the period (measured on a
+    16-CPU quota: pools of 16 -> 3 throttled periods and 6-8 ms hiccups in 160 forwards, pools of 14 -> none;
+    tools/experiments/r5_stall_hunt5.py, profiles/r05_notes.md 2)."""
+    n = effective_cpus(sys_root)
+    q = cgroup_cpu_quota(sys_root)
+    if q is not None and n >= 4 and n >= int(q):
+        n -= 2
+    return max(1, n)
+
+
 def cap_thread_pools(n=None):
     """Size the CPU math libraries' pools (OpenMP / MKL / OpenBLAS: torch's CPU operators, numpy) to `n` threads (default:
-    effective_cpus()) through their environment variables -- call before they are imported.  Existing settings are kept when
+    pool_threads()) through their environment variables -- call before they are imported.  Existing settings are kept when
     they are not larger."""
-    n = effective_cpus() if n is None else max(1, int(n))
+    n = pool_threads() if n is None else max(1, int(n))
     for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         cur = os.environ.get(var)
         if not (cur and cur.isdigit() and 0 < int(cur) <= n):
@@ -168,8 +181,9 @@ def plan(local_rank, world, allowed=None, sys_root="/sys"):
     phys = len({_core_of(c, sys_root) for c in cpus})
     threads = max(1, phys)
     quota = cgroup_cpu_quota(sys_root)
-    if quota is not None:  # the ranks of this host share the cgroup's CPU bandwidth
-        threads = max(1, min(threads, int(quota) // world))
+    if quota is not None:  # the ranks of this host share the cgroup's CPU bandwidth; two CPUs' worth stays free per rank (pool_threads)
+        share = int(quota) // world
+        threads = max(1, min(threads, share - 2 if share >= 4 else share))
     return {"gpu": int(local_rank), "numa_node": int(my_node), "cpus": format_cpulist(cpus), "n_cpus": len(cpus), "physical_cores": phys,
             "threads": threads, "cgroup_cpu_quota": quota, "source": source}
 

@@ -164,6 +164,19 @@ def test_placement_plan_follows_the_gpu_numa_nodes(tmp_path):
     assert set(plc.parse_cpulist(p["cpus"])) <= {0, 1, 2, 3, 4, 5, 16, 17}
     q = [plc.plan(g, 4, allowed=list(range(8)), sys_root=str(tmp_path / "nothing")) for g in range(4)]
     assert [x["cpus"] for x in q] == ["0-1", "2-3", "4-5", "6-7"] and all(x["numa_node"] == -1 for x in q)
+    # a cgroup CPU quota is bandwidth shared by the ranks: each pool is sized to its share minus two CPUs' worth (the Python thread
+    # and the HIP runtime's helpers run beside the pool; at exactly the quota the container still gets throttled -- round 5)
+    (root / "fs/cgroup").mkdir(parents=True)
+    (root / "fs/cgroup/cpu.max").write_text("1600000 100000\n")
+    assert plc.cgroup_cpu_quota(str(root)) == 16.0
+    assert [plc.plan(g, 4, allowed=list(range(ncpu)), sys_root=str(root))["threads"] for g in range(4)] == [2, 2, 2, 2]  # share 4 -> 2
+    assert plc.plan(0, 1, allowed=list(range(ncpu)), sys_root=str(root))["threads"] == 8  # one rank: its node's 8 cores < 16 - 2
+    (root / "fs/cgroup/cpu.max").write_text("800000 100000\n")
+    assert plc.plan(0, 1, allowed=list(range(ncpu)), sys_root=str(root))["threads"] == 6  # 8 cores, quota 8 -> 6
+    (root / "fs/cgroup/cpu.max").write_text("1600000 100000\n")
+    assert plc.pool_threads(str(root)) == min(len(os.sched_getaffinity(0)), 16) - (2 if len(os.sched_getaffinity(0)) >= 16 else 0)
+    (root / "fs/cgroup/cpu.max").write_text("max 100000\n")
+    assert plc.cgroup_cpu_quota(str(root)) is None and plc.pool_threads(str(root)) == plc.effective_cpus(str(root))
 
 
 def test_dead_rank_at_world_8_stops_the_others_quickly():
