@@ -444,10 +444,16 @@ def linear(x, w, bias, out=None, accumulate=False):
     return y
 
 
+WATCH_CHUNK_WORDS = 4096  # include/einx.h: EINX_WATCH_CHUNK_WORDS
+
+
 class ParamWatch:
     """Device-side content watch of a module's fp32 parameters / buffers (einx_params_hash): `.data` edits, which no host-side
-    version counter sees, raise `stale` at the next forward.  Built when the module packs its weights; `check()` enqueues one
-    small launch on the current stream; the flag travels to the host with the counts the forward reads back anyway."""
+    version counter sees, raise `stale` at the next forward.  Exact since round 5: EVERY word is hashed (round 4 sampled 65 per
+    tensor), tensors cut into rows of 4096 words, one wave per row -- 1.3 M extractor weights are 380 rows riding on spare
+    workgroups of the descriptor sampling kernel, LightGlue's 12 M one 10 us launch.  Built when the module packs its weights;
+    `check()` enqueues one small launch on the current stream; the flag travels to the host with the counts the forward reads
+    back anyway."""
 
     def __init__(self, tensors):
         ts = [t.detach() for t in tensors if torch.is_tensor(t) and t.dtype == F32 and t.numel() > 0 and t.device.type == "cuda"
@@ -455,12 +461,13 @@ class ParamWatch:
         if os.environ.get("EINX_NO_WATCH") == "1":  # tools: A/B of the watch's cost
             ts = []
         self.keep = ts
-        self.n = len(ts)
         self.stale = None
-        if not ts:
+        rows = [[t.data_ptr() + 4 * off, min(WATCH_CHUNK_WORDS, t.numel() - off)] for t in ts for off in range(0, t.numel(), WATCH_CHUNK_WORDS)]
+        self.n = len(rows)
+        if not rows:
             return
         dev = ts[0].device
-        self.table = torch.tensor([[t.data_ptr(), t.numel()] for t in ts], dtype=torch.int64).to(dev)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.ref = torch.empty((self.n,), dtype=torch.int64, device=dev)
         self.scratch = torch.empty((self.n,), dtype=torch.int64, device=dev)
         self.stale = torch.zeros((1,), dtype=torch.int32, device=dev)

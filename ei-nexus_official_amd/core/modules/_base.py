@@ -54,11 +54,11 @@ class NativeExtractor(nn.Module):
     def _signature(self):
         """(storage, version) of every parameter and buffer: in-place edits made THROUGH the parameter (`with no_grad():
         p.add_(..)` / `p.copy_(..)`, optimiser steps, `load_state_dict`) bump `p._version`, `.to()` changes the storage.
-        NOT detected HERE: edits through `p.data` (`p.data.copy_(w)`, `p.data.mul_(..)`): `.data` is an alias with its OWN
-        version counter, so `p._version` stays put.  Those are caught by the device-side content watch instead (round 4:
-        65 sampled words per tensor, checked by every forward, which then rebuilds the images and runs again) -- as long as
-        the edit touches a sampled word: dense edits always do, a single-element patch may not, and REPLACING a Parameter
-        object is invisible to both; `refresh()` covers those (tests/test_host_cpu.py::test_data_alias_edits_need_refresh,
+        NOT detected HERE: edits through `p.data` (`p.data.copy_(w)`, `p.data.mul_(..)`, `p.data[i, j] = v`): `.data` is an alias
+        with its OWN version counter, so `p._version` stays put.  Those are caught by the device-side content watch instead
+        (round 5: a hash over EVERY word of every fp32 parameter / buffer, checked by every forward, which then rebuilds the
+        images and runs again).  REPLACING a Parameter object is invisible to both (the watch holds the old storage);
+        `refresh()` covers that (tests/test_host_cpu.py::test_data_alias_edits_need_refresh,
         tests/test_r4_gpu.py::test_data_edits_of_weights_take_effect_at_the_next_forward).  The flat tensor list is cached (walking the module
         tree costs 50-450 us per call); `_apply`, `load_state_dict` and `refresh()` drop it."""
         ts = self._sig_tensors
@@ -67,10 +67,8 @@ class NativeExtractor(nn.Module):
         return tuple((t.data_ptr(), t._version) for t in ts)
 
     def refresh(self):
-        """Drop the kernel-native weight images.  Needed after REPLACING Parameter objects and after `.data` edits that the
-        content watch cannot see (it samples 65 words per tensor: dense edits such as `p.data.copy_(w)` / `p.data.mul_(..)` are
-        caught at the next forward, which rebuilds the images and runs again; a single-element edit may not be); harmless
-        otherwise (everything else is detected by `_signature`)."""
+        """Drop the kernel-native weight images.  Needed after REPLACING Parameter objects; harmless otherwise (in-place edits
+        are detected by `_signature`, `.data` edits -- down to a single element -- by the content watch at the next forward)."""
         self._engine = self._scale_host = self._sig_tensors = None
 
     def _layer(self, block, pool=False):

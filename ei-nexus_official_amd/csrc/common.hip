@@ -144,10 +144,10 @@ EINX_EXPORT int einx_div_inplace(float* x, size_t n, float divisor, void* stream
 // ------------------------------------------------------------------------------------------
 // Content watch of a module's weights (round 4).  The reference's modules are plain nn.Modules: an in-place edit of a
 // weight through `p.data` takes effect at the next forward.  Here weights are repacked / folded into kernel-native images,
-// and `.data` edits do not move the version counters the host-side cache keys on.  One 64-lane workgroup per tensor hashes
-// 64 evenly spread words + the last word of the tensor; mode "store" (ref == NULL) records the hashes at pack time, mode
-// "compare" raises *stale when a tensor's hash differs -- read back with the keypoint counts the forward fetches anyway.
-// Best effort by construction: an edit that leaves all 65 sampled words unchanged is not seen (refresh() remains).
+// and `.data` edits do not move the version counters the host-side cache keys on.  One 64-lane wave per table row hashes every
+// word of the row (einx_watch_tensor; the host cuts tensors into rows of EINX_WATCH_CHUNK_WORDS); mode "store" (ref == NULL)
+// records the hashes at pack time, mode "compare" raises *stale when a row's hash differs -- read back with the keypoint
+// counts the forward fetches anyway.  Exact since round 5 (round 4 sampled 65 words per tensor and missed sparse edits).
 // ------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(64) void params_hash_kernel(const EinxWatch w) { einx_watch_tensor(w, (int)blockIdx.x, (int)threadIdx.x); }

@@ -66,15 +66,39 @@ struct EinxWatch {
   int n, bit;
 };
 #ifdef __HIPCC__
+// one 64-lane wave hashes EVERY word of table row t (round 5; round 4 sampled 65 words per tensor).  Rows are chunks of at most
+// a few thousand words (the host cuts the tensors, einx.h: EINX_WATCH_CHUNK_WORDS), so the loads of a row are all in flight
+// at once.  term(word, position) = ((position << 32) + word) * odd constant is injective in (word, position); the wrap-around
+// sum over a row is order independent, so any edit of any word changes the row's hash (up to a 2^-64 cancellation).
 __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int lane) {
   const uint32_t* p = reinterpret_cast<const uint32_t*>((uintptr_t)w.table[2 * t]);
   const long long n = w.table[2 * t + 1];
+  constexpr unsigned long long MIX = 0x9E3779B97F4A7C15ull;
   unsigned long long h = 0;
-  if (n > 0) {
-    const long long i = (long long)lane * (n >> 6) + (((long long)lane * (n & 63)) >> 6);  // floor(lane * n / 64) without 128-bit arithmetic
-    h = (unsigned long long)p[i] * (2ull * (unsigned long long)lane + 1ull) * 0x9E3779B97F4A7C15ull;
-    if (lane == 63) h += (unsigned long long)p[n - 1] * 0xD1342543DE82EF95ull;
+  long long i0 = 0;
+  if ((((uintptr_t)p) & 15) == 0) {  // 16-byte loads, eight per lane in flight
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* p4 = reinterpret_cast<const u32x4*>(p);
+    const long long n4 = n >> 2;
+    for (long long j0 = 0; j0 < n4; j0 += 64 * 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long j = j0 + lane + 64 * u;
+        v[u] = p4[j < n4 ? j : n4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long j = j0 + lane + 64 * u;
+        if (j < n4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h += ((((unsigned long long)(4 * j + e)) << 32) + v[u][e]) * MIX;
+        }
+      }
+    }
+    i0 = n4 << 2;
   }
+  for (long long i = i0 + lane; i < n; i += 64) h += ((((unsigned long long)i) << 32) + p[i]) * MIX;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off, 64);  // wrap-around sum: order independent
   if (lane == 0) {

@@ -44,8 +44,12 @@ int einx_device_count(void);
 
 /* Content watch of a module's weights (the reference's nn.Modules see an in-place edit through `p.data` at the next forward,
  * torch/nn/modules/module.py semantics; here weights are repacked / folded at load time).  table: device [n][2] int64 =
- * (device pointer, number of 32-bit words) per tensor.  ref == stale == NULL: store the hashes (64 spread words + the last
- * word per tensor) in hash[n]; otherwise hash[n] is scratch and *stale (device int32) is OR-ed with 1 when any differs. */
+ * (device pointer, number of 32-bit words) per row.  Every word of a row is hashed (position-dependent, order-independent sum:
+ * any edit of any word changes the hash) by ONE 64-lane wave, so callers cut large tensors into rows of
+ * EINX_WATCH_CHUNK_WORDS words (any row length works; short rows keep a row's loads in flight together).
+ * ref == stale == NULL: store the hashes in hash[n]; otherwise hash[n] is scratch and *stale (device int32) is OR-ed with 1
+ * when any row's hash differs from ref. */
+#define EINX_WATCH_CHUNK_WORDS 4096
 int einx_params_hash(const int64_t* table, int n, uint64_t* hash, const uint64_t* ref, int32_t* stale, void* stream);
 
 /* Measurement aid (no reference counterpart; the reference's scripts time with wall clocks around

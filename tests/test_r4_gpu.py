@@ -182,7 +182,7 @@ def test_forward_graph_budget_fallback_stays_on_the_graphs_buffers():
 def test_data_edits_of_weights_take_effect_at_the_next_forward(cfg_name):
     """The reference's modules are plain nn.Modules: `p.data.mul_(..)` / `p.data.copy_(..)` change the next forward.  Here weights
     are repacked / folded into native images and no host-side version counter sees a `.data` edit; the device-side content watch
-    (einx_params_hash: 65 sampled words per tensor, read back with the counts) does, and the forward that notices rebuilds the
+    (einx_params_hash: every word hashed since round 5, read back with the counts) does, and the forward that notices rebuilds the
     images and runs again -- the result equals a model built from the edited weights."""
     from helpers import synth
     cfg = pkg.default_config(cfg_name, event_channels=5)

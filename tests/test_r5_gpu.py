@@ -139,3 +139,60 @@ def test_torch_free_c_abi_host_values_equal_the_oracle(oracle, tmp_path):
         n = len(oe["sparse_positions"][b])
         assert np.array_equal(m0[b, :n], em["matches0"])
         assert nmatch[b] == int((em["matches0"] > -1).sum())
+
+
+@pytest.mark.parametrize("cfg_name", ["SP_MNN", "SP_LG"])
+def test_single_element_data_edits_are_seen_by_the_weight_watch(cfg_name):
+    """Round 4's content watch hashed 65 sampled words per tensor: `p.data[i, j, ...] = v` at an unsampled position was silently
+    ignored.  The watch now hashes every word (one wave per 4096-word row): ONE edited element anywhere in a
+    convolution weight, a BatchNorm buffer or a LightGlue matrix -- at positions the old sampler provably skipped -- makes the next
+    forward rebuild the native images, and the result equals a model built from the edited weights."""
+    from helpers import synth
+    cfg = pkg.default_config(cfg_name, event_channels=5)
+
+    def build(sd):
+        m = pkg.EIM(cfg, device=DEV).eval()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return m
+
+    model0 = pkg.EIM(cfg, device=DEV)
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model0.state_dict().items()], seed=43)
+    model = build(sd)
+    ev, mask = synth.synth_events(61, 1, 5)
+    img = synth.synth_image(61, 1)
+    model(_t(ev), _t(img), _t(mask))
+    edits = ["event_extractor.extractor.backbone.l3.0.0.weight", "event_extractor.extractor.backbone.l2.1.2.running_var",
+             "image_extractor.extractor.conv4a.weight"]
+    if cfg_name == "SP_LG":
+        edits.append("matcher.matcher.transformers.5.cross_attn.to_out.weight")
+    tensors = dict(model.named_parameters())
+    tensors.update(dict(model.named_buffers()))
+    sd2 = dict(sd)
+    for k in edits:
+        n = sd[k].size
+        # round 4 sampled words floor(lane * n / 64) for lane = 0..63 and the last word: pick a flat index that is none of them
+        sampled = {(lane * n) // 64 for lane in range(64)} | {n - 1}
+        flat = next((i for i in range(n // 3, n) if i not in sampled), n // 2)  # (tensors of <= 64 words were covered entirely)
+        new = sd[k].copy().reshape(-1)
+        new[flat] = new[flat] * np.float32(-3.0) + np.float32(0.75)
+        new = new.reshape(sd[k].shape)
+        tensors[k].data.view(-1)[flat] = float(new.reshape(-1)[flat])  # one element, through the alias no version counter sees
+        sd2[k] = new
+    got = model(_t(ev), _t(img), _t(mask))
+    exp = build(sd2)(_t(ev), _t(img), _t(mask))
+    for side in (0, 1):
+        assert torch.equal(got[side]["sparse_positions"][0], exp[side]["sparse_positions"][0])
+        assert torch.equal(got[side]["sparse_descriptors"][0], exp[side]["sparse_descriptors"][0])
+        assert torch.equal(got[side]["raw_descriptors"], exp[side]["raw_descriptors"])
+    assert torch.equal(got[2]["matches0"][0], exp[2]["matches0"][0])
+    assert torch.equal(got[2]["matching_scores0"][0], exp[2]["matching_scores0"][0])
+    # each edit alone is noticed too (the images are current again after the forward above)
+    for k in edits:
+        t = tensors[k].data.view(-1)
+        flat = int(t.numel() // 2 + 1)
+        t[flat] = t[flat] + 0.5
+        a = model(_t(ev), _t(img), _t(mask))
+        sd2[k] = _np(tensors[k].data).copy()
+        e = build(sd2)(_t(ev), _t(img), _t(mask))
+        assert torch.equal(a[0]["raw_descriptors"], e[0]["raw_descriptors"]) and torch.equal(a[1]["raw_descriptors"], e[1]["raw_descriptors"]), k
+        assert torch.equal(a[2]["matching_scores0"][0], e[2]["matching_scores0"][0]), k

@@ -11,6 +11,7 @@ mkdir -p "$OUT" "$ROOT/ab_libs"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall -Wno-unused-function $*"
 for f in common conv detect desc mnn lightglue events metrics extract; do
   X=""; if [ $f = desc ]; then X="-fno-slp-vectorize"; fi  # as the Makefile
+  if [ $f = lightglue ]; then X="-mllvm -amdgpu-mfma-vgpr-form=1"; fi
   /opt/rocm/bin/hipcc $FLAGS $X -c "$SRC/$f.hip" -o "$OUT/$f.o" &
 done
 wait
