@@ -297,8 +297,19 @@ def write_readme(pmc, busy):
         A(f"## Per-variant conv counters (`{R}_pmc_conv_tiles.json`, `tools/experiments/r3_pmc_conv.sh` + `tools/pmc_tiles.py`)")
         A("")
         tj = json.load(open(tp))
-        A("| kernel variant | LDS conflicts / idx-active (plain pitch -> shipped) | MFMA busy (plain -> shipped) | effective MHz | mean us (profiled) |")
-        A("|---|---|---|---|---|")
+        if "kernels" in tj:  # round 5: one build, per kernel variant
+            A(tj.get("what", ""))
+            A("")
+            A(tj.get("reading", ""))
+            A("")
+            A("| kernel variant | MFMA busy | VALU / MFMA (incl. the MFMAs) | LDS / MFMA | effective MHz | mean us (profiled) |")
+            A("|---|---|---|---|---|---|")
+            for k, v in tj["kernels"].items():
+                A(f"| `{k}` | {v.get('mfma_busy_frac')} | {v.get('valu_per_mfma')} | {v.get('lds_per_mfma')} | {v.get('effective_mhz'):.0f} | {v.get('mean_us_per_launch_profiled')} |")
+            A("")
+            tj = {"conflict_free_pitch": {}, "plain_pitch": {}}
+        A("| kernel variant | LDS conflicts / idx-active (plain pitch -> shipped) | MFMA busy (plain -> shipped) | effective MHz | mean us (profiled) |") if tj["conflict_free_pitch"] else None
+        A("|---|---|---|---|---|") if tj["conflict_free_pitch"] else None
         for k, v in tj["conflict_free_pitch"].items():
             o = tj["plain_pitch"].get(k, {})
             A(f"| `{k}` | {o.get('lds_bank_conflict_per_idx_active')} -> {v.get('lds_bank_conflict_per_idx_active')} | {o.get('mfma_busy_frac')} -> "
