@@ -377,6 +377,7 @@ class ExtractorEngine:
         if det.cap > 8192:
             # unbounded-capacity configuration (no top-k or detection_threshold < 1): size the
             # descriptor buffer from the real counts (one extra sync, never on the default path)
+            bf.sized_from_counts = True  # (a host round trip: EIM.forward_graph refuses to capture this configuration)
             cmax = max(int(det.counts.max().item()), 1)
             det.positions = det.positions[:, :cmax].contiguous()
             det.indices = det.indices[:, :cmax].contiguous()

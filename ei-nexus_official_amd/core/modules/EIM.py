@@ -240,6 +240,9 @@ class EIM(nn.Module):
             are not touched, so the `/= 255` is never applied to them) and the graph is dropped: the next call captures a new
             one with the grown budget;
           * weights are read at replay time (edits through load_state_dict need a new capture: call `reset_graphs()`);
+          * configurations whose keypoint capacity is the whole map (no top-k, or a detection_threshold below 1: the forward then
+            sizes its descriptor buffer from the real counts, a host round trip) cannot be captured: NotImplementedError, use
+            `forward`;
           * one graph per input geometry, dtype AND configuration: the key holds every attribute that changes what is enqueued
             (`dense_outputs`, `want_log_assignment`, the detector settings, the matcher thresholds), so changing one of them
             captures a new graph instead of replaying the old configuration;
@@ -292,9 +295,15 @@ class EIM(nn.Module):
         with torch.cuda.stream(stream):
             for _ in range(3):  # builds the native weight images, the library's side streams / events for THIS stream, the pinned buffers
                 static[1].copy_(image)
-                self._finish(self._enqueue(*static, slot="g"))
+                warm = self._enqueue(*static, slot="g")
+                self._finish(warm)
             static[1].copy_(image)
         stream.synchronize()
+        if getattr(warm["ev"], "sized_from_counts", False) or getattr(warm["im"], "sized_from_counts", False):
+            # no top-k, or a detection_threshold below 1: the keypoint capacity is the whole map and the descriptor buffer is sized
+            # from the real counts -- a host round trip in the middle of the forward, which a captured graph cannot contain
+            raise NotImplementedError("einx: forward_graph needs a bounded keypoint capacity (detection_top_k set and detection_threshold >= 1, "
+                                      "the shipped configurations); use forward() for this configuration")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             p = self._enqueue(*static, slot="g")

@@ -94,7 +94,13 @@ class NativeExtractor(nn.Module):
             eng.desc_head = [self._layer(b) for b in desc]
             eng.watch = N.ParamWatch(self._sig_tensors)  # `.data` edits: seen by content (round 4, inside einx_extract), see refresh()
             self._engine = eng
-        return self._engine
+        # the reference's forward reads these attributes at every call (EventExtractors.py:545-556, superpoint_extractor.py:388-406):
+        # assigning `extractor.detection_top_k = 500` between two forwards takes effect at the next one (the native handle is
+        # keyed on them and rebuilt when one changes)
+        eng = self._engine
+        eng.top_k, eng.radius, eng.border = self.detection_top_k, self.nms_radius, self.remove_borders
+        eng.det_thr, eng.ordering = self.detection_threshold, self.ordering
+        return eng
 
     def _prepare_input(self, x):
         return x

@@ -157,7 +157,10 @@ __device__ __forceinline__ void vox_corner_add(const VoxSlab sb, const float4 r,
   const float xf = r.x, yf = r.y, tn = r.z, value = r.w;
   const int xl = (int)xf + dx, yl = (int)yf + dy, tl = (int)tn + dt;
   const float w = value * (1.0f - fabsf((float)xl - xf)) * (1.0f - fabsf((float)yl - yf)) * (1.0f - fabsf((float)tl - tn));
-  bool pend = in && xl >= sb.c_lo && xl < sb.c_hi && yl >= sb.r0 && yl < sb.r0 + sb.nr && yl >= 0 && tl >= 0 && tl < sb.bins && w != 0.0f;
+  // t_norm is NaN when all timestamps are equal (one event, or a burst with one time stamp: 0 / 0 in representations.py:76-80).
+  // torch's `.int()` turns NaN into INT_MIN on the CPU, so the reference's range mask drops every such event and the grid stays
+  // zero; v_cvt_i32_f32 turns NaN into 0, which would pass the range test and add NaN weights
+  bool pend = in && tn == tn && xl >= sb.c_lo && xl < sb.c_hi && yl >= sb.r0 && yl < sb.r0 + sb.nr && yl >= 0 && tl >= 0 && tl < sb.bins && w != 0.0f;
   const int cell = pend ? (tl * sb.rows + (yl - sb.r0)) * sb.W + xl : 0;
   const int h = cell & (VOX_TAGS - 1);
   volatile unsigned* tag = sb.tag;

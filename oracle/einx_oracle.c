@@ -893,6 +893,10 @@ EXPORT void orc_voxel_grid(const float* x, const float* y, const double* t, cons
           const float tn = ((float)(bins - 1) * (tf - tf0)) / (tfl - tf0);
           float value = p[i];
           if (value < 1.0f) value = -1.0f;
+          /* all timestamps equal (one event, one-stamp bursts): t_norm = 0 / 0 = NaN; torch's t_norm.int() is INT_MIN on the
+           * CPU, so the reference's mask (representations.py:94-101) drops the event -- stated here instead of relying on the
+           * undefined (int)NaN */
+          if (tn != tn) continue;
           const int xl = (int)x[i] + dx, yl = (int)y[i] + dy, tl = (int)tn + dt;
           if (xl < W && xl >= 0 && yl < H && yl >= 0 && tl >= 0 && tl < bins) {
             const float w = value * (1.0f - fabsf((float)xl - x[i])) * (1.0f - fabsf((float)yl - y[i])) * (1.0f - fabsf((float)tl - tn));

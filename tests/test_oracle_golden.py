@@ -460,3 +460,24 @@ def test_torch_cpu_pipeline_agrees_with_the_oracle(oracle):
             np.testing.assert_allclose(desc, exp[1], atol=1e-5)
         r = oracle.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
         assert nm[b] == int((r["matches0"] > -1).sum())
+
+
+def test_voxel_grid_degenerate_time_stamps_vs_reference(oracle):
+    """All time stamps equal (one event, a one-stamp burst): t_norm = 0 / 0 = NaN, the reference's range mask drops every event on
+    the CPU and the grid stays zero (tests/golden/gen_events_degenerate.py ran the reference); two stamps are the ordinary case."""
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "events_degenerate.npz"))
+    names = sorted({k.split(".")[0] for k in z.files if "." in k})
+    assert len(names) == 4
+    for name in names:
+        ev = {k: z[f"{name}.{k}"] for k in ("x", "y", "t", "p")}
+        size = tuple(int(v) for v in z[f"{name}.size"])
+        for norm in (0, 1):
+            exp = z[f"{name}.grid_norm{norm}"]
+            got = oracle.voxel_grid({k: v.copy() for k, v in ev.items()}, size, normalize=bool(norm))
+            if norm and name == "two_stamps":  # the statistics are reductions: 1e-5 like the other normalised fixtures
+                np.testing.assert_allclose(got, exp, atol=1e-5, rtol=1e-5)
+            else:
+                assert np.array_equal(got, exp), (name, norm)
+            assert (np.count_nonzero(exp) == 0) == (name != "two_stamps")

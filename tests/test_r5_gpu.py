@@ -196,3 +196,69 @@ def test_single_element_data_edits_are_seen_by_the_weight_watch(cfg_name):
         e = build(sd2)(_t(ev), _t(img), _t(mask))
         assert torch.equal(a[0]["raw_descriptors"], e[0]["raw_descriptors"]) and torch.equal(a[1]["raw_descriptors"], e[1]["raw_descriptors"]), k
         assert torch.equal(a[2]["matching_scores0"][0], e[2]["matching_scores0"][0]), k
+
+
+def test_voxel_grid_degenerate_time_stamps(oracle):
+    """Found by tools/fuzz_parity.py: with all time stamps equal t_norm is NaN; `v_cvt_i32_f32` maps NaN to bin 0 (in range), torch's
+    CPU `.int()` to INT_MIN (out of range) -- the kernel added NaN weights where the reference leaves the grid zero.  Now equal to the
+    reference-generated fixture and to the oracle, single events and one-stamp bursts, batched with an ordinary sample."""
+    from importlib import import_module
+    from helpers import GOLDEN
+    rep = import_module(pkg.__name__ + ".datasets.representations")
+    z = np.load(os.path.join(GOLDEN, "events_degenerate.npz"))
+    names = sorted({k.split(".")[0] for k in z.files if "." in k})
+    for name in names:
+        ev = {k: z[f"{name}.{k}"] for k in ("x", "y", "t", "p")}
+        size = tuple(int(v) for v in z[f"{name}.size"])
+        for norm in (False, True):
+            got = _np(rep.events_to_voxel_grid({k: v.copy() for k, v in ev.items()}, size, normalize=norm))
+            exp = z[f"{name}.grid_norm{int(norm)}"]
+            if norm and name == "two_stamps":  # the reference's mean / std are torch reductions: 1e-5, as for the other fixtures
+                np.testing.assert_allclose(got, exp, atol=1e-5, rtol=1e-5)
+            else:
+                assert np.array_equal(got, exp), (name, norm)
+            assert np.array_equal(got, oracle.voxel_grid(ev, size, normalize=norm))
+    # a degenerate sample next to an ordinary one in one batch
+    a = {k: z[f"burst_one_stamp.{k}"] for k in ("x", "y", "t", "p")}
+    b = {k: z[f"two_stamps.{k}"] for k in ("x", "y", "t", "p")}
+    size = tuple(int(v) for v in z["two_stamps.size"])
+    got = _np(rep.events_to_voxel_grid_batch([a, b, a], size, normalize=True))
+    assert np.count_nonzero(got[0]) == 0 and np.count_nonzero(got[2]) == 0
+    assert np.array_equal(got[1], oracle.voxel_grid(b, size, normalize=True))
+
+
+def test_detector_attributes_assigned_between_forwards_take_effect(oracle):
+    """Found by tools/fuzz_parity.py: the reference's extractors read `detection_top_k`, `nms_radius`, `remove_borders`,
+    `detection_threshold` and `ordering` in every forward (EventExtractors.py:545-556, superpoint_extractor.py:388-406), so assigning one
+    between two forwards changes the next; the native engine was built once from the values at the first forward and kept them.
+    It now follows the module's attributes at every call (the native handle is re-keyed)."""
+    from helpers import sub_dict, synth
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=47)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ev, mask = synth.synth_events(47, 2, 5, 120, 152)
+    img = synth.synth_image(47, 2, 120, 152)
+    esd, isd = sub_dict(sd, "event_extractor.extractor."), sub_dict(sd, "image_extractor.extractor.")
+    settings = [dict(top_k=1024, radius=4, border=4, det_thr=1.0, ordering="yx"), dict(top_k=37, radius=4, border=4, det_thr=1.0, ordering="yx"),
+                dict(top_k=37, radius=2, border=9, det_thr=1.0, ordering="xy"), dict(top_k=400, radius=0, border=0, det_thr=0.02, ordering="yx"),
+                dict(top_k=1024, radius=4, border=4, det_thr=1.0, ordering="yx")]
+    counts = []
+    for st in settings:
+        for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+            ext.detection_top_k, ext.nms_radius, ext.remove_borders = st["top_k"], st["radius"], st["border"]
+            ext.detection_threshold, ext.ordering = st["det_thr"], st["ordering"]
+        for fwd in (model.__call__, model.forward_graph):
+            if st["det_thr"] < 1.0 and fwd == model.forward_graph:  # capacity = the whole map: sized from the real counts, not capturable
+                with pytest.raises(NotImplementedError, match="bounded keypoint capacity"):
+                    fwd(_t(ev), _t(img.copy()), _t(mask))
+                continue
+            ef, imf, m = fwd(_t(ev), _t(img.copy()), _t(mask))
+            oe = oracle.extractor_forward("vgg", esd, ev.copy(), mask, **st)
+            oi = oracle.extractor_forward("superpointv1", isd, img.copy(), None, **st)
+            for got, exp in ((ef, oe), (imf, oi)):
+                for b in range(2):
+                    assert np.array_equal(_np(got["sparse_positions"][b]), exp["sparse_positions"][b]), st
+                    assert np.array_equal(_np(got["sparse_descriptors"][b]), exp["sparse_descriptors"][b]), st
+        counts.append(len(oe["sparse_positions"][0]))
+    assert counts[1] <= 37 < counts[0] and counts[-1] == counts[0]

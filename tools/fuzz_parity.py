@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign on the GPU box: random image sizes, batch sizes, detector settings, masks and keypoint counts
+through the drop-in (EIM.forward, the voxel grid, MNN thresholds) against the CPU oracle, bit for bit.  Every case is derived from
+one integer seed, printed on failure.    python tools/fuzz_parity.py [--seconds 300] [--seed0 1] [--family sp|silk|both]
+(test infrastructure: the oracle is the checker, never the product)"""
+import argparse, importlib, os, sys, time, traceback
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("ei-nexus_official_amd")
+from oracle import oracle as orc  # noqa: E402
+synth = pkg.synth
+DEV = "cuda:0"
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+n = lambda x: x.detach().cpu().numpy()  # noqa: E731
+sub = lambda sd, p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
+MODELS = {}
+
+
+def model_for(family, ce, top_k, radius, border, det_thr, ordering, seed):
+    key = (family, ce, seed % 3)
+    if key not in MODELS:
+        cfg = pkg.default_config("SP_MNN" if family == "sp" else "SiLK_MNN", event_channels=ce)
+        m = pkg.EIM(cfg, device=DEV).eval()
+        sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=100 + seed % 3)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        MODELS[key] = (m, sd)
+    m, sd = MODELS[key]
+    for ext in (m.event_extractor.extractor, m.image_extractor.extractor):
+        ext.detection_top_k, ext.nms_radius, ext.remove_borders = top_k, radius, border
+        ext.detection_threshold, ext.ordering = det_thr, ordering
+        ext.dense_outputs = False
+    return m, sd
+
+
+def one_case(seed, families):
+    r = np.random.default_rng(seed)
+    family = families[int(r.integers(len(families)))]
+    ce = int(r.choice([1, 3, 5, 8]))
+    B = int(r.choice([1, 1, 2, 3, 5]))
+    if family == "sp":
+        H, W = int(r.integers(24, 200)), int(r.integers(24, 260))
+    else:
+        H, W = int(r.integers(24, 90)), int(r.integers(24, 120))
+    top_k = int(r.choice([1, 7, 50, 300, 1024, 5000]))
+    radius = int(r.choice([0, 1, 2, 3, 4, 4, 4]))
+    border = int(r.choice([0, 1, 4, 4, 9]))
+    det_thr = float(r.choice([1.0, 1.0, 0.5, 0.02, 0.005]))
+    ordering = str(r.choice(["yx", "yx", "xy"]))
+    desc = f"seed {seed}: {family} ce={ce} B={B} {H}x{W} top_k={top_k} r={radius} border={border} thr={det_thr} {ordering}"
+    m, sd = model_for(family, ce, top_k, radius, border, det_thr, ordering, seed)
+    ev, mask = synth.synth_events(seed, B, ce, H, W)
+    mode = int(r.integers(4))
+    if mode == 1:
+        mask[:] = False  # nothing visible on the event side
+    elif mode == 2:
+        mask[:] = True
+    elif mode == 3:
+        mask[..., : W // 2] = False
+    img = synth.synth_image(seed + 1, B, H, W)
+    if r.integers(5) == 0:
+        img[:] = np.float32(r.integers(0, 255))  # flat image: every score ties
+    ef, imf, mt = m(t(ev), t(img.copy()), t(mask))
+    ek, ik = ("vgg", "superpointv1") if family == "sp" else ("vgg_np", "silk")
+    kw = dict(top_k=top_k, radius=radius, border=border, det_thr=det_thr, ordering=ordering)
+    es, is_ = (float(e.descriptor_scale_factor.detach()) for e in (m.event_extractor.extractor, m.image_extractor.extractor))
+    oe = orc.extractor_forward(ek, sub(sd, "event_extractor.extractor."), ev.copy(), mask, scale=es, **kw)
+    oi = orc.extractor_forward(ik, sub(sd, "image_extractor.extractor."), img.copy(), None, scale=is_, **kw)
+    for side, got, exp in (("event", ef, oe), ("image", imf, oi)):
+        for b in range(B):
+            for key in ("sparse_positions", "sparse_descriptors"):
+                g, e = n(got[key][b]), exp[key][b]
+                if g.shape != e.shape or not np.array_equal(g, e):
+                    raise AssertionError(f"{desc}: {side} {key}[{b}] differs (shapes {g.shape} vs {e.shape})")
+        for key in ("score", "nms", "logits", "raw_descriptors"):
+            g, e = n(got[key]), exp[key]
+            if g.shape != np.asarray(e).shape or not np.array_equal(g, e):
+                raise AssertionError(f"{desc}: {side} {key} differs")
+    for b in range(B):
+        e = orc.mnn(oe["sparse_descriptors"][b], oi["sparse_descriptors"][b], want_la=False)
+        g = n(mt["matches0"][b]).reshape(-1)
+        if not np.array_equal(g, np.asarray(e["matches0"]).reshape(-1)):
+            raise AssertionError(f"{desc}: matches0[{b}] differs")
+    return desc
+
+
+def voxel_case(seed):
+    from importlib import import_module
+    rep = import_module(pkg.__name__ + ".datasets.representations")
+    r = np.random.default_rng(seed)
+    bins = int(r.choice([1, 2, 3, 5, 10]))
+    H, W = int(r.integers(8, 300)), int(r.integers(8, 400))
+    nev = int(r.choice([1, 2, 17, 1000, 20000, 70000]))
+    norm = bool(r.integers(2))
+    desc = f"seed {seed}: voxel bins={bins} {H}x{W} events={nev} normalize={norm}"
+    x = (r.uniform(-2, W + 2, nev) if r.integers(2) else r.integers(-1, W + 1, nev)).astype(np.float32)
+    y = (r.uniform(-2, H + 2, nev) if r.integers(2) else r.integers(-1, H + 1, nev)).astype(np.float32)
+    if r.integers(3) == 0:  # a hot pixel: long same-voxel accumulation chains
+        hot = r.uniform(0, 1, nev) < 0.4
+        x = np.where(hot, np.float32(W // 2) + np.float32(0.5), x).astype(np.float32)
+        y = np.where(hot, np.float32(H // 3) + np.float32(0.25), y).astype(np.float32)
+    tt = 1.5e9 + np.sort(r.uniform(0, 0.1, nev))
+    p = (r.choice([-1.0, 1.0], nev) if r.integers(2) else r.choice([0.0, 1.0], nev)).astype(np.float32)
+    ev = {"x": x, "y": y, "t": tt, "p": p}
+    got = n(rep.events_to_voxel_grid(ev, (bins, H, W), normalize=norm))
+    exp = orc.voxel_grid(ev, (bins, H, W), normalize=norm)
+    if got.shape != exp.shape or not np.array_equal(got, exp, equal_nan=True):
+        raise AssertionError(f"{desc}: voxel grid differs ({np.abs(got - exp).max() if got.shape == exp.shape else 'shape'})")
+    gm = n(rep.events_mask(ev, (W, H))) if hasattr(rep, "events_mask") else None
+    if gm is not None and not np.array_equal(gm.astype(bool), orc.events_mask(ev, (W, H))):
+        raise AssertionError(f"{desc}: events mask differs")
+    return desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed0", type=int, default=1)
+    ap.add_argument("--family", default="both")
+    a = ap.parse_args()
+    fams = ["sp", "silk"] if a.family == "both" else [a.family]
+    t0, seed, ok, bad = time.time(), a.seed0, 0, []
+    last = t0
+    while time.time() - t0 < a.seconds:
+        try:
+            (voxel_case if seed % 4 == 0 else lambda s: one_case(s, fams))(seed)
+            ok += 1
+        except AssertionError as e:
+            bad.append(str(e))
+            print("MISMATCH", e, flush=True)
+        except Exception as e:  # an error path that the oracle does not share is a finding too
+            bad.append(f"seed {seed}: {type(e).__name__}: {e}")
+            print("ERROR seed", seed, type(e).__name__, e, flush=True)
+            traceback.print_exc()
+        seed += 1
+        if time.time() - last > 45:
+            last = time.time()
+            print(f"... {ok} cases equal, {len(bad)} findings, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz: {ok} cases bit-equal to the oracle, {len(bad)} findings, seeds {a.seed0}..{seed - 1}")
+    for b in bad[:40]:
+        print("  ", b)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
