@@ -1,0 +1,34 @@
+"""A fixed slice of the randomised differential campaigns (tools/fuzz_parity.py, tools/fuzz_ops.py) inside the GPU suite: every case is
+derived from its seed, so a failure names a reproducible input.  The open-ended runs (`--seconds N`) found two defects in round 5
+(detector attributes assigned between forwards were ignored; all-equal time stamps put NaN into the voxel grid) and then ran clean
+over 690 end-to-end and 100,000+ op-level cases."""
+import importlib.util
+import os
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _tool(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_end_to_end_seeds(oracle):
+    fz = _tool("fuzz_parity")
+    for seed in range(1, 41):
+        if seed % 4 == 0:
+            fz.voxel_case(seed)
+        else:
+            fz.one_case(seed, ["sp", "silk"])
+
+
+def test_op_level_seeds(oracle):
+    fz = _tool("fuzz_ops")
+    for seed in range(1, 241):
+        fz.CASES[seed % len(fz.CASES)](seed)
