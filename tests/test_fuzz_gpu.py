@@ -24,6 +24,8 @@ def test_end_to_end_seeds(oracle):
     for seed in range(1, 41):
         if seed % 4 == 0:
             fz.voxel_case(seed)
+        elif seed % 4 == 2:  # forward_graph / forward_stream / dense on demand / standalone wrappers == the eager forward
+            fz.modes_case(seed, ["sp", "silk"])
         else:
             fz.one_case(seed, ["sp", "silk"])
 

@@ -86,6 +86,86 @@ def one_case(seed, families):
     return desc
 
 
+def _same(a, b, path, desc):
+    """bit equality of two output structures (dicts / lists / tensors)"""
+    if isinstance(a, dict):
+        if sorted(a.keys()) != sorted(b.keys()):
+            raise AssertionError(f"{desc}: keys differ at {path}: {sorted(a.keys())} vs {sorted(b.keys())}")
+        for k in a.keys():
+            _same(a[k], b[k], f"{path}.{k}", desc)
+    elif isinstance(a, (list, tuple)):
+        if len(a) != len(b):
+            raise AssertionError(f"{desc}: lengths differ at {path}")
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]", desc)
+    elif torch.is_tensor(a):
+        if a.shape != b.shape or a.dtype != b.dtype or not torch.equal(a, b):
+            raise AssertionError(f"{desc}: {path} differs ({tuple(a.shape)} {a.dtype} vs {tuple(b.shape)} {b.dtype})")
+    elif a is None or b is None:
+        if a is not b:
+            raise AssertionError(f"{desc}: {path}: None vs value")
+    elif a != b:
+        raise AssertionError(f"{desc}: {path}: {a} vs {b}")
+
+
+def modes_case(seed, families):
+    """The other front doors against the eager forward, bit for bit: forward_graph (captured and replayed twice), forward_stream,
+    dense outputs computed in the forward vs on demand, the standalone extractor wrappers; dense maps vs the oracle."""
+    r = np.random.default_rng(seed)
+    family = families[int(r.integers(len(families)))]
+    ce = int(r.choice([1, 5]))
+    B = int(r.choice([1, 2, 3]))
+    H, W = (int(r.integers(24, 140)), int(r.integers(24, 180))) if family == "sp" else (int(r.integers(24, 70)), int(r.integers(24, 90)))
+    top_k = int(r.choice([7, 100, 1024]))
+    radius, border = int(r.choice([0, 2, 4])), int(r.choice([0, 4]))
+    ordering = str(r.choice(["yx", "xy"]))
+    desc = f"seed {seed}: modes {family} ce={ce} B={B} {H}x{W} top_k={top_k} r={radius} border={border} {ordering}"
+    m, sd = model_for(family, ce, top_k, radius, border, 1.0, ordering, seed)
+    ev, mask = synth.synth_events(seed, B, ce, H, W)
+    img = synth.synth_image(seed + 1, B, H, W)
+    use_mask = bool(r.integers(4))
+    args = lambda: (t(ev), t(img.copy()), t(mask) if use_mask else None)  # noqa: E731
+    ref = m(*args())
+    # graph mode: capture + two replays
+    for rep in range(2):
+        g = m.forward_graph(*args())
+        for i in range(3):
+            _same({k: v for k, v in g[i].items()}, {k: v for k, v in ref[i].items()}, f"graph[{rep}][{i}]", desc)
+    m.reset_graphs()
+    # stream mode
+    outs = list(m.forward_stream([args() for _ in range(3)], depth=2))
+    for j, o in enumerate(outs):
+        for i in range(3):
+            _same(dict(o[i].items()), dict(ref[i].items()), f"stream[{j}][{i}]", desc)
+    # dense outputs in the forward == on demand; and == the oracle's dense map
+    for ext in (m.event_extractor.extractor, m.image_extractor.extractor):
+        ext.dense_outputs = True
+    eager = m(*args())
+    for ext in (m.event_extractor.extractor, m.image_extractor.extractor):
+        ext.dense_outputs = "lazy"
+    lazy = m(*args())
+    for i in range(2):
+        for k in ("normalized_descriptors", "dense_descriptors", "dense_positions"):
+            _same(lazy[i][k], eager[i][k], f"lazy[{i}].{k}", desc)
+    ek, ik = ("vgg", "superpointv1") if family == "sp" else ("vgg_np", "silk")
+    kw = dict(top_k=top_k, radius=radius, border=border, det_thr=1.0, ordering=ordering, dense=True)
+    es, is_ = (float(e.descriptor_scale_factor.detach()) for e in (m.event_extractor.extractor, m.image_extractor.extractor))
+    oe = orc.extractor_forward(ek, sub(sd, "event_extractor.extractor."), ev.copy(), mask if use_mask else None, scale=es, **kw)
+    oi = orc.extractor_forward(ik, sub(sd, "image_extractor.extractor."), img.copy(), None, scale=is_, **kw)
+    for side, got, exp in (("event", eager[0], oe), ("image", eager[1], oi)):
+        if not np.array_equal(n(got["normalized_descriptors"]), exp["normalized_descriptors"]):
+            raise AssertionError(f"{desc}: {side} normalized_descriptors differ from the oracle")
+    # standalone wrappers (the reference's EventKeypointsExtractor / ImageKeypointsExtractor front doors)
+    fe = m.event_extractor(t(ev), t(mask)) if use_mask else m.event_extractor(t(ev))
+    fi = m.image_extractor(t(img.copy()))
+    for k in ("sparse_positions", "sparse_descriptors", "score", "nms", "logits"):
+        _same(fe[k], lazy[0][k], f"event_extractor.{k}", desc)
+        _same(fi[k], lazy[1][k], f"image_extractor.{k}", desc)
+    for ext in (m.event_extractor.extractor, m.image_extractor.extractor):
+        ext.dense_outputs = False
+    return desc
+
+
 def voxel_case(seed):
     from importlib import import_module
     rep = import_module(pkg.__name__ + ".datasets.representations")
@@ -119,13 +199,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed0", type=int, default=1)
     ap.add_argument("--family", default="both")
+    ap.add_argument("--no-modes", action="store_true")
     a = ap.parse_args()
     fams = ["sp", "silk"] if a.family == "both" else [a.family]
     t0, seed, ok, bad = time.time(), a.seed0, 0, []
     last = t0
     while time.time() - t0 < a.seconds:
         try:
-            (voxel_case if seed % 4 == 0 else lambda s: one_case(s, fams))(seed)
+            (voxel_case if seed % 4 == 0 else (lambda s: modes_case(s, fams)) if seed % 4 == 2 and not a.no_modes else lambda s: one_case(s, fams))(seed)
             ok += 1
         except AssertionError as e:
             bad.append(str(e))
