@@ -270,7 +270,11 @@ def _mask_u8(mask, H, W):
         raise RuntimeError(f"einx: the mask must live on a HIP device, got {mask.device}")
     if tuple(mask.shape[-2:]) != (H, W):
         raise ValueError(f"mask spatial size {tuple(mask.shape[-2:])} does not match the image ({H},{W})")
-    return mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    # other dtypes: "non-zero is visible" -- the reference averages `score_mask.float()` over 3x3 and tests `> 0`
+    # (EventExtractors.py:529-535), so a fractional 0.5 counts; a plain cast to uint8 would truncate it to 0
+    return mask.ne(0).contiguous().view(torch.uint8)
 
 
 class ExtractorEngine:

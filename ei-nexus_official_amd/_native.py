@@ -199,7 +199,8 @@ def score_map(logits, mask=None, pads=(0, 0, 0, 0), dilate=False, border=0):
     if mask is not None:
         if tuple(mask.shape[-2:]) != (H, W):
             raise ValueError(f"mask spatial size {tuple(mask.shape[-2:])} does not match the image ({H},{W})")
-        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+        # non-bool masks: non-zero is visible (the reference tests `conv(mask.float()) > 0`), see _extract._mask_u8
+        m8 = (mask if mask.dtype == torch.bool else mask.ne(0)).contiguous().view(torch.uint8)
     check(lib().einx_score_map(_ptr(logits), B, C, hc, wc, _ptr(m8), H, W, h0, w0, int(dilate), int(border), _ptr(prob), _ptr(score),
                                _stream(logits)), "einx_score_map")
     return prob, score

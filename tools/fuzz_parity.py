@@ -62,7 +62,20 @@ def one_case(seed, families):
     img = synth.synth_image(seed + 1, B, H, W)
     if r.integers(5) == 0:
         img[:] = np.float32(r.integers(0, 255))  # flat image: every score ties
-    ef, imf, mt = m(t(ev), t(img.copy()), t(mask))
+    mt_ = t(mask)
+    md = int(r.integers(4))  # the mask as bool / uint8 / float with fractional "visible" values / int64
+    if md == 1:
+        mt_ = mt_.to(torch.uint8)
+    elif md == 2:
+        mt_ = mt_.float() * 0.5
+    elif md == 3:
+        mt_ = mt_.long() * 7
+    evt = t(ev)
+    if r.integers(5) == 0:  # a non-contiguous view of a wider tensor
+        wide = torch.zeros((B, ce, H, W + 3), device=DEV)
+        wide[..., :W] = evt
+        evt = wide[..., :W]
+    ef, imf, mt = m(evt, t(img.copy()), mt_)
     ek, ik = ("vgg", "superpointv1") if family == "sp" else ("vgg_np", "silk")
     kw = dict(top_k=top_k, radius=radius, border=border, det_thr=det_thr, ordering=ordering)
     es, is_ = (float(e.descriptor_scale_factor.detach()) for e in (m.event_extractor.extractor, m.image_extractor.extractor))
