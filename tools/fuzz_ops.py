@@ -231,6 +231,65 @@ def lg_case(seed):
             raise AssertionError(f"{desc}: matches0[{i}] = {m0[i]} vs {e0[i]} without a near-tie")
 
 
+def lg_batch_case(seed):
+    """The batched matcher path (both sides of every pair stacked into one launch per layer, device-side counts): B pairs with
+    different keypoint counts each equal their own per-pair oracle run; padding rows beyond a pair's count stay unmatched."""
+    from importlib import import_module
+    bt = import_module(pkg.__name__ + ".core.modules.matchers._batched")
+    r = np.random.default_rng(seed)
+    din = 256
+    if din not in _LG:
+        lg = pkg.LightGlue({"input_dim": din}).to(DEV).eval()
+        sd = pkg.synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=900 + din)
+        lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        _LG[din] = (lg, sd)
+    lg, sd = _LG[din]
+    B = int(r.choice([2, 3, 5]))
+    cap0, cap1 = int(r.choice([8, 64, 150, 256])), int(r.choice([8, 70, 128, 300]))
+    n0 = [int(r.integers(1, cap0 + 1)) for _ in range(B)]
+    n1 = [int(r.integers(1, cap1 + 1)) for _ in range(B)]
+    if r.integers(2):
+        n0[0], n1[-1] = cap0, cap1
+    H, W = int(r.integers(60, 300)), int(r.integers(60, 400))
+    desc = f"seed {seed}: lightglue batch B={B} caps {cap0}/{cap1} counts {n0} / {n1} size {H}x{W}"
+    K0, K1 = np.zeros((B, cap0, 3), np.float32), np.zeros((B, cap1, 3), np.float32)
+    D0, D1 = np.zeros((B, cap0, din), np.float32), np.zeros((B, cap1, din), np.float32)
+    for b in range(B):
+        d0, d1 = f32(r, (n0[b], din)), f32(r, (n1[b], din))
+        k = min(n0[b], n1[b]) // 2
+        d1[:k] = d0[:k] + f32(r, (k, din), -0.1, 0.1)
+        D0[b, :n0[b]] = d0 / np.linalg.norm(d0, axis=1, keepdims=True)
+        D1[b, :n1[b]] = d1 / np.linalg.norm(d1, axis=1, keepdims=True)
+        K0[b, :n0[b]] = np.stack([r.uniform(0, H, n0[b]), r.uniform(0, W, n0[b]), r.uniform(0, 1, n0[b])], 1)
+        K1[b, :n1[b]] = np.stack([r.uniform(0, H, n1[b]), r.uniform(0, W, n1[b]), r.uniform(0, 1, n1[b])], 1)
+        # rows past the count hold garbage the kernels must never read into a result
+        D0[b, n0[b]:] = 7.0
+        D1[b, n1[b]:] = -3.0
+        K0[b, n0[b]:] = 1e6
+    pbs = []
+    for K, D, cnt, cap in ((K0, D0, n0, cap0), (K1, D1, n1, cap1)):
+        pb = bt.PairBatch()
+        pb.kpts, pb.desc, pb.counts = t(K), t(D), t(np.asarray(cnt, np.int32))
+        pb.cap, pb.B, pb.image_size, pb.counts_host = cap, B, (H, W), None
+        pbs.append(pb)
+    mr = lg.match_batched(pbs[0], pbs[1])
+    m0, s0 = n(mr.matches0), n(mr.scores0)
+    for b in range(B):
+        exp = orc.lightglue(sd, K0[b, :n0[b]], D0[b, :n0[b]], K1[b, :n1[b]], D1[b, :n1[b]], size0=(H, W), size1=(H, W))
+        if np.abs(s0[b, :n0[b]] - exp["matching_scores0"]).max() > 1e-4:
+            raise AssertionError(f"{desc}: pair {b} matching_scores0 off by {np.abs(s0[b, :n0[b]] - exp['matching_scores0']).max():.2e}")
+        e0 = np.asarray(exp["matches0"])
+        for i in np.nonzero(m0[b, :n0[b]] != e0)[0]:
+            row = exp["log_assignment"][i, :-1]
+            cand = [j for j in (m0[b, i], e0[i]) if j >= 0]
+            near_tie = len(cand) == 2 and abs(row[cand[0]] - row[cand[1]]) < 2e-3
+            near_thr = min(abs(float(np.exp(row[j]))) for j in cand) < 2e-3 if cand else False
+            if not (near_tie or near_thr):
+                raise AssertionError(f"{desc}: pair {b} matches0[{i}] = {m0[b, i]} vs {e0[i]} without a near-tie")
+        if (m0[b, n0[b]:] != -1).any() or (m0[b, :n0[b]] >= n1[b]).any():
+            raise AssertionError(f"{desc}: pair {b}: a padding row matched or a match points past the other side's count")
+
+
 def metrics_case(seed):
     from importlib import import_module
     nm = import_module(pkg.__name__ + ".core.metrics._native_metrics")
@@ -260,7 +319,7 @@ def metrics_case(seed):
         raise AssertionError(f"{desc}: {got} vs {exp}")
 
 
-CASES = [conv_case, conv_case, detect_case, upsample_case, mnn_case, sample_case, lg_case, metrics_case]
+CASES = [conv_case, conv_case, detect_case, upsample_case, mnn_case, sample_case, lg_case, metrics_case, lg_batch_case]
 
 
 def main():
