@@ -17,6 +17,7 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
 n = lambda x: x.detach().cpu().numpy()  # noqa: E731
 sub = lambda sd, p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}  # noqa: E731
 MODELS = {}
+LARGE = False
 
 
 def model_for(family, ce, top_k, radius, border, det_thr, ordering, seed):
@@ -40,7 +41,10 @@ def one_case(seed, families):
     family = families[int(r.integers(len(families)))]
     ce = int(r.choice([1, 3, 5, 8]))
     B = int(r.choice([1, 1, 2, 3, 5]))
-    if family == "sp":
+    if LARGE:  # sensor-sized inputs (DSEC 480x640, 720p): grid / tile / radix-select limits
+        B = int(r.choice([1, 2]))
+        H, W = (int(r.integers(400, 721)), int(r.integers(500, 1281))) if family == "sp" else (int(r.integers(200, 300)), int(r.integers(250, 400)))
+    elif family == "sp":
         H, W = int(r.integers(24, 200)), int(r.integers(24, 260))
     else:
         H, W = int(r.integers(24, 90)), int(r.integers(24, 120))
@@ -213,8 +217,13 @@ def main():
     ap.add_argument("--seed0", type=int, default=1)
     ap.add_argument("--family", default="both")
     ap.add_argument("--no-modes", action="store_true")
+    ap.add_argument("--large", action="store_true", help="sensor-sized images (400-720 x 500-1280), whole forwards only")
     a = ap.parse_args()
     fams = ["sp", "silk"] if a.family == "both" else [a.family]
+    global LARGE
+    LARGE = a.large
+    if LARGE:
+        a.no_modes = True
     t0, seed, ok, bad = time.time(), a.seed0, 0, []
     last = t0
     while time.time() - t0 < a.seconds:
