@@ -159,7 +159,7 @@ def sample_case(seed):
     hc, wc = int(r.integers(2, 34)), int(r.integers(2, 45))
     bil = bool(r.integers(2))
     Hp, Wp = (hc * 8, wc * 8) if bil else (hc, wc)
-    cap = int(r.choice([1, 8, 100]))
+    cap = min(int(r.choice([1, 8, 100])), Hp * Wp)
     counts = r.integers(0, cap + 1, B).astype(np.int32)
     idx = [np.sort(r.choice(Hp * Wp, int(c), replace=False)).astype(np.int32) for c in counts]
     sc = float(r.choice([1.0, 1.41]))
