@@ -318,9 +318,10 @@ class ExtractorEngine:
             self._handle = None
         arr = lambda layers: (_lib.ConvDesc * len(layers))(*[l.desc for l in layers])  # noqa: E731
         bb, det, desc = arr(self.backbone), arr(self.det_head), arr(self.desc_head)
+        mh = getattr(self, "merged_head0", None)
         d = _lib.ExtractorDesc(self.cell, len(self.backbone), len(self.det_head), len(self.desc_head), bb, det, desc, int(bool(dilate_mask)),
                                int(self.border), int(self.radius), int(self.top_k or 0), float(self.det_thr), int(self.ordering == "xy"),
-                               float(scale), float(input_div))
+                               float(scale), float(input_div), ctypes.pointer(mh.desc) if mh is not None else None)
         h = L.einx_extractor_create(ctypes.byref(d))
         if not h:
             raise _lib.EinxError("einx_extractor_create failed: " + L.einx_last_error().decode(errors="replace"))

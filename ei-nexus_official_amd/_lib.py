@@ -29,7 +29,8 @@ class ExtractorDesc(ctypes.Structure):
     _fields_ = [("cell", ctypes.c_int32), ("n_backbone", ctypes.c_int32), ("n_det", ctypes.c_int32), ("n_desc", ctypes.c_int32),
                 ("backbone", ctypes.POINTER(ConvDesc)), ("det_head", ctypes.POINTER(ConvDesc)), ("desc_head", ctypes.POINTER(ConvDesc)),
                 ("dilate_mask", ctypes.c_int32), ("border", ctypes.c_int32), ("nms_radius", ctypes.c_int32), ("top_k", ctypes.c_int32),
-                ("det_thr", c_float), ("ordering_xy", ctypes.c_int32), ("desc_scale", c_float), ("input_div", c_float)]
+                ("det_thr", c_float), ("ordering_xy", ctypes.c_int32), ("desc_scale", c_float), ("input_div", c_float),
+                ("merged_head0", ctypes.POINTER(ConvDesc))]
 
 
 class ExtractShapes(ctypes.Structure):

@@ -71,9 +71,30 @@ class NativeExtractor(nn.Module):
         are detected by `_signature`, `.data` edits -- down to a single element -- by the content watch at the next forward)."""
         self._engine = self._scale_host = self._sig_tensors = None
 
+    def _spec(self, block):
+        """(conv, BatchNorm or None, relu) of one entry of `_stacks()` (families that list their layers differently override it
+        together with `_layer`)"""
+        return block_spec(block)[:3]
+
     def _layer(self, block, pool=False):
         conv, bn, relu, pool = block_spec(block, pool)
         return N.ConvLayer(conv.weight, conv.bias, None if bn is None else N.bn_tuple(bn), relu=relu, pool=pool)
+
+    def _merged_head0(self, det, desc):
+        """The two heads' first 3x3 layers read the same backbone features: as ONE layer (output channels of the detector's first,
+        then the descriptor's) they are one launch instead of two on a single pair's latency-bound chain (einx.h:
+        einx_extractor_desc::merged_head0; used for B == 1).  None when the heads are not two layers of the same structure."""
+        if len(det) != 2 or len(desc) != 2:
+            return None
+        (ca, ba, ra), (cb, bb_, rb) = self._spec(det[0]), self._spec(desc[0])
+        same = (ca.kernel_size == cb.kernel_size == (3, 3) and ca.in_channels == cb.in_channels and ra == rb and (ba is None) == (bb_ is None)
+                and (ca.bias is None) == (cb.bias is None) and ca.out_channels % 64 == 0 and (ba is None or ba.eps == bb_.eps))
+        if not same:
+            return None
+        cat = lambda a, b: torch.cat([a.detach(), b.detach()], 0)  # noqa: E731
+        bn = None if ba is None else (cat(ba.weight, bb_.weight), cat(ba.bias, bb_.bias), cat(ba.running_mean, bb_.running_mean),
+                                      cat(ba.running_var, bb_.running_var), ba.eps)
+        return N.ConvLayer(cat(ca.weight, cb.weight), None if ca.bias is None else cat(ca.bias, cb.bias), bn, relu=ra, pool=False)
 
     def _stacks(self):
         """-> (backbone blocks [(block, pool)], detector blocks, descriptor blocks)"""
@@ -92,6 +113,7 @@ class NativeExtractor(nn.Module):
             eng.backbone = [self._layer(b, p) for b, p in bb]
             eng.det_head = [self._layer(b) for b in det]
             eng.desc_head = [self._layer(b) for b in desc]
+            eng.merged_head0 = self._merged_head0(det, desc)
             eng.watch = N.ParamWatch(self._sig_tensors)  # `.data` edits: seen by content (round 4, inside einx_extract), see refresh()
             self._engine = eng
         # the reference's forward reads these attributes at every call (EventExtractors.py:545-556, superpoint_extractor.py:388-406):

@@ -40,6 +40,10 @@ class SuperPointv1(NativeExtractor):
         self._init_common(nms_radius, detection_top_k, detection_threshold, remove_borders, ordering, descriptor_scale_factor,
                           learnable_descriptor_scale_factor)
 
+    def _spec(self, spec):
+        conv, relu = spec
+        return conv, None, relu
+
     def _layer(self, spec, pool=False):
         conv, relu = spec
         return N.ConvLayer(conv.weight, conv.bias, None, relu=relu, pool=pool)

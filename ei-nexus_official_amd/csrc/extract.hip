@@ -35,6 +35,8 @@ struct EinxSide {
 struct einx_extractor {
   einx_extractor_desc d;
   std::vector<einx_conv_desc> backbone, det, desc;
+  bool has_merged = false;  // det[0] + desc[0] as one layer (see einx_extractor_desc::merged_head0)
+  einx_conv_desc merged;
   mutable std::mutex sides_mu;
   mutable std::map<std::pair<int, hipStream_t>, EinxSide> sides;
   ~einx_extractor() {
@@ -133,6 +135,7 @@ bool make_plan(const einx_extractor* e, int H, int W, Plan* pl) {
   size_t he = 0;
   for (size_t i = 0; i + 1 < e->det.size(); ++i) he = std::max(he, (size_t)e->det[i].cout * h * w);
   for (size_t i = 0; i + 1 < e->desc.size(); ++i) he = std::max(he, (size_t)e->desc[i].cout * h * w);
+  if (e->has_merged) he = std::max(he, (size_t)e->merged.cout * h * w);
   pl->head_elems = he;
   return h * e->d.cell == pl->Hp && w * e->d.cell == pl->Wp;
 }
@@ -182,6 +185,23 @@ EINX_EXPORT einx_extractor* einx_extractor_create(const einx_extractor_desc* d) 
   e->d.backbone = e->backbone.data();
   e->d.det_head = e->det.data();
   e->d.desc_head = e->desc.data();
+  e->d.merged_head0 = nullptr;
+  if (d->merged_head0) {
+    const einx_conv_desc& m = *d->merged_head0;
+    const einx_conv_desc &a = e->det.front(), &b = e->desc.front();
+    if (e->det.size() != 2 || e->desc.size() != 2 || m.cin != a.cin || m.cin != b.cin || m.cout != a.cout + b.cout || m.ks != a.ks || m.ks != b.ks ||
+        m.relu != a.relu || m.relu != b.relu || m.pool || a.pool || b.pool || !m.w_native || (m.scale == nullptr) != (a.scale == nullptr) ||
+        (m.scale == nullptr) != (b.scale == nullptr) || a.cout % 64 != 0) {
+      einx_set_error("einx_extractor_create: merged_head0 (cin %d cout %d ks %d relu %d pool %d bn %d) does not describe det_head[0] (%d layers; cin %d cout %d ks %d relu %d bn %d) + "
+                     "desc_head[0] (%d layers; cin %d cout %d ks %d relu %d bn %d): two-layer heads of one structure, det_head[0].cout a multiple of 64",
+                     m.cin, m.cout, m.ks, m.relu, m.pool, m.scale != nullptr, (int)e->det.size(), a.cin, a.cout, a.ks, a.relu, a.scale != nullptr,
+                     (int)e->desc.size(), b.cin, b.cout, b.ks, b.relu, b.scale != nullptr);
+      delete e;
+      return nullptr;
+    }
+    e->merged = m;
+    e->has_merged = true;
+  }
   const int want = d->cell == 8 ? 65 : 1;
   if (e->det.back().cout != want || e->backbone.back().cout != e->det.front().cin || e->backbone.back().cout != e->desc.front().cin) {
     einx_set_error("einx_extractor_create: head shapes do not fit (detector head must end in %d channels)", want);
@@ -289,9 +309,18 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
     return 0;
   };
   const int D = e->desc.back().cout;
+  // single images: the two heads' first layers as one launch into `head` (det channels first); each head's second layer then reads
+  // its slice (one image: a channel slice is contiguous)
+  const bool merged = e->has_merged && B == 1;
+  if (merged && (rc = einx_conv_block(o->feats, B, h, w, 0, 0, h, w, &e->merged, head, stream))) return rc;
+  const float* desc_in = head + (size_t)e->det.front().cout * h * w;
+  auto det_branch = [&](void* st) -> int {
+    if (merged) return einx_conv_block(head, B, h, w, 0, 0, h, w, &e->det[1], o->logits, st);
+    return run_head(e->det, head, o->logits, st);
+  };
   // descriptor branch: head convs + the dense by-product that depends on `raw` only
   auto desc_branch = [&](void* st) -> int {
-    int r = run_head(e->desc, head2, o->raw, st);
+    int r = merged ? einx_conv_block(desc_in, B, h, w, 0, 0, h, w, &e->desc[1], o->raw, st) : run_head(e->desc, head2, o->raw, st);
     if (r) return r;
     if (e->d.cell == 8) r = einx_normalize_map(o->raw, B, D, h * w, e->d.desc_scale, o->coarse, o->raw_cl, st);
     return r;
@@ -315,12 +344,12 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
       einx_set_error("einx_extract: join failed");
       return EINX_ERR_LAUNCH;
     }
-    if ((rc = run_head(e->det, head, o->logits, stream))) {
+    if ((rc = det_branch(stream))) {
       (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
       return rc;
     }
   } else {
-    if ((rc = run_head(e->det, head, o->logits, stream))) return rc;
+    if ((rc = det_branch(stream))) return rc;
     if ((rc = desc_branch(stream))) return rc;
   }
   rc = einx_score_map(o->logits, B, e->det.back().cout, h, w, mask, H, W, pl.h0, pl.w0, e->d.dilate_mask, e->d.border, o->prob, o->score,

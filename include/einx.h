@@ -321,6 +321,11 @@ typedef struct einx_extractor_desc {
   int32_t ordering_xy; /* 0: (y,x,p)  1: (x,y,p) */
   float desc_scale;    /* descriptor_scale_factor */
   float input_div;     /* SuperPointv1 scales its input in place (`image /= 255.0`, superpoint_extractor.py:372); 0 = off */
+  /* optional (NULL = off): det_head[0] and desc_head[0] -- two 3x3 layers that read the same backbone features -- as ONE layer whose
+   * output channels are det_head[0]'s followed by desc_head[0]'s (weights / bias / BatchNorm concatenated by the caller).  Used for
+   * single images (B == 1, two-layer heads): one launch instead of two on the latency-bound chain of a single-pair forward; every
+   * output channel is the same k-ordered chain, so results are bit-identical.  Larger batches keep the two launches. */
+  const einx_conv_desc* merged_head0;
 } einx_extractor_desc;
 
 typedef struct einx_extract_shapes_t {

@@ -262,3 +262,34 @@ def test_detector_attributes_assigned_between_forwards_take_effect(oracle):
                     assert np.array_equal(_np(got["sparse_descriptors"][b]), exp["sparse_descriptors"][b]), st
         counts.append(len(oe["sparse_positions"][0]))
     assert counts[1] <= 37 < counts[0] and counts[-1] == counts[0]
+
+
+@pytest.mark.parametrize("cfg_name", ["SP_MNN", "SiLK_MNN"])
+def test_single_image_merged_head_layer_equals_the_batched_path(oracle, cfg_name):
+    """Single images run the two heads' first 3x3 layers as ONE launch (einx_extractor_desc::merged_head0: the detector's output
+    channels, then the descriptor's); batches keep the two launches.  Same bits either way: image 0 alone == image 0 of a batch of
+    three, for both extractor families (VGG heads with BatchNorm, SuperPoint's and SiLK's without), and == the oracle."""
+    from helpers import sub_dict, synth
+    cfg = pkg.default_config(cfg_name, event_channels=5)
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=53)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    H, W = (120, 152) if cfg_name == "SP_MNN" else (64, 80)
+    ev, mask = synth.synth_events(53, 3, 5, H, W)
+    img = synth.synth_image(53, 3, H, W)
+    for ext in (model.event_extractor.extractor, model.image_extractor.extractor):
+        eng = ext.engine()
+        assert eng.merged_head0 is not None and eng.merged_head0.cout == eng.det_head[0].cout + eng.desc_head[0].cout
+    one = model(_t(ev[:1]), _t(img[:1].copy()), _t(mask[:1]))
+    three = model(_t(ev), _t(img.copy()), _t(mask))
+    for side in (0, 1):
+        for key in ("logits", "raw_descriptors", "score"):
+            assert torch.equal(one[side][key][0], three[side][key][0]), (side, key)
+        assert torch.equal(one[side]["sparse_positions"][0], three[side]["sparse_positions"][0])
+        assert torch.equal(one[side]["sparse_descriptors"][0], three[side]["sparse_descriptors"][0])
+    kinds = ("vgg", "superpointv1") if cfg_name == "SP_MNN" else ("vgg_np", "silk")
+    es, is_ = (float(e.descriptor_scale_factor.detach()) for e in (model.event_extractor.extractor, model.image_extractor.extractor))
+    oe = oracle.extractor_forward(kinds[0], sub_dict(sd, "event_extractor.extractor."), ev[:1].copy(), mask[:1], top_k=1024, scale=es)
+    oi = oracle.extractor_forward(kinds[1], sub_dict(sd, "image_extractor.extractor."), img[:1].copy(), None, top_k=1024, scale=is_)
+    for got, exp in ((one[0], oe), (one[1], oi)):
+        assert np.array_equal(_np(got["logits"]), exp["logits"]) and np.array_equal(_np(got["raw_descriptors"]), exp["raw_descriptors"])
