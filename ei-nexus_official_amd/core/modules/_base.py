@@ -127,6 +127,32 @@ class NativeExtractor(nn.Module):
     def _prepare_input(self, x):
         return x
 
+    def _pooled_padding0_error(self, x, score_mask):
+        """VGGExtractor(padding=0) (pooled, un-padded 3x3 layers) constructs in the reference but no forward of it can complete
+        (measured with the reference, tests/golden/gen_pad0_pooled.py): its score map is smaller than the padded input (eight valid
+        backbone layers and one head layer under three poolings), so with a mask `score[~score_mask] = 0` fails on the shapes
+        (EventExtractors.py:553-554), and without one `filter_sparse_feats` indexes the H*W dense descriptors with a validity mask
+        over the smaller score map (:608 -> :499-500).  The drop-in raises the same IndexError with the same shapes, before any launch.
+        (The EIM / Extractors front-ends never pass `padding` to this class: Extractors.py:46-58.)"""
+        from ..._native import padder_pads
+        B, _, H, W = x.shape
+        w0, w1, h0, h1 = padder_pads(H, W, 8)
+        Hp, Wp = H + h0 + h1, W + w0 + w1
+
+        def head_size(n):
+            for _ in range(3):
+                n = (n - 4) // 2   # two valid 3x3 layers, then MaxPool2d(2, 2)
+            return n - 4 - 2       # l4's two layers, the heads' 3x3 layer
+        hs, ws = head_size(Hp) * 8, head_size(Wp) * 8
+        if hs <= 0 or ws <= 0:
+            raise RuntimeError(f"Calculated padded input size per channel: ({Hp} x {Wp}). Kernel size: (3 x 3). Kernel size can't be greater than "
+                               "actual input size")
+        if score_mask is not None:
+            raise IndexError(f"The shape of the mask [{B}, 1, {Hp}, {Wp}] at index 2 does not match the shape of the indexed tensor "
+                             f"[{B}, 1, {hs}, {ws}] at index 2")
+        raise IndexError(f"The shape of the mask [{hs * ws}] at index 0 does not match the shape of the indexed tensor "
+                         f"[{Hp * Wp}, {self.descriptor_dim}] at index 0")  # dense_descriptors are taken before the unpad (:591-592)
+
     @on_input_device
     def extract_batched(self, x, score_mask=None, nms_iters=None, dense=None, prepared=False, defer_dense=False):
         """prepared=True: an IN-PLACE input scaling (SuperPointv1's `image /= 255`) has already been applied to `x` by an earlier
@@ -134,6 +160,8 @@ class NativeExtractor(nn.Module):
         defer_dense=True: the dense descriptor map is left to the caller (`bf.run_dense()` on a stream of its choice)."""
         if self.training and self.uses_batchnorm:
             raise RuntimeError("the native path implements eval-mode BatchNorm (running statistics) only; call .eval() first")
+        if getattr(self, "padding", 1) == 0 and self.cell_size == 8:
+            self._pooled_padding0_error(x, score_mask)
         if not (prepared and self.input_div):
             x = self._prepare_input(x)
         eng = self.engine()

@@ -9,9 +9,8 @@ class VGGBackBone(nn.Module):
         super().__init__()
         if padding not in (0, 1):
             raise AssertionError(padding)  # backbone.py:26
-        if padding == 0 and use_max_pooling:
-            raise NotImplementedError("einx: padding=0 is implemented for the un-pooled (cell 1) networks, where the reference maps "
-                                      "the keypoints back (+9); the pooled variant is not used by EI-Nexus")
+        # (padding=0 with pooling constructs like in the reference; its forward cannot complete there either: see
+        # _base.NativeExtractor._pooled_padding0_error)
         self.padding = padding
         self.use_max_pooling = use_max_pooling
         chans = [(in_channels, 64), (64, 64), (64, 128), (128, feat_channels)]
