@@ -1055,7 +1055,9 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
   SelArgs a;
   a.map = cur;
   a.flags = flags;
-  a.nms_out = nms_out;
+  // the thresholded, cropped map (the `nms` output) is written by nms_crop_kernel below: the selection kernel's fast path never walks
+  // the whole map after the threshold is known (its generic path could, and used to write the map a second time)
+  a.nms_out = nullptr;
   a.positions = positions;
   a.indices = indices;
   a.counts = counts;
