@@ -283,7 +283,8 @@ class EIM(nn.Module):
             return tuple(getattr(e, k, None) for k in ("dense_outputs", "detection_top_k", "detection_threshold", "nms_radius", "remove_borders",
                                                        "ordering", "dilate_mask"))
         m = self.matcher.matcher
-        mk = None if m is None else (type(m).__name__,) + tuple(repr(getattr(m, k, None)) for k in ("want_log_assignment", "ratio_thresh", "distance_thresh"))
+        mk = None if m is None else (type(m).__name__,) + tuple(repr(getattr(m, k, None)) for k in ("want_log_assignment", "ratio_thresh", "distance_thresh")) \
+            + (repr(getattr(getattr(m, "conf", None), "filter_threshold", None)),)
         return (ext(self.event_extractor.extractor), ext(self.image_extractor.extractor), mk, bool(getattr(self, "overlap_extractors", True)))
 
     @on_input_device

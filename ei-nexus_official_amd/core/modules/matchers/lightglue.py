@@ -203,6 +203,7 @@ class LightGlue(nn.Module):
         if pb0.desc.shape[-1] != self.conf.input_dim or pb1.desc.shape[-1] != self.conf.input_dim:
             raise AssertionError("descriptor dimension does not match conf.input_dim")
         w = self._pack()[0]
+        w.filter_threshold = float(self.conf.filter_threshold)  # read at every call like the reference's filter_matches call (lightglue.py:656)
         stale = self._watch.check()
         r = N.lightglue(w, pb0, pb1, want_la=self.want_log_assignment, want_ref=True, all_layers=all_layers)
         r.stale = stale

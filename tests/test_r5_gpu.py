@@ -293,3 +293,36 @@ def test_single_image_merged_head_layer_equals_the_batched_path(oracle, cfg_name
     oi = oracle.extractor_forward(kinds[1], sub_dict(sd, "image_extractor.extractor."), img[:1].copy(), None, top_k=1024, scale=is_)
     for got, exp in ((one[0], oe), (one[1], oi)):
         assert np.array_equal(_np(got["logits"]), exp["logits"]) and np.array_equal(_np(got["raw_descriptors"]), exp["raw_descriptors"])
+
+
+def test_lightglue_filter_threshold_assigned_between_forwards(oracle):
+    """The reference passes `self.conf.filter_threshold` to filter_matches in every forward (lightglue.py:656); the native weight image
+    used to keep the value it was packed with.  Assigning it between two forwards changes the next one (eager and graph mode)."""
+    from helpers import synth
+    lg = pkg.LightGlue({"input_dim": 256}).to(DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=59)
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    r = np.random.default_rng(59)
+    n0, n1 = 120, 150
+    d0 = r.uniform(-1, 1, (n0, 256)).astype(np.float32)
+    d1 = r.uniform(-1, 1, (n1, 256)).astype(np.float32)
+    d1[:60] = d0[:60] + r.uniform(-0.05, 0.05, (60, 256)).astype(np.float32)
+    d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    k0 = np.stack([r.uniform(0, 260, n0), r.uniform(0, 346, n0), r.uniform(0, 1, n0)], 1).astype(np.float32)
+    k1 = np.stack([r.uniform(0, 260, n1), r.uniform(0, 346, n1), r.uniform(0, 1, n1)], 1).astype(np.float32)
+    size = torch.tensor([260, 346])
+    f0 = {"sparse_descriptors": _t(d0)[None], "sparse_positions": _t(k0)[None], "image_size": [size]}
+    f1 = {"sparse_descriptors": _t(d1)[None], "sparse_positions": _t(k1)[None], "image_size": [size]}
+    base = oracle.lightglue(sd, k0, d0, k1, d1, filter_threshold=0.0)
+    scores = np.sort(base["matching_scores0"][np.asarray(base["matches0"]) > -1])
+    assert len(scores) >= 4
+    thr = float((scores[len(scores) // 2 - 1] + scores[len(scores) // 2]) / 2)  # a threshold between two matched scores
+    counts = []
+    for value in (0.0, thr, 0.0):
+        lg.conf.filter_threshold = value
+        got = lg(f0, f1)
+        exp = oracle.lightglue(sd, k0, d0, k1, d1, filter_threshold=value)
+        assert np.array_equal(_np(got["matches0"])[0], exp["matches0"]), value
+        counts.append(int((np.asarray(exp["matches0"]) > -1).sum()))
+    assert counts[1] < counts[0] == counts[2]
