@@ -555,9 +555,11 @@ EINX_EXPORT size_t einx_voxel_ws_bytes(int B, int bins, int H, int W, int64_t to
 
 EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t, const float* p, const int64_t* offsets_host, int B,
                                 int bins, int H, int W, int normalize, float* grid, void* ws, size_t ws_bytes, void* stream) {
-  EINX_CHECK_ARG(x && y && t && p && offsets_host && grid && ws, "null pointer");
+  EINX_CHECK_ARG(offsets_host && grid && ws, "null pointer");
   EINX_CHECK_ARG(B > 0 && bins > 0 && H > 0 && W > 0 && H < 60000 && W < 60000, "bad shape");
   EINX_CHECK_ARG(offsets_host[0] == 0, "offsets_host[0] must be 0");
+  // a batch without a single event (every sample empty): the event arrays may be NULL, the grids are zero like an empty sample's
+  EINX_CHECK_ARG(offsets_host[B] == 0 || (x && y && t && p), "null event arrays");
   hipStream_t s = (hipStream_t)stream;
   const size_t per = (size_t)bins * H * W;
   const VoxGeom g = vox_geom(bins, H, W);
@@ -617,8 +619,9 @@ EINX_EXPORT int einx_voxel_grid(const float* x, const float* y, const double* t,
 
 EINX_EXPORT int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host, int B, int H, int W, void* ws, uint8_t* mask,
                                  void* stream) {
-  EINX_CHECK_ARG(x && y && offsets_host && ws && mask, "null pointer");
+  EINX_CHECK_ARG(offsets_host && ws && mask, "null pointer");
   EINX_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad shape");
+  EINX_CHECK_ARG(offsets_host[B] == 0 || (x && y), "null event arrays");  // (no event at all: all-false masks)
   hipStream_t s = (hipStream_t)stream;
   const int n = H * W;
   int32_t* cnt = (int32_t*)((char*)ws + (size_t)B * 32);

@@ -30,6 +30,12 @@ def test_end_to_end_seeds(oracle):
             fz.one_case(seed, ["sp", "silk"])
 
 
+def test_harness_seeds(oracle):
+    fz = _tool("fuzz_parity")
+    for seed in range(1, 13):
+        fz.harness_case(seed)
+
+
 def test_op_level_seeds(oracle):
     fz = _tool("fuzz_ops")
     for fn, count in ((fz.conv_case, 60), (fz.detect_case, 30), (fz.upsample_case, 30), (fz.mnn_case, 30), (fz.sample_case, 30), (fz.metrics_case, 30),

@@ -326,3 +326,21 @@ def test_lightglue_filter_threshold_assigned_between_forwards(oracle):
         assert np.array_equal(_np(got["matches0"])[0], exp["matches0"]), value
         counts.append(int((np.asarray(exp["matches0"]) > -1).sum()))
     assert counts[1] < counts[0] == counts[2]
+
+
+def test_event_batches_without_any_event(oracle):
+    """Found by tools/fuzz_parity.py --harness: a batch whose samples are ALL empty hands NULL event arrays to the C ABI, which
+    refused them ("null pointer") although one empty sample among others had always given a zero grid.  Zero grids and all-false
+    masks, also through the evaluator step."""
+    from importlib import import_module
+    rep = import_module(pkg.__name__ + ".datasets.representations")
+    empty = {"x": np.zeros(0, np.float32), "y": np.zeros(0, np.float32), "t": np.zeros(0, np.float64), "p": np.zeros(0, np.float32)}
+    grid = _np(rep.events_to_voxel_grid_batch([empty, empty], (5, 40, 56)))
+    mask = _np(rep.events_mask_batch([empty, empty], (56, 40)))
+    assert grid.shape == (2, 5, 40, 56) and not grid.any()
+    assert mask.shape == (2, 1, 40, 56) and not mask.any()
+    one = {"x": np.array([3.5], np.float32), "y": np.array([2.25], np.float32), "t": np.array([1.0]), "p": np.array([1.0], np.float32)}
+    g2 = _np(rep.events_to_voxel_grid_batch([empty, one], (5, 40, 56)))
+    assert not g2.any()  # (one event: NaN t_norm, dropped like in the reference)
+    m2 = _np(rep.events_mask_batch([empty, one], (56, 40)))
+    assert not m2[0].any() and m2[1].sum() == 1 and m2[1, 0, 2, 3]

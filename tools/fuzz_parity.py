@@ -183,6 +183,61 @@ def modes_case(seed, families):
     return desc
 
 
+def harness_case(seed):
+    """The reference's evaluation step (test_events-image_same-time.py:130-194 / _different_time.py:187-264): raw event arrays -> voxel
+    grid + mask -> EIM.forward -> MR / MMA / VDD rows, against the oracle chain from the same raw events; random event counts per
+    sample (including empty and one-event samples), sizes, bins and homographies."""
+    r = np.random.default_rng(seed)
+    bins = int(r.choice([3, 5]))
+    B = int(r.choice([1, 2, 3]))
+    H, W = int(r.integers(40, 140)), int(r.integers(40, 180))
+    top_k = int(r.choice([20, 128]))
+    desc = f"seed {seed}: harness bins={bins} B={B} {H}x{W} top_k={top_k}"
+    m, sd = model_for("sp", bins, top_k, 4, 4, 1.0, "yx", seed)
+    evs = []
+    for b in range(B):
+        nev = int(r.choice([0, 1, 50, 3000, 12000]))
+        x = r.integers(0, W, nev).astype(np.float32) if r.integers(2) else r.uniform(0, W - 1, nev).astype(np.float32)
+        y = r.integers(0, H, nev).astype(np.float32) if r.integers(2) else r.uniform(0, H - 1, nev).astype(np.float32)
+        evs.append({"x": x, "y": y, "t": 1.5e9 + np.sort(r.uniform(0, 0.05, nev)), "p": r.choice([0.0, 1.0], nev).astype(np.float32)})
+    desc += f" events={[len(e['x']) for e in evs]}"
+    img = synth.synth_image(seed + 1, B, H, W)
+    use_hom = bool(r.integers(2))
+    homs = None
+    if use_hom:
+        homs = np.stack([np.eye(3) + r.uniform(-1, 1, (3, 3)) * np.array([[0.03, 0.03, 4], [0.03, 0.03, 4], [2e-5, 2e-5, 0]]) for _ in range(B)]).astype(np.float32)
+        ev_ = pkg.DifferentTimeEvaluator(m, bins=bins, resolution=(W, H))
+        rows, (ef, imf, mt) = ev_.step(evs, t(img.copy()), t(homs))
+    else:
+        ev_ = pkg.SameTimeEvaluator(m, bins=bins, resolution=(W, H))
+        rows, (ef, imf, mt) = ev_.step(evs, t(img.copy()))
+    rows = n(rows)
+    grid = n(ev_.last_inputs[0])
+    mask = np.stack([orc.events_mask(e, (W, H)) for e in evs])[:, None]
+    if not np.array_equal(n(ev_.last_inputs[1]).astype(bool), mask):
+        raise AssertionError(f"{desc}: events mask differs")
+    for b in range(B):
+        if not np.allclose(grid[b], orc.voxel_grid(evs[b], (bins, H, W)), atol=2e-5, rtol=1e-5):
+            raise AssertionError(f"{desc}: voxel grid of sample {b} differs")
+    oe = orc.extractor_forward("vgg", sub(sd, "event_extractor.extractor."), grid.copy(), mask, top_k=top_k)
+    oi = orc.extractor_forward("superpointv1", sub(sd, "image_extractor.extractor."), img.copy(), None, top_k=top_k)
+    for side, got, exp in (("event", ef, oe), ("image", imf, oi)):
+        for b in range(B):
+            if not (np.array_equal(n(got["sparse_positions"][b]), exp["sparse_positions"][b]) and
+                    np.array_equal(n(got["sparse_descriptors"][b]), exp["sparse_descriptors"][b])):
+                raise AssertionError(f"{desc}: {side} features of sample {b} differ")
+    for b in range(B):
+        k0, k1, d0, d1 = oe["sparse_positions"][b], oi["sparse_positions"][b], oe["sparse_descriptors"][b], oi["sparse_descriptors"][b]
+        if len(k0) == 0 or len(k1) == 0:
+            continue  # (the empty-side rows are pinned by the metric fixtures)
+        rr = orc.mnn(d0, d1, want_la=False)
+        mk0, mk1 = orc.matched_kpts(k0, k1, rr["matches0"], 3)
+        exp = orc.pair_metrics(k0, k1, d0, d1, mk0, mk1, (H, W), (H, W), hom=None if homs is None else homs[b])
+        if not np.allclose(rows[b], exp, atol=2e-3, rtol=1e-5, equal_nan=True):
+            raise AssertionError(f"{desc}: metric row {b}: {rows[b]} vs {exp}")
+    return desc
+
+
 def voxel_case(seed):
     from importlib import import_module
     rep = import_module(pkg.__name__ + ".datasets.representations")
@@ -217,6 +272,7 @@ def main():
     ap.add_argument("--seed0", type=int, default=1)
     ap.add_argument("--family", default="both")
     ap.add_argument("--no-modes", action="store_true")
+    ap.add_argument("--harness", action="store_true", help="the evaluation step: raw events -> voxel grid + mask -> forward -> metric rows")
     ap.add_argument("--large", action="store_true", help="sensor-sized images (400-720 x 500-1280), whole forwards only")
     a = ap.parse_args()
     fams = ["sp", "silk"] if a.family == "both" else [a.family]
@@ -228,7 +284,10 @@ def main():
     last = t0
     while time.time() - t0 < a.seconds:
         try:
-            (voxel_case if seed % 4 == 0 else (lambda s: modes_case(s, fams)) if seed % 4 == 2 and not a.no_modes else lambda s: one_case(s, fams))(seed)
+            if a.harness:
+                harness_case(seed)
+            else:
+                (voxel_case if seed % 4 == 0 else (lambda s: modes_case(s, fams)) if seed % 4 == 2 and not a.no_modes else lambda s: one_case(s, fams))(seed)
             ok += 1
         except AssertionError as e:
             bad.append(str(e))
