@@ -110,6 +110,7 @@ SIGNATURES = {
     "einx_pair_metrics": (c_int, [ctypes.POINTER(MetricParams)] + [c_void_p] * 13),
     "einx_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "einx_lg_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "einx_lg_ws_bytes_heads": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "einx_lightglue": (c_int, [ctypes.POINTER(LgWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_void_p]),

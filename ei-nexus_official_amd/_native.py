@@ -369,7 +369,10 @@ def lightglue(weights, pb0, pb1, want_la=True, want_ref=False, all_layers=False)
     L = lib()
     dev = pb0.desc.device
     d = int(weights.d)
-    ws = torch.empty(L.einx_lg_ws_bytes(B, cap0, cap1, d, int(weights.input_dim)), dtype=torch.uint8, device=dev)
+    nbytes = L.einx_lg_ws_bytes_heads(B, cap0, cap1, d, int(weights.heads), int(weights.input_dim))
+    if not nbytes:
+        raise NotImplementedError("einx LightGlue: descriptor_dim must be num_heads x head_dim with head_dim 32, 64 or 128")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     r = MatchResult()
     r.matches0 = torch.empty((B, cap0), dtype=torch.int64, device=dev)
     r.matches1 = torch.empty((B, cap1), dtype=torch.int64, device=dev)

@@ -97,16 +97,20 @@ class LightGlue(nn.Module):
     def __init__(self, conf):
         super().__init__()
         self.conf = conf = _merge(self.default_conf, conf)
-        if conf.add_scale_ori:
-            raise NotImplementedError("einx LightGlue: add_scale_ori is not used by EI-Nexus")
-        if conf.num_heads * 64 != conf.descriptor_dim:
-            raise NotImplementedError("einx LightGlue kernels are built for 64-wide heads")
+        # widths as the reference derives them (lightglue.py:246-248, 456): any num_heads dividing descriptor_dim; the attention
+        # kernel exists for 32-, 64- and 128-wide heads (256 = 4 x 64, every EI-Nexus YAML, runs its own instantiation)
+        assert conf.descriptor_dim % conf.num_heads == 0
+        if conf.descriptor_dim // conf.num_heads not in (32, 64, 128):
+            raise NotImplementedError("einx LightGlue: descriptor_dim // num_heads must be 32, 64 or 128 "
+                                      f"(got {conf.descriptor_dim} // {conf.num_heads})")
         if conf.input_dim != conf.descriptor_dim:
             self.input_proj = nn.Linear(conf.input_dim, conf.descriptor_dim, bias=True)
         else:
             self.input_proj = nn.Identity()
         head_dim = conf.descriptor_dim // conf.num_heads
-        self.posenc = LearnableFourierPositionalEncoding(2, head_dim, head_dim)
+        # add_scale_ori: the reference builds a 4-input encoding (:457-459) but its forward never appends scales / orientations
+        # (:540-560 are commented out), so every forward fails in posenc.Wr on the 2-column keypoints; mirrored in forward()
+        self.posenc = LearnableFourierPositionalEncoding(2 + 2 * bool(conf.add_scale_ori), head_dim, head_dim)
         h, n, d = conf.num_heads, conf.n_layers, conf.descriptor_dim
         self.transformers = nn.ModuleList([TransformerLayer(d, h, conf.flash) for _ in range(n)])
         self.log_assignment = nn.ModuleList([MatchAssignment(d) for _ in range(n)])
@@ -198,8 +202,21 @@ class LightGlue(nn.Module):
         self._packed = (w, layers, keep)
         return self._packed
 
+    def _add_scale_ori_error(self, feats0):
+        """What the reference's forward raises with add_scale_ori=True (recorded from the reference, tests/golden/lgcfg.json): the
+        descriptor-width assert comes first (:562-563), then posenc.Wr -- Linear(4, head_dim/2) -- meets [b, n, 2] keypoints (:565)."""
+        pos, desc = feats0["sparse_positions"], feats0["sparse_descriptors"]
+        pos = pos if torch.is_tensor(pos) else pos[0][None]
+        desc = desc if torch.is_tensor(desc) else desc[0][None]
+        if desc.shape[-1] != self.conf.input_dim:
+            raise AssertionError("descriptor dimension does not match conf.input_dim")
+        rows = pos.shape[0] * pos.shape[1] if pos.dim() == 3 else pos.shape[0]
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({rows}x2 and 4x{self.posenc.Wr.weight.shape[0]})")
+
     @on_input_device
     def match_batched(self, pb0, pb1, all_layers=False):
+        if self.conf.add_scale_ori:
+            raise RuntimeError("einx LightGlue: add_scale_ori=True has no working forward in the reference (lightglue.py:540-565)")
         if pb0.desc.shape[-1] != self.conf.input_dim or pb1.desc.shape[-1] != self.conf.input_dim:
             raise AssertionError("descriptor dimension does not match conf.input_dim")
         w = self._pack()[0]
@@ -218,6 +235,8 @@ class LightGlue(nn.Module):
         (`self.training`) ref_descriptors hold every layer's output [B,L,n,d] (:626-629,709-710);
         forward values only -- autograd / the loss are outside this build."""
         pos0, pos1 = feats0["sparse_positions"], feats1["sparse_positions"]
+        if self.conf.add_scale_ori:
+            self._add_scale_ori_error(feats0)
         stacked = torch.is_tensor(pos0) and pos0.dim() == 3 and torch.is_tensor(pos1) and pos1.dim() == 3
         if stacked:
             if feats0["sparse_descriptors"].shape[-1] != self.conf.input_dim or feats1["sparse_descriptors"].shape[-1] != self.conf.input_dim:

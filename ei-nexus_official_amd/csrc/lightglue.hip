@@ -24,21 +24,24 @@ using namespace einx_match;
 
 namespace {
 
+// The shipped configuration (every EI-Nexus YAML): descriptor_dim 256 = 4 heads x 64.  Its kernels are instantiated with these
+// as compile-time constants; any other (heads, head_dim in {32, 64, 128}) configuration of lightglue.py:456-461 runs the same
+// kernels with the widths taken from the arguments.
 constexpr int D = 256;   // descriptor_dim
 constexpr int DH = 64;   // head dim
-constexpr int HEADS = 4;
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // ------------------------------------------------------------------------------------------
-// positional encoding: enc[b][i][0..63] = cos, [64..127] = sin of Wr . normalised keypoint,
+// positional encoding: enc[b][i][0..dh-1] = cos, [dh..2dh-1] = sin of Wr . normalised keypoint (Wr: [dh/2, 2]),
 // each frequency repeated twice (repeat_interleave(2)).
 // ------------------------------------------------------------------------------------------
-__global__ void lg_posenc_kernel(const float* kpts, const int32_t* cnt, int cap, float s0, float s1, const float* Wr, float* enc) {
+__global__ void lg_posenc_kernel(const float* kpts, const int32_t* cnt, int cap, float s0, float s1, const float* Wr, float* enc, int dh) {
   const int b = blockIdx.y;
   const int n = min(cnt[b], cap);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 5, f = t & 31;
+  const int nf = dh >> 1;
+  const int i = t / nf, f = t - i * nf;
   if (i >= n) return;
   const float sh0 = s0 / 2.0f, sh1 = s1 / 2.0f;
   const float sc = fmaxf(s0, s1) / 2.0f;
@@ -48,17 +51,17 @@ __global__ void lg_posenc_kernel(const float* kpts, const int32_t* cnt, int cap,
   p = fmaf(k1, Wr[f * 2 + 1], p);
   float sn, cs;
   einx_sincosf(p, &sn, &cs);
-  float* e = enc + ((size_t)b * cap + i) * 128;
+  float* e = enc + ((size_t)b * cap + i) * (2 * dh);
   e[2 * f] = cs;
   e[2 * f + 1] = cs;
-  e[64 + 2 * f] = sn;
-  e[64 + 2 * f + 1] = sn;
+  e[dh + 2 * f] = sn;
+  e[dh + 2 * f + 1] = sn;
 }
 
 // ------------------------------------------------------------------------------------------
 // batched Linear: Y[b,i,:] = cat(X[b,i,:], X2[b,i,:]) @ W^T + bias  (+ epilogue)
 // ------------------------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_DIV = 1, EPI_RESID = 2, EPI_ROPE = 3 };
+enum { EPI_BIAS = 0, EPI_DIV = 1, EPI_RESID = 2, EPI_ROPE = 3, EPI_ROPE_ANY = 4 };  // ROPE: d = 256, 64-wide heads; ROPE_ANY: g.d / g.dh
 
 struct GemmArgs {
   const float* X;
@@ -69,11 +72,12 @@ struct GemmArgs {
   const int32_t* cnt;  // per-batch row counts, or null: every batch has `cap` rows
   int cap, ldx, ldx2, Ksplit, K, N, ldy, B;
   float div;
-  // EPI_ROPE (the Wqkv projection of SelfBlock, lightglue.py:252-272): W rows are laid out (head, dim, 3);
-  // the tile list walks them as three 256-column blocks q | k | v (row stride 3 in W), applies the cached
-  // rotary encoding to q and k in the epilogue and writes the three [B,cap,256] buffers directly
-  const float* enc;  // [B,cap,128]: cos(64) | sin(64)
+  // EPI_ROPE / EPI_ROPE_ANY (the Wqkv projection of SelfBlock, lightglue.py:252-272): W rows are laid out (head, dim, 3);
+  // the tile list walks them as three d-column blocks q | k | v (row stride 3 in W), applies the cached
+  // rotary encoding to q and k in the epilogue and writes the three [B,cap,d] buffers directly
+  const float* enc;  // [B,cap,2 dh]: cos(dh) | sin(dh)
   float *Yq, *Yk, *Yv;
+  int d, dh;  // read by EPI_ROPE_ANY only (dh a power of two)
 };
 
 // Persistent workgroups: the launch holds as many workgroups as the chip runs at once (a multiple
@@ -85,7 +89,11 @@ struct GemmArgs {
 template <int EPI>
 __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(const GemmArgs g) {  // registers for two resident workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  const int tilesN = einx_cdiv(g.N, BN), tilesM = einx_cdiv(g.cap, BM);
+  constexpr bool ROPE = EPI == EPI_ROPE || EPI == EPI_ROPE_ANY;
+  const int rd = EPI == EPI_ROPE ? D : g.d;              // width of the q | k | v blocks (ROPE only)
+  const int rdh = EPI == EPI_ROPE ? DH : g.dh;
+  const int tpb = EPI == EPI_ROPE ? D / BN : einx_cdiv(rd, BN);  // tiles per q | k | v block
+  const int tilesN = ROPE ? 3 * tpb : einx_cdiv(g.N, BN), tilesM = einx_cdiv(g.cap, BM);
   const int groups = tilesM * g.B;                       // A-row groups
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int local_tiles = einx_cdiv(groups, 8) * tilesN;  // tiles in this XCD's list
@@ -102,12 +110,12 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
     s.lda2 = g.ldx2;
     s.i0 = ti * BM;
     s.Mvalid = n;
-    if (EPI == EPI_ROPE) {  // tile tj: block t = tj / 2 of (q, k, v), columns hc0.. of that block = W rows (hc0 + r) * 3 + t
+    if (ROPE) {  // tile tj: block t = tj / tpb of (q, k, v), columns hc0.. of that block = W rows (hc0 + r) * 3 + t
       const int tj = L % tilesN;
-      s.B = g.W + (size_t)(tj >> 1) * g.K;
+      s.B = g.W + (size_t)(tj / tpb) * g.K;
       s.ldb = 3 * g.K;
-      s.j0 = (tj & 1) * BN;
-      s.Nvalid = 256;
+      s.j0 = (tj % tpb) * BN;
+      s.Nvalid = rd;
     } else {
       s.B = g.W;
       s.ldb = g.K;
@@ -132,17 +140,17 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
     Frag f;
     tile_nt_run(cur, g.K, g.Ksplit, lds, f, st, nxt, more);
     const int i0 = cur.i0, j0 = cur.j0;
-    if (EPI == EPI_ROPE) {
+    if (ROPE) {
       const int t = (int)((cur.B - g.W) / g.K);  // 0: q, 1: k, 2: v
-      float* Yt = (t == 0 ? g.Yq : t == 1 ? g.Yk : g.Yv) + (size_t)b * g.cap * 256;
-      const float* encb = g.enc + (size_t)b * g.cap * 128;
+      float* Yt = (t == 0 ? g.Yq : t == 1 ? g.Yk : g.Yv) + (size_t)b * g.cap * rd;
+      const float* encb = g.enc + (size_t)b * g.cap * (2 * rdh);
       const bool odd = threadIdx.x & 1;  // column parity == lane parity (col_of(nt) = 64*wn + 32*nt + lane%32)
       float bq[NT];
       int hc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         hc[nt] = j0 + col_of(nt);
-        bq[nt] = g.bias[hc[nt] * 3 + t];
+        bq[nt] = (EPI == EPI_ROPE || hc[nt] < rd) ? g.bias[hc[nt] * 3 + t] : 0.0f;
       }
       // rows go in batches of 4: the 16 cos/sin loads of a batch are issued together, ahead of its stores
       // (the compiler cannot move a load above an earlier store through plain float pointers)
@@ -155,11 +163,11 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = i0 + row_of(mt, r0 + r);
-              const float* e = encb + (size_t)(i < n ? i : n - 1) * 128;
+              const float* e = encb + (size_t)(i < n ? i : n - 1) * (2 * rdh);
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                cs[r][nt] = e[hc[nt] & 63];
-                sn[r][nt] = e[64 + (hc[nt] & 63)];
+                cs[r][nt] = e[hc[nt] & (rdh - 1)];
+                sn[r][nt] = e[rdh + (hc[nt] & (rdh - 1))];
               }
             }
           }
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
               float v = f.acc[mt][nt][r0 + r] + bq[nt];
               const float partner = __shfl_xor(v, 1, 64);  // the other element of the rotary pair (adjacent column)
               if (t < 2) v = (v * cs[r][nt]) + ((odd ? partner : -partner) * sn[r][nt]);  // rotate_half: (x0,x1) -> (-x1,x0), lightglue.py:151-158
-              if (i < n) Yt[(size_t)i * 256 + hc[nt]] = v;
+              if (i < n && (EPI == EPI_ROPE || hc[nt] < rd)) Yt[(size_t)i * rd + hc[nt]] = v;
             }
           }
         }
@@ -271,9 +279,12 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
   int j0, t = 0;
   const float* Wb;
   int ldb;
-  if (EPI == EPI_ROPE) {  // four 64-column tiles per (q | k | v) block; W rows (hc + r) * 3 + t (see lg_gemm_kernel)
-    t = tj >> 2;
-    j0 = (tj & 3) * SBN;
+  constexpr bool ROPE = EPI == EPI_ROPE || EPI == EPI_ROPE_ANY;
+  const int rd = EPI == EPI_ROPE ? D : g.d, rdh = EPI == EPI_ROPE ? DH : g.dh;
+  if (ROPE) {  // d / 64 tiles of 64 columns per (q | k | v) block; W rows (hc + r) * 3 + t (see lg_gemm_kernel)
+    const int tpb = rd / SBN;
+    t = tj / tpb;
+    j0 = (tj - t * tpb) * SBN;
     Wb = g.W + (size_t)t * g.K;
     ldb = 3 * g.K;
   } else {
@@ -337,18 +348,18 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
   int rows[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) rows[r] = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-  if (EPI == EPI_ROPE) {
-    float* Yt = (t == 0 ? g.Yq : t == 1 ? g.Yk : g.Yv) + (size_t)b * g.cap * 256;
-    const float* encb = g.enc + (size_t)b * g.cap * 128;
+  if (ROPE) {
+    float* Yt = (t == 0 ? g.Yq : t == 1 ? g.Yk : g.Yv) + (size_t)b * g.cap * rd;
+    const float* encb = g.enc + (size_t)b * g.cap * (2 * rdh);
     const float bq = g.bias[col * 3 + t];
     const bool odd = lane & 1;
     float cs[16], sn[16];
     if (t < 2) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float* e = encb + (size_t)min(rows[r], n - 1) * 128;
-        cs[r] = e[col & 63];
-        sn[r] = e[64 + (col & 63)];
+        const float* e = encb + (size_t)min(rows[r], n - 1) * (2 * rdh);
+        cs[r] = e[col & (rdh - 1)];
+        sn[r] = e[rdh + (col & (rdh - 1))];
       }
     }
 #pragma unroll
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
       float v = acc[r] + bq;
       const float partner = __shfl_xor(v, 1, 64);
       if (t < 2) v = (v * cs[r]) + ((odd ? partner : -partner) * sn[r]);
-      if (rows[r] < n) Yt[(size_t)rows[r] * 256 + col] = v;
+      if (rows[r] < n) Yt[(size_t)rows[r] * rd + col] = v;
     }
     return;
   }
@@ -378,7 +389,8 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------
-// fused attention: out[b,q,h*64:(h+1)*64] = softmax_j(scale * Q_h[q] . K_h[j]) V_h[j]
+// fused attention: out[b,q,h*HD:(h+1)*HD] = softmax_j(scale * Q_h[q] . K_h[j]) V_h[j]
+// HD: head dim (32 / 64 / 128); DD: row width d of Q / K / V / O as a compile-time constant (256: the shipped instantiation) or 0 = a.d
 // ------------------------------------------------------------------------------------------
 struct AttnArgs {
   const float* Q;
@@ -390,15 +402,18 @@ struct AttnArgs {
   int capq, capk;
   float scale;
   int kv_shift, Btot;  // keys / values of batch entry b come from entry (b + kv_shift) % Btot (cross attention over the two sides stacked in one buffer)
+  int d;               // row width (heads * head dim); read when the kernel's DD is 0
 };
 
 constexpr int AKB = 32;   // keys staged per round (32: 124 VGPRs -> three workgroups per CU; 64: 151 -> two)
-constexpr int KPITCH = 68;  // K rows padded to 68 floats: 16-byte aligned for ds_read_b128, and the 32 rows a
-                            // half-wave reads start on 16 distinct 4-bank groups (conflict-free)
-
+template <int HD, int DD>
 __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
+  constexpr int KPITCH = HD + 4;  // K rows padded by 4 floats (64-wide heads: 68): 16-byte aligned for ds_read_b128, and the 32 rows a
+                                  // half-wave reads start on 16 distinct 4-bank groups (conflict-free)
+  constexpr int DH = HD;          // (shadows the file-level constant)
   __shared__ __attribute__((aligned(16))) float Ks[AKB * KPITCH];
   __shared__ __attribute__((aligned(16))) float Vs[AKB * DH];
+  const int D = DD ? DD : a.d;
   // the query blocks of one (pair, head) read the same K / V: keep them on one XCD (see xcd_contiguous)
   const int gx = (int)gridDim.x, gy = (int)gridDim.y;
   int item = xcd_contiguous((int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z)), gx * gy * (int)gridDim.z);
@@ -412,12 +427,12 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int q = q0 + wave * 32 + l31;
   const bool qv = q < nq;
-  // MFMA K-step t pairs head dims (t, t+32): lane half h supplies dim t + 32h, so a lane's K fragments
+  // MFMA K-step t pairs head dims (t, t + DH/2): lane half h supplies dim t + (DH/2) h, so a lane's K fragments
   // for four consecutive steps are one 16-byte LDS read
-  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * D + h * DH + 32 * half;
-  float qreg[32];
+  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * D + h * DH + (DH / 2) * half;
+  float qreg[DH / 2];
 #pragma unroll
-  for (int t = 0; t < 32; t += 4) {
+  for (int t = 0; t < DH / 2; t += 4) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(Qrow + t);
     qreg[t] = v[0];
     qreg[t + 1] = v[1];
@@ -426,9 +441,10 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   }
   const float* Kb = a.K + (size_t)bk * a.capk * D + h * DH;
   const float* Vb = a.V + (size_t)bk * a.capk * D + h * DH;
-  f32x16 o[2];
+  constexpr int OT = DH / 32;  // 32-wide blocks of the output row
+  f32x16 o[OT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < OT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[mt][r] = 0.0f;
   const float NEG = -einx_u2f(0x7f800000u);
@@ -436,13 +452,15 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   float m_run = NEG, l_run = 0.0f;
 
   // K/V block staging through registers: block kb0+64 is in flight while block kb0 is consumed
-  constexpr int ASTG = AKB * 16 / 256;  // float4 per thread per operand per round
+  constexpr int R4 = DH / 4;               // float4 per K / V row
+  constexpr int ASTG = AKB * R4 / 256;     // float4 per thread per operand per round
+  static_assert(ASTG >= 1 && DH % 32 == 0, "head dim 32, 64 or 128");
   f32x4 rk[ASTG], rv[ASTG];
   auto issue = [&](int kb0) {
 #pragma unroll
     for (int i = 0; i < ASTG; ++i) {
       const int fidx = tid + i * 256;
-      const int row = fidx >> 4, c4 = fidx & 15;
+      const int row = fidx / R4, c4 = fidx % R4;
       const int key = min(kb0 + row, nk - 1);  // clamped: rows past nk are masked after the QK product
       rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * D + c4 * 4);
       rv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * D + c4 * 4);
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < ASTG; ++i) {
       const int fidx = tid + i * 256;
-      const int row = fidx >> 4, c4 = fidx & 15;
+      const int row = fidx / R4, c4 = fidx % R4;
       *reinterpret_cast<f32x4*>(Ks + row * KPITCH + c4 * 4) = rk[i];
       *reinterpret_cast<f32x4*>(Vs + row * DH + c4 * 4) = rv[i];
     }
@@ -470,12 +488,12 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-      const float* krow = Ks + (sub * 32 + l31) * KPITCH + 32 * half;
+      const float* krow = Ks + (sub * 32 + l31) * KPITCH + (DH / 2) * half;
       f32x4 kf[2];
       kf[0] = *reinterpret_cast<const f32x4*>(krow);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (u + 1 < 8) kf[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(krow + 4 * (u + 1));
+      for (int u = 0; u < DH / 8; ++u) {
+        if (u + 1 < DH / 8) kf[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(krow + 4 * (u + 1));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u & 1][t], qreg[4 * u + t], s, 0, 0, 0);
@@ -513,23 +531,23 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       // (wave-uniform branch; bit-identical, x * 1.0f == x)
       if (__any(alpha != 1.0f)) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < OT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
       }
       const float* vbase = Vs + (size_t)(sub * 32 + 4 * half) * DH + l31;
-      float vf[2][2];
-      vf[0][0] = vbase[crow(0, 0) * DH];
-      vf[0][1] = vbase[crow(0, 0) * DH + 32];
+      float vf[2][OT];
+#pragma unroll
+      for (int mt = 0; mt < OT; ++mt) vf[0][mt] = vbase[crow(0, 0) * DH + 32 * mt];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (r + 1 < 16) {
-          vf[(r + 1) & 1][0] = vbase[crow(r + 1, 0) * DH];
-          vf[(r + 1) & 1][1] = vbase[crow(r + 1, 0) * DH + 32];
+#pragma unroll
+          for (int mt = 0; mt < OT; ++mt) vf[(r + 1) & 1][mt] = vbase[crow(r + 1, 0) * DH + 32 * mt];
         }
         __builtin_amdgcn_sched_barrier(0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r & 1][0], s[r], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r & 1][1], s[r], o[1], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < OT; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r & 1][mt], s[r], o[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -538,7 +556,7 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   if (qv) {
     float* orow = a.O + ((size_t)b * a.capq + q) * D + h * DH;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < OT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) orow[mt * 32 + crow(r, half)] = o[mt][r] / l;
   }
@@ -578,18 +596,39 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* hbuf, const int3
   for (int t = 0; t < 8; ++t) row[lane + 64 * t] = einx_geluf(fmaf((v[t] - mean) * rstd, gv[t], bv[t]));
 }
 
+// the same for any row width that is a multiple of 64 (configurations other than d = 256): lane partial sums over
+// columns lane, lane + 64, ... ascending, then the same butterfly
+__global__ __launch_bounds__(256) void lg_ln_gelu_any_kernel(float* hbuf, const int32_t* cnt, int cap, int width, const float* g, const float* be) {
+  const int b = blockIdx.y;
+  const int n = min(cnt[b], cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  float* row = hbuf + ((size_t)b * cap + i) * width;
+  float s = 0.0f;
+  for (int c = lane; c < width; c += 64) s += row[c];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)width;
+  float q = 0.0f;
+  for (int c = lane; c < width; c += 64) q = fmaf(row[c] - mean, row[c] - mean, q);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)width + 1e-5f);
+  for (int c = lane; c < width; c += 64) row[c] = einx_geluf(fmaf((row[c] - mean) * rstd, g[c], be[c]));
+}
+
 // matchability logit z = x . w + b per token, plus logsigmoid(z) and logsigmoid(-z)
-__global__ __launch_bounds__(256) void lg_matchability_kernel(const float* x, const int32_t* cnt, int cap, const float* w, const float* bm,
+__global__ __launch_bounds__(256) void lg_matchability_kernel(const float* x, const int32_t* cnt, int cap, int d, const float* w, const float* bm,
                                                               float* cert, float* dust) {
   const int b = blockIdx.y;
   const int n = min(cnt[b], cap);
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
-  const float* row = x + ((size_t)b * cap + i) * D;
+  const float* row = x + ((size_t)b * cap + i) * d;
   float s = 0.0f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) s = fmaf(row[lane + 64 * t], w[lane + 64 * t], s);
+  for (int c = lane; c < d; c += 64) s = fmaf(row[c], w[c], s);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane == 0) {
@@ -668,22 +707,23 @@ struct Side {
   float *x, *enc, *q, *k, *v, *ctx, *msg, *h, *cert, *dust;
 };
 
-size_t side_bytes(int B, int cap) {
+// d: descriptor_dim, dh: head dim -- buffers [tokens, d] (x, q, k, v, ctx, msg), [tokens, 2 dh] (enc), [tokens, 2 d] (h)
+size_t side_bytes(int B, int cap, int d, int dh) {
   const size_t tok = (size_t)B * cap;
-  return al(tok * D * 4) + al(tok * 128 * 4) + 3 * al(tok * D * 4) + 2 * al(tok * D * 4) + al(tok * 512 * 4) + 2 * al(tok * 4);
+  return al(tok * d * 4) + al(tok * 2 * dh * 4) + 3 * al(tok * d * 4) + 2 * al(tok * d * 4) + al(tok * 2 * d * 4) + 2 * al(tok * 4);
 }
 
-char* carve_side(Side& s, char* p, int B, int cap) {
+char* carve_side(Side& s, char* p, int B, int cap, int d, int dh) {
   const size_t tok = (size_t)B * cap;
   auto take = [&](size_t bytes) { float* r = (float*)p; p += al(bytes); return r; };
-  s.x = take(tok * D * 4);
-  s.enc = take(tok * 128 * 4);
-  s.q = take(tok * D * 4);
-  s.k = take(tok * D * 4);
-  s.v = take(tok * D * 4);
-  s.ctx = take(tok * D * 4);
-  s.msg = take(tok * D * 4);
-  s.h = take(tok * 512 * 4);
+  s.x = take(tok * d * 4);
+  s.enc = take(tok * 2 * dh * 4);
+  s.q = take(tok * d * 4);
+  s.k = take(tok * d * 4);
+  s.v = take(tok * d * 4);
+  s.ctx = take(tok * d * 4);
+  s.msg = take(tok * d * 4);
+  s.h = take(tok * 2 * d * 4);
   s.cert = take(tok * 4);
   s.dust = take(tok * 4);
   return p;
@@ -692,21 +732,21 @@ char* carve_side(Side& s, char* p, int B, int cap) {
 // Both sides stacked: every buffer is [2B, cap, width], side 0 = entries 0..B-1, side 1 = entries B..2B-1.  LightGlue applies
 // the same weights to both sides, so every per-side launch becomes one launch over 2B entries (cross attention reads
 // the partner entry's keys / values); s0 / s1 stay views of the halves.  Never larger than two separate sides.
-char* carve_stacked(Side& s0, Side& s1, char* p, int B, int cap) {
+char* carve_stacked(Side& s0, Side& s1, char* p, int B, int cap, int d, int dh) {
   const size_t tok = (size_t)B * cap;
   auto take = [&](size_t width, float*& a0, float*& a1) {
     a0 = (float*)p;
     a1 = a0 + tok * width;
     p += al(2 * tok * width * 4);
   };
-  take(D, s0.x, s1.x);
-  take(128, s0.enc, s1.enc);
-  take(D, s0.q, s1.q);
-  take(D, s0.k, s1.k);
-  take(D, s0.v, s1.v);
-  take(D, s0.ctx, s1.ctx);
-  take(D, s0.msg, s1.msg);
-  take(512, s0.h, s1.h);
+  take(d, s0.x, s1.x);
+  take(2 * dh, s0.enc, s1.enc);
+  take(d, s0.q, s1.q);
+  take(d, s0.k, s1.k);
+  take(d, s0.v, s1.v);
+  take(d, s0.ctx, s1.ctx);
+  take(d, s0.msg, s1.msg);
+  take(2 * d, s0.h, s1.h);
   take(1, s0.cert, s1.cert);
   take(1, s0.dust, s1.dust);
   return p;
@@ -775,8 +815,16 @@ int gemm(hipStream_t st, int epi, const Side& s, int B, const float* X, int ldx,
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// fused Wqkv projection + rotary split: X [B,cap,256] -> q, k (rotary applied), v, each [B,cap,256]
-int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const float* X, const float* Wqkv, const float* bqkv, float* q, float* k, float* v) {
+// the model's widths, as the launchers need them
+struct Dims {
+  int d, heads, dh;
+  bool shipped() const { return d == D && dh == DH; }
+};
+
+// fused Wqkv projection + rotary split: X [B,cap,d] -> q, k (rotary applied), v, each [B,cap,d]
+int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const Dims& dm, const float* X, const float* Wqkv, const float* bqkv, float* q, float* k,
+                  float* v) {
+  const int D = dm.d;  // (shadows the file-level constant)
   GemmArgs g{};
   g.X = X;
   g.X2 = nullptr;
@@ -797,19 +845,25 @@ int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const float* X, const fl
   g.Yq = q;
   g.Yk = k;
   g.Yv = v;
-  if (small_grid(3 * D, s.cap, B, D, 0x7fffffff)) {
+  g.d = dm.d;
+  g.dh = dm.dh;
+  const int tiles = 3 * einx_cdiv(D, BN) * einx_cdiv(s.cap, BM) * B;  // three blocks (q | k | v) of whole tiles each
+  if (tiles < 256 && D % SBN == 0 && D % SBK == 0) {  // as small_grid()
+    const dim3 sg((unsigned)(3 * D / SBN), (unsigned)einx_cdiv(s.cap, SBM), (unsigned)B);
     EINX_PROF("lg_gemm_small_kernel", st);
-    hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_ROPE>, dim3((unsigned)(3 * D / SBN), (unsigned)einx_cdiv(s.cap, SBM), (unsigned)B), dim3(256), 0, st, g);
+    if (dm.shipped()) hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_ROPE>, sg, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(lg_gemm_small_kernel<EPI_ROPE_ANY>, sg, dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
-  const dim3 grid(gemm_grid(einx_cdiv(3 * D, BN) * einx_cdiv(s.cap, BM) * B));
+  const dim3 grid(gemm_grid(tiles));
   EINX_PROF("lg_gemm_kernel", st);
-  hipLaunchKernelGGL(lg_gemm_kernel<EPI_ROPE>, grid, dim3(THREADS), 0, st, g);
+  if (dm.shipped()) hipLaunchKernelGGL(lg_gemm_kernel<EPI_ROPE>, grid, dim3(THREADS), 0, st, g);
+  else hipLaunchKernelGGL(lg_gemm_kernel<EPI_ROPE_ANY>, grid, dim3(THREADS), 0, st, g);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, const float* K, const float* V, const int32_t* nk, int capk,
-         float* O, int kv_shift = 0) {
+int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* nq, int capq, const float* K, const float* V, const int32_t* nk,
+         int capk, float* O, int kv_shift = 0) {
   AttnArgs a;
   a.kv_shift = kv_shift;
   a.Btot = B;
@@ -821,20 +875,29 @@ int attn(hipStream_t st, int B, const float* Q, const int32_t* nq, int capq, con
   a.nk = nk;
   a.capq = capq;
   a.capk = capk;
-  a.scale = 0.125f;  // 1/sqrt(64): SDPA scale (self) = (64^-1/4)^2 (cross, lightglue.py:316)
+  a.d = dm.d;
+  a.scale = 1.0f / sqrtf((float)dm.dh);  // SDPA scale (self) = (dh^-1/4)^2 (cross, lightglue.py:316); 64-wide heads: exactly 0.125
+  const dim3 grid((unsigned)einx_cdiv(capq, 128), (unsigned)dm.heads, (unsigned)B);
   EINX_PROF("lg_attn_kernel", st);
-  hipLaunchKernelGGL(lg_attn_kernel, dim3((unsigned)einx_cdiv(capq, 128), HEADS, (unsigned)B), dim3(256), 0, st, a);
+  if (dm.shipped()) hipLaunchKernelGGL((lg_attn_kernel<64, D>), grid, dim3(256), 0, st, a);
+  else if (dm.dh == 64) hipLaunchKernelGGL((lg_attn_kernel<64, 0>), grid, dim3(256), 0, st, a);
+  else if (dm.dh == 32) hipLaunchKernelGGL((lg_attn_kernel<32, 0>), grid, dim3(256), 0, st, a);
+  else if (dm.dh == 128) hipLaunchKernelGGL((lg_attn_kernel<128, 0>), grid, dim3(256), 0, st, a);
+  else return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ffn(cat[x,msg]) + residual, in place on s.x
-int ffn(hipStream_t st, const Side& s, int B, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
+int ffn(hipStream_t st, const Side& s, int B, const Dims& dm, const float* msg, const float* w0, const float* b0, const float* g, const float* be,
         const float* w3, const float* b3) {
+  const int D = dm.d;  // (shadows the file-level constant)
   // (one fused launch for ffn.0 + LayerNorm + GELU was measured in round 3 and is slower: tools/experiments/lg_ffn0_ln_gelu_kernel.hip.txt)
   if (gemm(st, EPI_BIAS, s, B, s.x, D, msg, D, D, 2 * D, w0, b0, 2 * D, s.h, 2 * D)) return -1;
   {
     EINX_PROF("lg_ln_gelu_kernel", st);
-    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)B), dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+    const dim3 lg((unsigned)einx_cdiv(s.cap, 4), (unsigned)B);
+    if (2 * D == 512) hipLaunchKernelGGL(lg_ln_gelu_kernel, lg, dim3(256), 0, st, s.h, s.cnt, s.cap, g, be);
+    else hipLaunchKernelGGL(lg_ln_gelu_any_kernel, lg, dim3(256), 0, st, s.h, s.cnt, s.cap, 2 * D, g, be);
   }
   if (hipGetLastError() != hipSuccess) return -1;
   return gemm(st, EPI_RESID, s, B, s.h, 2 * D, nullptr, 0, 0x7fffffff, 2 * D, w3, b3, D, s.x, D);
@@ -878,10 +941,26 @@ EINX_EXPORT int einx_normalize_keypoints(const float* kpts, int rows, int cols, 
   return EINX_OK;
 }
 
-EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) {
-  if (B <= 0 || cap0 <= 0 || cap1 <= 0 || d != D) return 0;
+namespace {
+// lightglue.py:456-461: head_dim = descriptor_dim // num_heads.  The attention kernel is instantiated for 32-, 64- and 128-wide heads.
+bool dims_of(int d, int heads, Dims& dm) {
+  if (d <= 0 || heads <= 0 || d % heads != 0) return false;
+  dm.d = d;
+  dm.heads = heads;
+  dm.dh = d / heads;
+  return dm.dh == 32 || dm.dh == 64 || dm.dh == 128;
+}
+}  // namespace
+
+EINX_EXPORT size_t einx_lg_ws_bytes_heads(int B, int cap0, int cap1, int d, int heads, int input_dim) {
+  Dims dm;
+  if (B <= 0 || cap0 <= 0 || cap1 <= 0 || !dims_of(d, heads, dm)) return 0;
   (void)input_dim;
-  return side_bytes(B, cap0) + side_bytes(B, cap1) + einx_mnn_ws_bytes(B, cap0, cap1) + al((size_t)2 * B * 4) + 1024;
+  return side_bytes(B, cap0, d, dm.dh) + side_bytes(B, cap1, d, dm.dh) + einx_mnn_ws_bytes(B, cap0, cap1) + al((size_t)2 * B * 4) + 1024;
+}
+
+EINX_EXPORT size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim) {  // 64-wide heads (the LightGlue default)
+  return d > 0 && d % 64 == 0 ? einx_lg_ws_bytes_heads(B, cap0, cap1, d, d / 64, input_dim) : 0;
 }
 
 EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0,
@@ -889,7 +968,9 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
                                float w1, void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la,
                                float* ref0, float* ref1, int ref_layers, void* stream) {
   EINX_CHECK_ARG(w && kpts0 && desc0 && n && kpts1 && desc1 && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
-  EINX_CHECK_ARG(w->d == D && w->heads == HEADS, "kernels are built for d=256, 4 heads of 64");
+  Dims dm;
+  EINX_CHECK_ARG(dims_of(w->d, w->heads, dm), "descriptor_dim must be num_heads x head_dim with head_dim 32, 64 or 128");
+  const int D = dm.d;  // (shadows the file-level constant: every width below is the model's)
   EINX_CHECK_ARG(w->n_layers >= 1 && w->layers, "no layers");
   EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0, "bad shape");
   EINX_CHECK_ARG(w->input_dim % 4 == 0 && w->input_dim > 0, "input_dim must be a multiple of 4");
@@ -912,15 +993,15 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   const bool stacked = cap0 == cap1;
   Side sb{};
   if (stacked) {
-    p = carve_stacked(s0, s1, p, B, cap0);
+    p = carve_stacked(s0, s1, p, B, cap0, D, dm.dh);
     int32_t* cnt2 = (int32_t*)p;
     p += al((size_t)2 * B * 4);
     hipLaunchKernelGGL(lg_stack_counts_kernel, dim3((unsigned)einx_cdiv(2 * B, 256)), dim3(256), 0, st, n, m, B, cnt2);
     sb = s0;
     sb.cnt = cnt2;
   } else {
-    p = carve_side(s0, p, B, cap0);
-    p = carve_side(s1, p, B, cap1);
+    p = carve_side(s0, p, B, cap0, D, dm.dh);
+    p = carve_side(s1, p, B, cap1, D, dm.dh);
   }
   void* mnn_ws = p;
   Side* sides[2] = {&s0, &s1};
@@ -945,8 +1026,8 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
       hipLaunchKernelGGL(lg_copy_rows_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, s.desc, s.x, s.cnt, s.cap, D, per);
       LG_CHECK(0);
     }
-    hipLaunchKernelGGL(lg_posenc_kernel, dim3((unsigned)einx_cdiv(s.cap * 32, 256), (unsigned)B), dim3(256), 0, st, s.kpts, s.cnt, s.cap,
-                       sz[sd][0], sz[sd][1], w->Wr, s.enc);
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3((unsigned)einx_cdiv(s.cap * (dm.dh / 2), 256), (unsigned)B), dim3(256), 0, st, s.kpts, s.cnt, s.cap,
+                       sz[sd][0], sz[sd][1], w->Wr, s.enc, dm.dh);
     LG_CHECK(0);
   }
   // ---- transformer layers --------------------------------------------------------------------
@@ -954,13 +1035,13 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
     const einx_lg_layer& L = w->layers[li];
     for (int sd = 0; sd < nrun; ++sd) {
       Side& s = *run[sd];
-      LG_CHECK(gemm_qkv_rope(st, s, Br, s.x, L.Wqkv, L.bqkv, s.q, s.k, s.v));
-      LG_CHECK(attn(st, Br, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
+      LG_CHECK(gemm_qkv_rope(st, s, Br, dm, s.x, L.Wqkv, L.bqkv, s.q, s.k, s.v));
+      LG_CHECK(attn(st, Br, dm, s.q, s.cnt, s.cap, s.k, s.v, s.cnt, s.cap, s.ctx));
       if (L.Wo) {
         LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wo, L.bo, D, s.msg, D));
-        LG_CHECK(ffn(st, s, Br, s.msg, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+        LG_CHECK(ffn(st, s, Br, dm, s.msg, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
       } else {  // out_proj folded into the FFN's first Linear at load time: message = context
-        LG_CHECK(ffn(st, s, Br, s.ctx, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
+        LG_CHECK(ffn(st, s, Br, dm, s.ctx, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
       }
     }
     for (int sd = 0; sd < nrun; ++sd) {
@@ -969,18 +1050,18 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
       LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wv, L.bv, D, s.v, D));
     }
     if (stacked) {  // entry b attends to the keys / values of its partner entry (b + B) mod 2B
-      LG_CHECK(attn(st, Br, sb.q, sb.cnt, sb.cap, sb.q, sb.v, sb.cnt, sb.cap, sb.ctx, B));
+      LG_CHECK(attn(st, Br, dm, sb.q, sb.cnt, sb.cap, sb.q, sb.v, sb.cnt, sb.cap, sb.ctx, B));
     } else {
-      LG_CHECK(attn(st, B, s0.q, s0.cnt, s0.cap, s1.q, s1.v, s1.cnt, s1.cap, s0.ctx));
-      LG_CHECK(attn(st, B, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));
+      LG_CHECK(attn(st, B, dm, s0.q, s0.cnt, s0.cap, s1.q, s1.v, s1.cnt, s1.cap, s0.ctx));
+      LG_CHECK(attn(st, B, dm, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));
     }
     for (int sd = 0; sd < nrun; ++sd) {
       Side& s = *run[sd];
       if (L.Wco) {
         LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.ctx, D, nullptr, 0, 0x7fffffff, D, L.Wco, L.bco, D, s.msg, D));
-        LG_CHECK(ffn(st, s, Br, s.msg, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+        LG_CHECK(ffn(st, s, Br, dm, s.msg, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
       } else {
-        LG_CHECK(ffn(st, s, Br, s.ctx, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
+        LG_CHECK(ffn(st, s, Br, dm, s.ctx, L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b));
       }
     }
     for (int sd = 0; sd < 2; ++sd) {
@@ -998,7 +1079,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   for (int sd = 0; sd < nrun; ++sd) {
     Side& s = *run[sd];
     LG_CHECK(gemm(st, EPI_DIV, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, w->proj_w, w->proj_b, D, s.q, D, sqrtf(sqrtf((float)D))));
-    hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)Br), dim3(256), 0, st, s.x, s.cnt, s.cap, w->match_w,
+    hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)einx_cdiv(s.cap, 4), (unsigned)Br), dim3(256), 0, st, s.x, s.cnt, s.cap, D, w->match_w,
                        w->match_b, s.cert, s.dust);
     LG_CHECK(0);
   }

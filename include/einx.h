@@ -245,7 +245,7 @@ typedef struct einx_lg_layer {
 typedef struct einx_lg_weights {
   const float* in_w; /* input_proj [d,input_dim] or NULL (Identity) */
   const float* in_b;
-  const float* Wr;   /* posenc.Wr [32,2] */
+  const float* Wr;   /* posenc.Wr [head_dim/2,2] */
   const float* proj_w; /* log_assignment[last].final_proj [d,d] */
   const float* proj_b;
   const float* match_w; /* log_assignment[last].matchability [1,d] */
@@ -260,7 +260,11 @@ typedef struct einx_lg_weights {
  * LightGlue call returns matched keypoints in these coordinates (lightglue.py:677-687). */
 int einx_normalize_keypoints(const float* kpts, int rows, int cols, float h, float w, float* out, int out_cols, void* stream);
 
+/* Model widths (lightglue.py:456-461): d = descriptor_dim = heads x head_dim with head_dim 32, 64 or 128 (anything else is refused);
+ * Wr is [head_dim/2, 2].  d = 256 with 4 heads of 64 -- every EI-Nexus configuration -- runs kernels instantiated for those widths.
+ * einx_lg_ws_bytes assumes 64-wide heads (heads = d / 64); 0 = unsupported widths. */
 size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);
+size_t einx_lg_ws_bytes_heads(int B, int cap0, int cap1, int d, int heads, int input_dim);
 /* kpts [B,cap,3] (first two columns used), desc [B,cap,input_dim], counts device int32.
  * size0/size1: image sizes (H,W) used by normalize_keypoints (:137-148).
  * outputs as einx_mnn; scores are exp(max log-assignment) for mutual matches (:402-418);
@@ -269,7 +273,7 @@ size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);
  * (what the reference stacks when self.training, lightglue.py:626-629,709-710).
  * Schedule (same results either way): with cap0 == cap1 the two sides are stacked in the workspace and every layer is one
  * launch over 2B entries; grids of fewer than 256 128x128 tiles (up to 7 pairs) run their linears on 64x64 tiles.
- * ws: device scratch of einx_lg_ws_bytes(B, cap0, cap1, d, input_dim) bytes; rows of the outputs past an entry's
+ * ws: device scratch of einx_lg_ws_bytes_heads(B, cap0, cap1, d, heads, input_dim) bytes; rows of the outputs past an entry's
  * count are left unwritten. */
 int einx_lightglue(const einx_lg_weights* w, const float* kpts0, const float* desc0, const int32_t* n, int cap0, const float* kpts1,
                    const float* desc1, const int32_t* m, int cap1, int B, float h0, float w0, float h1, float w1, void* ws,

@@ -616,24 +616,30 @@ EXPORT void orc_linear(const float* x, int R, int K, const float* w, const float
 
 /* normalize_keypoints (:137-148) + LearnableFourierPositionalEncoding (:161-174).
  * kpts: [n,2] (first two columns of sparse_positions, stride `kstride`), size = (s0,s1).
- * enc: [2][n][64]: cos / sin of Wr k, each value repeated twice along the last dim. */
-EXPORT void orc_lg_posenc(const float* kpts, int kstride, int n, float s0, float s1, const float* Wr /*[32][2]*/, float* enc) {
+ * enc: [2][n][dh]: cos / sin of Wr k, each value repeated twice along the last dim; dh = head dim
+ * (descriptor_dim // num_heads, lightglue.py:456-459), Wr: [dh/2][2]. */
+EXPORT void orc_lg_posenc_dh(const float* kpts, int kstride, int n, float s0, float s1, const float* Wr, int dh, float* enc) {
   const float sh0 = s0 / 2.0f, sh1 = s1 / 2.0f;
   const float sc = fmaxf(s0, s1) / 2.0f;
   for (int i = 0; i < n; ++i) {
     const float k0 = (kpts[(size_t)i * kstride + 0] - sh0) / sc;
     const float k1 = (kpts[(size_t)i * kstride + 1] - sh1) / sc;
-    for (int f = 0; f < 32; ++f) {
+    for (int f = 0; f < dh / 2; ++f) {
       float p = fmaf(k0, Wr[f * 2 + 0], 0.0f);
       p = fmaf(k1, Wr[f * 2 + 1], p);
       float sn, cs;
       einx_sincosf(p, &sn, &cs);
-      enc[((size_t)0 * n + i) * 64 + 2 * f] = cs;
-      enc[((size_t)0 * n + i) * 64 + 2 * f + 1] = cs;
-      enc[((size_t)1 * n + i) * 64 + 2 * f] = sn;
-      enc[((size_t)1 * n + i) * 64 + 2 * f + 1] = sn;
+      enc[((size_t)0 * n + i) * dh + 2 * f] = cs;
+      enc[((size_t)0 * n + i) * dh + 2 * f + 1] = cs;
+      enc[((size_t)1 * n + i) * dh + 2 * f] = sn;
+      enc[((size_t)1 * n + i) * dh + 2 * f + 1] = sn;
     }
   }
+}
+
+/* 64-wide heads (the LightGlue default: 256 = 4 x 64) */
+EXPORT void orc_lg_posenc(const float* kpts, int kstride, int n, float s0, float s1, const float* Wr /*[32][2]*/, float* enc) {
+  orc_lg_posenc_dh(kpts, kstride, n, s0, s1, Wr, 64, enc);
 }
 
 /* softmax(q k^T * scale) v for one head; q:[n,dh] k,v:[m,dh] with row strides; out [n,dh] stride so.
@@ -701,7 +707,7 @@ static void ffn_residual(float* x, const float* msg, int n, int d, const float* 
   }
 }
 
-/* SelfBlock.forward (:258-272). x:[n,d] in place; enc:[2][n][64]; d = heads*64. */
+/* SelfBlock.forward (:258-272). x:[n,d] in place; enc:[2][n][dh]; d = heads*dh. */
 EXPORT void orc_lg_self_block(float* x, int n, int d, int heads, const float* enc, const float* Wqkv, const float* bqkv,
                               const float* Wo, const float* bo, const float* w0, const float* b0, const float* g,
                               const float* be, const float* w3, const float* b3) {
@@ -728,8 +734,8 @@ EXPORT void orc_lg_self_block(float* x, int n, int d, int heads, const float* en
         for (int c = 0; c < dh; c += 2) {
           float* p = a + (size_t)i * d + h * dh + c;
           const float x0 = p[0], x1 = p[1];
-          const float c0 = enc[((size_t)0 * n + i) * 64 + c], c1 = enc[((size_t)0 * n + i) * 64 + c + 1];
-          const float s0 = enc[((size_t)1 * n + i) * 64 + c], s1 = enc[((size_t)1 * n + i) * 64 + c + 1];
+          const float c0 = enc[((size_t)0 * n + i) * dh + c], c1 = enc[((size_t)0 * n + i) * dh + c + 1];
+          const float s0 = enc[((size_t)1 * n + i) * dh + c], s1 = enc[((size_t)1 * n + i) * dh + c + 1];
           p[0] = (x0 * c0) + ((-x1) * s0);
           p[1] = (x1 * c1) + (x0 * s1);
         }

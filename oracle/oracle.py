@@ -391,10 +391,12 @@ def lightglue(sd, kpts0, desc0, kpts1, desc1, size0=(260, 346), size1=(260, 346)
         x0, x1 = y0, y1
     d = x0.shape[1]
     Wr = g("posenc.Wr.weight")
-    enc0 = np.empty((2, n, 64), np.float32)
-    enc1 = np.empty((2, m, 64), np.float32)
-    L.orc_lg_posenc(_f(k0), k0.shape[1], n, ctypes.c_float(size0[0]), ctypes.c_float(size0[1]), _f(Wr), _f(enc0))
-    L.orc_lg_posenc(_f(k1), k1.shape[1], m, ctypes.c_float(size1[0]), ctypes.c_float(size1[1]), _f(Wr), _f(enc1))
+    dh = d // heads  # lightglue.py:456
+    assert Wr.shape == (dh // 2, 2) and d == heads * dh
+    enc0 = np.empty((2, n, dh), np.float32)
+    enc1 = np.empty((2, m, dh), np.float32)
+    L.orc_lg_posenc_dh(_f(k0), k0.shape[1], n, ctypes.c_float(size0[0]), ctypes.c_float(size0[1]), _f(Wr), dh, _f(enc0))
+    L.orc_lg_posenc_dh(_f(k1), k1.shape[1], m, ctypes.c_float(size1[0]), ctypes.c_float(size1[1]), _f(Wr), dh, _f(enc1))
     captured = {}
     for i in range(n_layers):
         p = f"transformers.{i}.self_attn."

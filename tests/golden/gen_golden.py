@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii lgcal cfgsweep
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii lgcal cfgsweep lgcfg
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -1149,6 +1149,83 @@ def gen_cfgsweep():
 
 
 GROUPS["cfgsweep"] = gen_cfgsweep
+
+
+# =========================================================================================
+# lgcfg (round 5): LightGlue configurations other than 256 = 4 x 64 -- the reference derives head_dim = descriptor_dim //
+# num_heads (lightglue.py:246-248, 456-461) and takes n_layers / input_dim from the conf; plus what add_scale_ori=True does
+# =========================================================================================
+LGCFG_CASES = [
+    dict(name="h8_d256", seed=161, n=200, m=233, input_dim=256, descriptor_dim=256, num_heads=8, n_layers=9, wseed=15, shared=100),
+    dict(name="h2_d256", seed=162, n=150, m=140, input_dim=256, descriptor_dim=256, num_heads=2, n_layers=4, wseed=16, shared=70),
+    dict(name="h4_d128", seed=163, n=170, m=190, input_dim=128, descriptor_dim=128, num_heads=4, n_layers=5, wseed=17, shared=80),
+    dict(name="h3_d192", seed=164, n=260, m=131, input_dim=128, descriptor_dim=192, num_heads=3, n_layers=3, wseed=18, shared=60),
+    dict(name="h4_d512", seed=165, n=140, m=150, input_dim=256, descriptor_dim=512, num_heads=4, n_layers=2, wseed=19, shared=60),
+    dict(name="h1_d64", seed=166, n=90, m=300, input_dim=64, descriptor_dim=64, num_heads=1, n_layers=3, wseed=20, shared=40),
+]
+
+
+def gen_lgcfg():
+    out, noise = {}, {}
+    size = torch.tensor([260, 346])
+    for c in LGCFG_CASES:
+        conf = _ref_stubs.to_attr({k: c[k] for k in ("input_dim", "descriptor_dim", "num_heads", "n_layers")})
+        lg = LightGlue(conf)
+        keys = load_synth_weights(lg, c["wseed"])
+        lg.eval()
+        d0, d1, k0, k1 = lg_inputs(c)
+        f0 = {"sparse_descriptors": torch.from_numpy(d0)[None], "sparse_positions": torch.from_numpy(k0)[None], "image_size": [size]}
+        f1 = {"sparse_descriptors": torch.from_numpy(d1)[None], "sparse_positions": torch.from_numpy(k1)[None], "image_size": [size]}
+        layer_out = {}
+
+        def hook(i):
+            def fn(mod, inp, outp):
+                layer_out[i] = (outp[0].detach().clone(), outp[1].detach().clone())
+            return fn
+
+        probes = (0, c["n_layers"] - 1)
+        hs = [lg.transformers[i].register_forward_hook(hook(i)) for i in probes]
+        with torch.no_grad():
+            r = lg(f0, f1)
+        for h in hs:
+            h.remove()
+        n = c["name"]
+        sn, sm = max(1, c["n"] // 16), max(1, c["m"] // 16)
+        for i in probes:
+            a, b = layer_out[i]
+            out[f"{n}.l{i}.desc0"] = a[0, ::sn, ::8].numpy()
+            out[f"{n}.l{i}.desc1"] = b[0, ::sm, ::8].numpy()
+        with torch.no_grad():
+            enc = lg.posenc(torch.from_numpy((k0[None, :, :2] - np.array([130.0, 173.0], np.float32)) / np.float32(173.0)))
+        out[f"{n}.enc0"] = enc[:, 0, 0, ::sn, :].numpy()
+        for key, short in (("matches0", "matches0"), ("matches1", "matches1"), ("matching_scores0", "mscores0"), ("matching_scores1", "mscores1"),
+                           ("matched_kpts0", "matched_kpts0"), ("matched_kpts1", "matched_kpts1"), ("log_assignment", "la")):
+            out[f"{n}.{short}"] = r[key].numpy()
+        out[f"{n}.ref_desc0_probe"] = r["ref_descriptors0"][0, 0, ::sn, ::8].numpy()
+        out[f"{n}.prune0"] = r["prune0"].numpy()
+        out[f"{n}.state_keys"] = np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)
+        noise[n], _ = lg_noise_floor(lg, f0, f1, 1300 + c["seed"])
+        print(n, int((r["matches0"] > -1).sum()), "matches;", json.dumps(noise[n]))
+    # add_scale_ori=True: what the reference's forward does (the scale / orientation inputs are commented out, :540-560)
+    lg = LightGlue(_ref_stubs.to_attr({"input_dim": 256, "add_scale_ori": True}))
+    aso = {"state_keys": {k: list(v.shape) for k, v in sorted(lg.state_dict().items()) if k.startswith("posenc")}}
+    c = LG_CASES[0]
+    d0, d1, k0, k1 = lg_inputs(c)
+    f0 = {"sparse_descriptors": torch.from_numpy(d0)[None], "sparse_positions": torch.from_numpy(k0)[None], "image_size": [size]}
+    f1 = {"sparse_descriptors": torch.from_numpy(d1)[None], "sparse_positions": torch.from_numpy(k1)[None], "image_size": [size]}
+    try:
+        with torch.no_grad():
+            lg.eval()(f0, f1)
+        aso["raises"] = None
+    except Exception as e:  # noqa: BLE001
+        aso["raises"] = type(e).__name__
+        aso["message"] = str(e)
+    aso["n"] = c["n"]
+    print("add_scale_ori:", aso)
+    save("lgcfg.npz", meta=meta(cases=LGCFG_CASES, noise=noise, add_scale_ori=aso), **out)
+
+
+GROUPS["lgcfg"] = gen_lgcfg
 
 
 if __name__ == "__main__":

@@ -83,7 +83,9 @@ def lg_noise(tag):
     global _LG_NOISE
     if _LG_NOISE is None:
         z = np.load(os.path.join(GOLDEN, "lgcal.npz"))
-        _LG_NOISE = json.loads(bytes(z["meta"]).decode())["noise"]
+        _LG_NOISE = dict(json.loads(bytes(z["meta"]).decode())["noise"])
+        z = np.load(os.path.join(GOLDEN, "lgcfg.npz"))  # other widths (round 5): tags "lgcfg.<case>"
+        _LG_NOISE.update({"lgcfg." + k: v for k, v in json.loads(bytes(z["meta"]).decode())["noise"].items()})
     return _LG_NOISE[tag]
 
 
@@ -99,7 +101,11 @@ def la_bound(tag):
     implementations each sit up to one noise floor from the exact value, so 2 x floor is what their difference can reach; the
     ulp term is the head-room (round 4 had none: one comparison sat at 96 % of its bound; now every recorded one is < 80 %)."""
     n = lg_noise(tag)
-    return max(1e-4, LA_NOISE_FACTOR * max(n["la_perm"], n["la_threads"]) + LA_ULPS * float(np.spacing(np.float32(n["la_absmax"]))))
+    # "lgcfg." fixtures (other widths, few layers): their floor is the maximum over only three permutations of a SHORT model
+    # (5e-5 .. 2e-4), and the k-ordered chains of the oracle / the kernels round more than torch's blocked sums as K grows
+    # (K = 1024 at d = 512: the oracle sits 1.6e-4 from the reference there); 4 x floor, largest recorded use 0.73
+    factor = 2 * LA_NOISE_FACTOR if tag.startswith("lgcfg.") else LA_NOISE_FACTOR
+    return max(1e-4, factor * max(n["la_perm"], n["la_threads"]) + LA_ULPS * float(np.spacing(np.float32(n["la_absmax"]))))
 
 
 def la_bound_e2e(tag, upstream=None):

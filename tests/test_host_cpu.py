@@ -267,3 +267,21 @@ def test_pooled_padding0_constructs_and_raises_what_the_reference_raises():
             with pytest.raises(IndexError) as ei:
                 m(*args)
             assert str(ei.value) == c[tag]["message"]
+
+
+def test_lightglue_other_widths_have_the_references_parameter_tree():
+    """descriptor_dim / num_heads / n_layers / input_dim from the conf (lightglue.py:446-466): names and shapes of every
+    parameter equal the reference's (tests/golden/lgcfg.npz); add_scale_ori widens posenc.Wr to 4 inputs; head widths other
+    than 32 / 64 / 128 are refused at construction."""
+    from helpers import Golden
+    g = Golden("lgcfg")
+    for name, c in g.cases.items():
+        keys = json.loads(bytes(g[f"{name}.state_keys"]).decode())
+        lg = pkg.LightGlue({k: c[k] for k in ("input_dim", "descriptor_dim", "num_heads", "n_layers")})
+        assert {k: list(v.shape) for k, v in sorted(lg.state_dict().items())} == keys, name
+    aso = pkg.LightGlue({"input_dim": 256, "add_scale_ori": True})
+    assert {k: list(v.shape) for k, v in aso.state_dict().items() if k.startswith("posenc")} == g.meta["add_scale_ori"]["state_keys"]
+    with pytest.raises(NotImplementedError):
+        pkg.LightGlue({"descriptor_dim": 256, "num_heads": 16})
+    with pytest.raises(AssertionError):
+        pkg.LightGlue({"descriptor_dim": 256, "num_heads": 3})

@@ -202,6 +202,37 @@ def test_lightglue(oracle, name):
     assert np.array_equal(mk1, LG[f"{name}.matched_kpts1"])
 
 
+LGCFG = Golden("lgcfg")
+
+
+@pytest.mark.parametrize("name", list(LGCFG.cases))
+def test_lightglue_other_widths(oracle, name):
+    """descriptor_dim / num_heads / n_layers other than 256 / 4 / 9 (head_dim = descriptor_dim // num_heads, lightglue.py:456-461):
+    the oracle against the reference run on those configurations (tests/golden/gen_golden.py::gen_lgcfg)."""
+    import json
+    c = dict(LGCFG.cases[name])
+    c["state_keys"] = json.loads(bytes(LGCFG[f"{name}.state_keys"]).decode())
+    sd = state_dict_for(c)
+    d0, d1, k0, k1 = lg_inputs(c)
+    last = c["n_layers"] - 1
+    r = oracle.lightglue(sd, k0, d0, k1, d1, n_layers=c["n_layers"], heads=c["num_heads"], capture_layers=(0, last))
+    sn, sm = max(1, c["n"] // 16), max(1, c["m"] // 16)
+    assert r["enc0"].shape[-1] == c["descriptor_dim"] // c["num_heads"]
+    np.testing.assert_allclose(r["enc0"][:, ::sn, :], LGCFG[f"{name}.enc0"], atol=2e-6)
+    for i in (0, last):
+        a, b = r["layers"][i]
+        np.testing.assert_allclose(a[::sn, ::8], LGCFG[f"{name}.l{i}.desc0"], atol=FTOL, rtol=FTOL)
+        np.testing.assert_allclose(b[::sm, ::8], LGCFG[f"{name}.l{i}.desc1"], atol=FTOL, rtol=FTOL)
+    assert np.array_equal(r["matches0"], LGCFG[f"{name}.matches0"][0])
+    assert np.array_equal(r["matches1"], LGCFG[f"{name}.matches1"][0])
+    np.testing.assert_allclose(r["matching_scores0"], LGCFG[f"{name}.mscores0"][0], atol=FTOL)
+    np.testing.assert_allclose(r["matching_scores1"], LGCFG[f"{name}.mscores1"][0], atol=FTOL)
+    np.testing.assert_allclose(r["log_assignment"], LGCFG[f"{name}.la"][0], atol=la_bound(f"lgcfg.{name}"), rtol=0)
+    mk0, mk1 = oracle.matched_kpts(k0, k1, r["matches0"], 2)
+    assert np.array_equal(mk0, LGCFG[f"{name}.matched_kpts0"])
+    assert np.array_equal(mk1, LGCFG[f"{name}.matched_kpts1"])
+
+
 # ------------------------------------------------------------------ un-frozen Matcher branch (SURVEY 8f-3)
 TRAIN = Golden("train")
 

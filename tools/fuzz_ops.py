@@ -183,15 +183,18 @@ def lg_case(seed):
     scores within the north_star's 1e-4."""
     r = np.random.default_rng(seed)
     din = int(r.choice([256, 256, 128]))
-    if din not in _LG:
-        lg = pkg.LightGlue({"input_dim": din}).to(DEV).eval()
+    # one case in three: widths other than 256 = 4 x 64 (head_dim = descriptor_dim // num_heads in {32, 64, 128}, lightglue.py:456-461)
+    heads, dh, layers = (4, 64, 9) if r.integers(3) else (int(r.choice([1, 2, 3, 4, 6, 8])), int(r.choice([32, 64, 128])), int(r.integers(1, 5)))
+    key = (din, heads, dh, layers)
+    if key not in _LG:
+        lg = pkg.LightGlue({"input_dim": din, "descriptor_dim": heads * dh, "num_heads": heads, "n_layers": layers}).to(DEV).eval()
         sd = pkg.synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=900 + din)
         lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-        _LG[din] = (lg, sd)
-    lg, sd = _LG[din]
+        _LG[key] = (lg, sd)
+    lg, sd = _LG[key]
     n0, n1 = int(r.choice([1, 2, 3, 31, 64, 65, 130, 257])), int(r.choice([1, 2, 5, 33, 64, 127, 200, 300]))
     H, W = int(r.integers(60, 400)), int(r.integers(60, 500))
-    desc = f"seed {seed}: lightglue input_dim={din} n0={n0} n1={n1} size {H}x{W}"
+    desc = f"seed {seed}: lightglue input_dim={din} heads={heads}x{dh} layers={layers} n0={n0} n1={n1} size {H}x{W}"
     d0, d1 = f32(r, (n0, din)), f32(r, (n1, din))
     k = min(n0, n1) // 2
     d1[:k] = d0[:k] + f32(r, (k, din), -0.1, 0.1)
@@ -202,7 +205,7 @@ def lg_case(seed):
     size = torch.tensor([H, W])
     f0 = {"sparse_descriptors": t(d0)[None], "sparse_positions": t(k0)[None], "image_size": [size]}
     f1 = {"sparse_descriptors": t(d1)[None], "sparse_positions": t(k1)[None], "image_size": [size]}
-    exp = orc.lightglue(sd, k0, d0, k1, d1, size0=(H, W), size1=(H, W))
+    exp = orc.lightglue(sd, k0, d0, k1, d1, size0=(H, W), size1=(H, W), n_layers=layers, heads=heads)
     if not (np.asarray(exp["matches0"]) > -1).any():
         try:
             lg(f0, f1)
@@ -238,7 +241,7 @@ def lg_batch_case(seed):
     bt = import_module(pkg.__name__ + ".core.modules.matchers._batched")
     r = np.random.default_rng(seed)
     din = 256
-    if din not in _LG:
+    if din not in _LG:  # (the batch case keeps the shipped widths: key = input_dim alone)
         lg = pkg.LightGlue({"input_dim": din}).to(DEV).eval()
         sd = pkg.synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=900 + din)
         lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
