@@ -11,7 +11,52 @@ from .. import _native as N
 from .._lib import check
 
 
-def _pack(events_list, device):
+class EventStage:
+    """Reusable upload path for the packed events of ONE in-flight batch: page-locked host arrays the samples are concatenated
+    into directly (no temporaries) and device arrays they are copied to with non-blocking copies on the current stream, so
+    that an evaluation loop can pack and upload batch i + 1 while the device still works on batch i
+    (harness.SameTimeEvaluator.run).  The arrays grow to the largest batch seen.  A stage must not be packed into again
+    before the work that reads its previous contents has finished."""
+    _FIELDS = (("x", np.float32, torch.float32), ("y", np.float32, torch.float32), ("t", np.float64, torch.float64), ("p", np.float32, torch.float32))
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cap = 0
+        self.host, self.dev = {}, {}
+        self.copy_stream = torch.cuda.Stream(self.device)  # the transfer overlaps the work already queued on the caller's stream
+
+    def _reserve(self, n):
+        if n <= self.cap:
+            return
+        self.cap = max(n, int(self.cap * 1.5))
+        for name, _, tdt in self._FIELDS:
+            self.host[name] = torch.empty(self.cap, dtype=tdt, pin_memory=True)
+            self.dev[name] = torch.empty(self.cap, dtype=tdt, device=self.device)
+
+    def pack(self, events_list):
+        offs = np.zeros(len(events_list) + 1, np.int64)
+        np.cumsum([len(ev["x"]) for ev in events_list], out=offs[1:])
+        n = int(offs[-1])
+        if n == 0:
+            return None
+        self._reserve(n)
+        out = []
+        for name, _, _ in self._FIELDS:
+            h = self.host[name][:n]
+            np.concatenate([np.asarray(ev[name]) for ev in events_list], out=h.numpy(), casting="unsafe")
+            with torch.cuda.stream(self.copy_stream):
+                out.append(self.dev[name][:n].copy_(h, non_blocking=True))
+        done = torch.cuda.Event()
+        done.record(self.copy_stream)
+        torch.cuda.current_stream(self.device).wait_event(done)  # the kernels that read the arrays are enqueued behind the copies
+        return (*out, offs)
+
+
+def _pack(events_list, device, stage=None):
+    if stage is not None:
+        packed = stage.pack(events_list)
+        if packed is not None:
+            return packed
     xs, ys, ts, ps, offs = [], [], [], [], [0]
     for ev in events_list:
         xs.append(np.asarray(ev["x"], np.float32))
@@ -56,10 +101,11 @@ def events_mask_batch(events_list, resolution, device="cuda", packed=None):
     return mask.view(torch.bool)
 
 
-def events_representation_batch(events_list, input_size, normalize=True, device="cuda"):
+def events_representation_batch(events_list, input_size, normalize=True, device="cuda", stage=None):
     """voxel grids [B,bins,H,W] and events masks [B,1,H,W] of B samples from ONE host-side packing and upload of the raw
-    event arrays (what test_events-image_same-time.py:130-140 builds per sample with two passes over the events)."""
+    event arrays (what test_events-image_same-time.py:130-140 builds per sample with two passes over the events).
+    stage: an EventStage -- the upload goes through its page-locked arrays without blocking the host."""
     bins, H, W = (int(v) for v in input_size)
-    packed = _pack(events_list, device)
+    packed = _pack(events_list, device, stage)
     return (events_to_voxel_grid_batch(events_list, input_size, normalize, device, packed=packed),
             events_mask_batch(events_list, (W, H), device, packed=packed))

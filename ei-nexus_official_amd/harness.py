@@ -11,7 +11,7 @@ DifferentTimeEvaluator hands over exactly what the reference passes to them.
 import torch
 
 from .core.metrics._native_metrics import batch_metrics, metric_names
-from .datasets.representations import events_representation_batch
+from .datasets.representations import EventStage, events_representation_batch
 
 
 class SameTimeEvaluator:
@@ -35,6 +35,9 @@ class SameTimeEvaluator:
         events_rep, events_mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev)
         self.last_inputs = (events_rep, events_mask)  # what the extractors saw (deterministic since round 4: bit-equal run to run)
         ef, imf, matches = self.model(events_rep, images, events_mask)
+        return self._account(ef, imf, matches, homography)
+
+    def _account(self, ef, imf, matches, homography):
         rows = batch_metrics(ef._batched, imf._batched, self.model._last_match, homography, self.mma_thr, self.vdd_thr)
         ok = ~torch.isnan(rows)
         z = torch.nan_to_num(rows)
@@ -42,6 +45,40 @@ class SameTimeEvaluator:
         self.counts = ok.sum(0).double() if self.counts is None else self.counts + ok.sum(0).double()
         self.pairs += rows.shape[0]
         return rows, (ef, imf, matches)
+
+    @torch.no_grad()
+    def run(self, batches, depth=2):
+        """The evaluation LOOP (test_events-image_same-time.py:130-194 iterates a DataLoader): `batches` yields
+        (events_list, images[, homography]) like the arguments of `step`; one `step` result per batch comes back, in order.
+        Up to `depth` batches are in flight: batch i + 1's events are concatenated into page-locked memory, uploaded with
+        non-blocking copies and its kernels enqueued (EIM.forward_stream's mechanism) BEFORE the host waits for batch i's
+        counts, so packing and the PCIe transfer hide under the device's work instead of adding to it.  Same kernels, same
+        results as `step`; every `images` tensor must stay untouched until its result has been yielded."""
+        from collections import deque
+        W, H = self.resolution
+        depth = max(int(depth), 1)
+        pending = deque()
+        if not hasattr(self, "_stages"):
+            self._stages = {}
+        k = 0
+        for item in batches:
+            events_list, images = item[0], item[1]
+            homography = item[2] if len(item) > 2 else None
+            slot = k % depth
+            dev = images.device
+            with torch.cuda.device(dev):
+                stage = self._stages.get((slot, dev))
+                if stage is None:
+                    stage = self._stages[(slot, dev)] = EventStage(dev)
+                rep, mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage)
+                pending.append((self.model._enqueue(rep, images, mask, slot=slot), homography))
+            k += 1
+            if len(pending) >= depth:
+                p, hom = pending.popleft()
+                yield self._account(*self.model._finish(p), hom)
+        while pending:
+            p, hom = pending.popleft()
+            yield self._account(*self.model._finish(p), hom)
 
     def result(self):
         """Mean of every metric over the pairs seen so far; sums are all-reduced when a process group is up."""

@@ -344,3 +344,43 @@ def test_event_batches_without_any_event(oracle):
     assert not g2.any()  # (one event: NaN t_norm, dropped like in the reference)
     m2 = _np(rep.events_mask_batch([empty, one], (56, 40)))
     assert not m2[0].any() and m2[1].sum() == 1 and m2[1, 0, 2, 3]
+
+
+def test_harness_run_streams_batches_with_the_results_of_step():
+    """SameTimeEvaluator.run (events packed into page-locked memory, uploaded on a side stream and enqueued while the
+    previous batch is still on the device) yields, batch by batch, exactly what step() returns: metric rows, keypoints,
+    descriptors and matches bit for bit -- over batches of different event counts, integer-typed event arrays, a batch
+    without any event and per-pair homographies; the accumulated means are equal too."""
+    from helpers import synth, synth_raw_events
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    for sec in (cfg.event_extractor.vgg, cfg.image_extractor.superpointv1):
+        sec.detection_top_k = 128
+    model = pkg.EIM(cfg, device=DEV).eval()
+    sdn = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=35)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    H, W, B = 100, 124, 3
+    batches = []
+    for i, n in enumerate((6000, 900, 0, 12000, 3000)):
+        evs = [synth_raw_events(dict(seed=600 + 10 * i + b, n=n + 37 * b if n else 0, H=H, W=W, bins=5, frac=False, pneg=False)) for b in range(B)]
+        if i == 1:  # what an HDF5 loader hands over: integer coordinates / polarities
+            evs = [dict(x=e["x"].astype(np.int16), y=e["y"].astype(np.int16), t=e["t"], p=e["p"].astype(np.int8)) for e in evs]
+        hom = None
+        if i % 2:
+            hom = _t(np.tile(np.array([[1.01, 0.01, -2.0], [-0.01, 0.99, 1.5], [1e-5, -1e-5, 1.0]], np.float32), (B, 1, 1)))
+        batches.append((evs, synth.synth_image(80 + i, B, H, W), hom))
+    a = pkg.DifferentTimeEvaluator(model, bins=5, resolution=(W, H))
+    exp = [a.step(evs, _t(img), hom) for evs, img, hom in batches]
+    b = pkg.DifferentTimeEvaluator(model, bins=5, resolution=(W, H))
+    for depth in (2, 3, 1):
+        got = list(b.run(((evs, _t(img), hom) for evs, img, hom in batches), depth=depth))
+        assert len(got) == len(exp)
+        for (r0, (e0, i0, m0)), (r1, (e1, i1, m1)) in zip(exp, got):
+            assert torch.equal(torch.nan_to_num(r0, nan=-7.0), torch.nan_to_num(r1, nan=-7.0))
+            for f0, f1 in ((e0, e1), (i0, i1)):
+                for key in ("sparse_positions", "sparse_descriptors"):
+                    assert all(torch.equal(x, y) for x, y in zip(f0[key], f1[key]))
+            assert all(torch.equal(x, y) for x, y in zip(m0["matches0"], m1["matches0"]))
+            assert all(torch.equal(x, y) for x, y in zip(m0["matched_kpts1"], m1["matched_kpts1"]))
+    ra, rb = a.result(), b.result()  # b saw every batch three times: same means
+    for k in ra:
+        assert (ra[k] != ra[k] and rb[k] != rb[k]) or abs(ra[k] - rb[k]) <= 1e-12 * max(1.0, abs(ra[k])), k
