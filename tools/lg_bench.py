@@ -37,9 +37,31 @@ def main():
     ap.add_argument("--skip-linear", action="store_true")
     ap.add_argument("--only-linear", action="store_true")
     ap.add_argument("--data", default="randn", choices=["randn", "zeros", "relu"], help="operand values of the linear shapes (power / clock sensitivity)")
+    ap.add_argument("--widths", action="store_true", help="LightGlue.match_batched at other (num_heads, head_dim) configurations and exit")
     a = ap.parse_args()
     dev = "cuda:0"
     B, n = a.batch, 1024
+    if a.widths:
+        from importlib import import_module
+        bt = import_module("ei-nexus_official_amd.core.modules.matchers._batched")
+        for heads, dh in ((4, 64), (8, 32), (2, 128), (4, 32), (3, 64), (4, 128)):
+            d = heads * dh
+            lg = pkg.LightGlue({"input_dim": d, "descriptor_dim": d, "num_heads": heads}).to(dev).eval()
+            lg.want_log_assignment = False
+            pbs = []
+            for s_ in (1, 2):
+                pb = bt.PairBatch()
+                g = torch.Generator(device=dev).manual_seed(s_)
+                pb.kpts = torch.rand(B, n, 3, device=dev, generator=g) * 250.0
+                pb.desc = torch.nn.functional.normalize(torch.randn(B, n, d, device=dev, generator=g), dim=-1).contiguous()
+                pb.counts = torch.full((B,), n, dtype=torch.int32, device=dev)
+                pb.cap, pb.B, pb.image_size, pb.counts_host = n, B, (260, 346), [n] * B
+                pbs.append(pb)
+            ms = timed(lambda: lg.match_batched(pbs[0], pbs[1]), a.reps)
+            # per pair and layer (out_proj / to_out folded): linears 2 n (3 d^2 + 4 d^2 + 2 d^2) + 2 n (2 d^2 + 4 d^2 + 2 d^2) MACs, attention 4 x 2 n^2 d
+            flop = 9 * (2.0 * 2 * n * 17 * d * d + 2.0 * 4 * 2 * n * n * d) + 2.0 * 2 * n * d * d + 2.0 * n * n * d
+            print(f"lightglue B={B} {heads} x {dh} (d={d}): {ms:8.2f} ms  {flop * B / ms / 1e9:7.1f} TFLOP/s", flush=True)
+        return
     if not a.skip_linear:
         for (K, Nn) in ((256, 768), (256, 256), (512, 512), (512, 256)):
             M = B * n
