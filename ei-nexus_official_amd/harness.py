@@ -71,6 +71,7 @@ class SameTimeEvaluator:
                 if stage is None:
                     stage = self._stages[(slot, dev)] = EventStage(dev)
                 rep, mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage)
+                self.last_inputs = (rep, mask)  # of the batch enqueued last (results lag by up to depth - 1 batches)
                 pending.append((self.model._enqueue(rep, images, mask, slot=slot), homography))
             k += 1
             if len(pending) >= depth:

@@ -207,10 +207,13 @@ def harness_case(seed):
     if use_hom:
         homs = np.stack([np.eye(3) + r.uniform(-1, 1, (3, 3)) * np.array([[0.03, 0.03, 4], [0.03, 0.03, 4], [2e-5, 2e-5, 0]]) for _ in range(B)]).astype(np.float32)
         ev_ = pkg.DifferentTimeEvaluator(m, bins=bins, resolution=(W, H))
-        rows, (ef, imf, mt) = ev_.step(evs, t(img.copy()), t(homs))
     else:
         ev_ = pkg.SameTimeEvaluator(m, bins=bins, resolution=(W, H))
-        rows, (ef, imf, mt) = ev_.step(evs, t(img.copy()))
+    if r.integers(2):  # the loop form: page-locked staging, upload on a side stream (one batch: its inputs are `last_inputs`)
+        desc += " (run)"
+        (rows, (ef, imf, mt)), = list(ev_.run([(evs, t(img.copy()), None if homs is None else t(homs))], depth=int(r.integers(1, 3))))
+    else:
+        rows, (ef, imf, mt) = ev_.step(evs, t(img.copy()), None if homs is None else t(homs))
     rows = n(rows)
     grid = n(ev_.last_inputs[0])
     mask = np.stack([orc.events_mask(e, (W, H)) for e in evs])[:, None]
