@@ -4,7 +4,7 @@
 // check that no torch type or allocator is needed below the boundary.
 //
 //   hipcc -O2 --offload-arch=gfx950 examples/c_abi_host.cpp -Iinclude -Lei-nexus_official_amd -leinx_hip \
-//         -Wl,-rpath,$PWD/ei-nexus_official_amd -o examples/c_abi_host && examples/c_abi_host [B [IN.bin OUT.bin]]
+//         -Wl,-rpath,$PWD/ei-nexus_official_amd -o examples/c_abi_host && examples/c_abi_host [B [IN.bin OUT.bin [lg]]]
 //
 // Weights are seeded pseudo-random (the network shape is SuperPointv1's / VGGExtractor's: superpoint_extractor.py:299-314,
 // net/backbone.py:37-103); the program prints keypoint / match counts and a checksum and exits non-zero on any ABI error.
@@ -12,6 +12,9 @@
 // exactly the order this program would otherwise draw them: per network, per layer w, b, [gamma, beta, mean, var]; then events,
 // mask, image) and the results are written to OUT.bin (per side counts, positions, sparse descriptors; then matches0 and the
 // match counts): tests/test_r5_gpu.py writes IN.bin from a seeded state dict and compares OUT.bin bit for bit with the oracle.
+// With a fourth argument `lg` the same features also go through a 3-layer LightGlue (einx_lightglue: lightglue.py:522-716; the
+// structs of einx.h filled in from C): its weights follow the inputs in IN.bin (per layer the fields of einx_lg_layer in their
+// order, each matrix then its bias; then posenc.Wr, final_proj, matchability) and OUT.bin ends with its matches0 / matches1 / scores0.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -157,6 +160,53 @@ static Net make_net(int cin, bool bn, bool dilate, float input_div, hipStream_t 
   return n;
 }
 
+// ---- LightGlue: the weight structs of einx.h filled in by a C program ---------------------------------------------------
+static const float* lg_array(size_t n, float amp) {
+  std::vector<float> h(n);
+  if (!from_file(h))
+    for (auto& v : h) v = (2.0f * urand() - 1.0f) * amp;
+  return upload(h);
+}
+
+struct LgModel {
+  std::vector<einx_lg_layer> layers;
+  einx_lg_weights w{};
+};
+
+static void make_lightglue(LgModel& m, int n_layers, int heads, int d, int input_dim) {
+  const float a1 = sqrtf(3.0f / (float)d), a2 = sqrtf(3.0f / (float)(2 * d));
+  auto lin = [&](const float*& w, const float*& b, int out, int in, float amp) {  // nn.Linear: weight [out,in], bias [out]
+    w = lg_array((size_t)out * in, amp);
+    b = lg_array((size_t)out, 0.05f);
+  };
+  auto ffn = [&](const float*& w0, const float*& b0, const float*& g, const float*& be, const float*& w3, const float*& b3) {
+    lin(w0, b0, 2 * d, 2 * d, a2);        // ffn.0
+    g = lg_array((size_t)2 * d, 1.0f);   // ffn.1 (LayerNorm) weight, bias
+    be = lg_array((size_t)2 * d, 0.05f);
+    lin(w3, b3, d, 2 * d, a2);            // ffn.3
+  };
+  m.layers.resize(n_layers);
+  for (auto& L : m.layers) {
+    lin(L.Wqkv, L.bqkv, 3 * d, d, a1);  // SelfBlock (lightglue.py:240-272)
+    lin(L.Wo, L.bo, d, d, a1);
+    ffn(L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b);
+    lin(L.Wqk, L.bqk, d, d, a1);        // CrossBlock (:275-330)
+    lin(L.Wv, L.bv, d, d, a1);
+    lin(L.Wco, L.bco, d, d, a1);
+    ffn(L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b);
+  }
+  m.w.in_w = m.w.in_b = nullptr;  // input_dim == d: Identity
+  m.w.Wr = lg_array((size_t)(d / heads / 2) * 2, 1.0f);  // posenc.Wr [head_dim/2, 2]
+  lin(m.w.proj_w, m.w.proj_b, d, d, a1);                 // log_assignment[last].final_proj
+  lin(m.w.match_w, m.w.match_b, 1, d, a1);               // ... .matchability
+  m.w.n_layers = n_layers;
+  m.w.heads = heads;
+  m.w.d = d;
+  m.w.input_dim = input_dim;
+  m.w.filter_threshold = 0.0f;
+  m.w.layers = m.layers.data();
+}
+
 struct Outs {
   einx_extract_out o{};
   einx_extract_shapes_t sh{};
@@ -193,6 +243,7 @@ int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 2;
   const int H = 260, W = 346, CE = 5;
   const char* out_path = argc > 3 ? argv[3] : nullptr;
+  const bool with_lg = argc > 4 && argv[4][0] == 'l';
   if (argc > 3 && !(g_in = fopen(argv[2], "rb"))) {
     fprintf(stderr, "cannot open %s\n", argv[2]);
     return 2;
@@ -241,6 +292,26 @@ int main(int argc, char** argv) {
   float* mk1 = dalloc<float>((size_t)B * cap0 * 3);
   int32_t* nmatch = dalloc<int32_t>(B);
   EINXCHK(einx_gather_matches(eo.o.positions, io.o.positions, m0, eo.o.counts, cap0, cap1, B, 3, mk0, mk1, nmatch, st));
+  // ---- optionally the learned matcher on the same features (device-side counts, no host synchronisation either)
+  int64_t *lm0 = nullptr, *lm1 = nullptr;
+  float *ls0 = nullptr, *ls1 = nullptr;
+  LgModel lgm;
+  if (with_lg) {
+    make_lightglue(lgm, /*n_layers*/ 3, /*heads*/ 4, D, D);
+    const size_t lws = einx_lg_ws_bytes_heads(B, cap0, cap1, D, 4, D);
+    if (!lws) {
+      fprintf(stderr, "einx_lg_ws_bytes_heads: unsupported widths\n");
+      return 3;
+    }
+    void* lgws = nullptr;
+    HIPCHK(hipMalloc(&lgws, lws));
+    lm0 = dalloc<int64_t>((size_t)B * cap0);
+    lm1 = dalloc<int64_t>((size_t)B * cap1);
+    ls0 = dalloc<float>((size_t)B * cap0);
+    ls1 = dalloc<float>((size_t)B * cap1);
+    EINXCHK(einx_lightglue(&lgm.w, eo.o.positions, eo.o.sparse_desc, eo.o.counts, cap0, io.o.positions, io.o.sparse_desc, io.o.counts, cap1, B,
+                           (float)H, (float)W, (float)H, (float)W, lgws, lm0, lm1, ls0, ls1, /*la*/ nullptr, /*ref*/ nullptr, nullptr, 0, st));
+  }
   HIPCHK(hipStreamSynchronize(st));
   std::vector<int32_t> n0(B), n1(B), nm(B), bad(2 * B);
   HIPCHK(hipMemcpy(n0.data(), eo.o.counts, B * 4, hipMemcpyDeviceToHost));
@@ -284,7 +355,25 @@ int main(int argc, char** argv) {
     }
     dump(m0, (size_t)B * cap0 * 8);
     dump(nmatch, (size_t)B * 4);
+    if (with_lg) {
+      dump(lm0, (size_t)B * cap0 * 8);
+      dump(lm1, (size_t)B * cap1 * 8);
+      dump(ls0, (size_t)B * cap0 * 4);
+    }
     fclose(fo);
+  }
+  if (with_lg) {
+    std::vector<int64_t> hm((size_t)B * cap0);
+    HIPCHK(hipMemcpy(hm.data(), lm0, hm.size() * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+      int cnt = 0;
+      for (int i = 0; i < n0[b]; ++i) {
+        const int64_t j = hm[(size_t)b * cap0 + i];
+        if (j >= n1[b] || j < -1) rc = 8;  // a match index must point at a keypoint of the other side
+        cnt += j >= 0;
+      }
+      printf("pair %d: %d LightGlue matches\n", b, cnt);
+    }
   }
   double nrm = 0.0;
   for (int c = 0; c < D; ++c) nrm += (double)desc[c] * desc[c];

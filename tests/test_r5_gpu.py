@@ -73,10 +73,12 @@ def test_no_forward_stalls_after_a_weight_reload():
     print("post-reload forwards (max, median) ms:", [(round(a_, 2), round(b_, 2)) for a_, b_ in worst])
 
 
-def test_torch_free_c_abi_host_values_equal_the_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("with_lg", [False, True])
+def test_torch_free_c_abi_host_values_equal_the_oracle(oracle, tmp_path, with_lg):
     """examples/c_abi_host -- the only consumer of include/einx.h that is neither Python nor torch -- fed with a seeded state
     dict and seeded inputs through a file: its keypoints, descriptors and match indices are bit-equal to the oracle's
-    (round 4 only checked its exit status and three log lines)."""
+    (round 4 only checked its exit status and three log lines).  with_lg: the program also fills einx_lg_weights / einx_lg_layer
+    from C and runs a 3-layer LightGlue on the same features: assignments equal the oracle's, scores within 1e-4."""
     from helpers import sub_dict, synth
     exe = os.path.join(ROOT, "examples", "c_abi_host")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
@@ -103,11 +105,23 @@ def test_torch_free_c_abi_host_values_equal_the_oracle(oracle, tmp_path):
     for name in ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convPb", "convDa", "convDb"):
         blob.extend([isd[name + ".weight"], isd[name + ".bias"]])
     blob.extend([ev, mask.astype(np.uint8), img])
+    lgsd = None
+    if with_lg:  # the fields of einx_lg_layer in their order (matrix, bias), then posenc.Wr, final_proj, matchability
+        lg = pkg.LightGlue({"input_dim": 256, "n_layers": 3})
+        lgsd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=43)
+        for i in range(3):
+            for blk, names in ((f"transformers.{i}.self_attn.", ("Wqkv", "out_proj", "ffn.0", "ffn.1", "ffn.3")),
+                               (f"transformers.{i}.cross_attn.", ("to_qk", "to_v", "to_out", "ffn.0", "ffn.1", "ffn.3"))):
+                for nm in names:
+                    blob.extend([lgsd[blk + nm + ".weight"], lgsd[blk + nm + ".bias"]])
+        blob.append(lgsd["posenc.Wr.weight"])
+        for nm in ("final_proj", "matchability"):
+            blob.extend([lgsd[f"log_assignment.2.{nm}.weight"], lgsd[f"log_assignment.2.{nm}.bias"]])
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
         for a in blob:
             f.write(np.ascontiguousarray(a).tobytes())
-    r = subprocess.run([exe, str(B), fin, fout], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(B), fin, fout] + (["lg"] if with_lg else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C ABI host: OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     raw = open(fout, "rb").read()
     cap, D, off = 1024, 256, 0
@@ -123,6 +137,8 @@ def test_torch_free_c_abi_host_values_equal_the_oracle(oracle, tmp_path):
     for _ in range(2):
         sides.append((take(np.int32, (B,)), take(np.float32, (B, cap, 3)), take(np.float32, (B, cap, D))))
     m0, nmatch = take(np.int64, (B, cap)), take(np.int32, (B,))
+    if with_lg:
+        lm0, lm1, ls0 = take(np.int64, (B, cap)), take(np.int64, (B, cap)), take(np.float32, (B, cap))
     assert off == len(raw)
     ecfg, icfg = cfg.event_extractor.vgg, cfg.image_extractor.superpointv1
     oe = oracle.extractor_forward("vgg", esd, ev.copy(), mask, top_k=1024, radius=4, border=4, det_thr=1.0, scale=1.0)
@@ -139,6 +155,13 @@ def test_torch_free_c_abi_host_values_equal_the_oracle(oracle, tmp_path):
         n = len(oe["sparse_positions"][b])
         assert np.array_equal(m0[b, :n], em["matches0"])
         assert nmatch[b] == int((em["matches0"] > -1).sum())
+        if with_lg:
+            m = len(oi["sparse_positions"][b])
+            el = oracle.lightglue(lgsd, oe["sparse_positions"][b], oe["sparse_descriptors"][b], oi["sparse_positions"][b],
+                                  oi["sparse_descriptors"][b], n_layers=3, heads=4)
+            assert np.array_equal(lm0[b, :n], el["matches0"]) and np.array_equal(lm1[b, :m], el["matches1"])
+            assert np.abs(ls0[b, :n] - el["matching_scores0"]).max() <= 1e-4
+            assert f"pair {b}: {int((el['matches0'] > -1).sum())} LightGlue matches" in r.stdout
 
 
 @pytest.mark.parametrize("cfg_name", ["SP_MNN", "SP_LG"])
