@@ -220,9 +220,10 @@ def test_lightglue_stacked_sides_equal_the_per_side_path(B, n, m):
 
 @pytest.mark.parametrize("n,m", [(1024, 1024), (700, 613)])
 def test_lightglue_small_grid_kernels_equal_the_large_grid_kernels(n, m):
-    """A single pair runs its linears on lg_gemm_small_kernel (64x64 tiles, fewer than 256 128x128 tiles), the same pair as
-    entry 0 of a batch of 8 on lg_gemm_kernel: every output of the pair must be bit-identical (one k-ordered chain per output
-    in both kernels)."""
+    """A single pair runs its linears on lg_gemm_small_kernel (64x64 tiles, fewer than 256 128x128 tiles) and its attention on
+    lg_attn16_kernel (four waves share every key block of 16 / 32 queries on the 16x16x4 instruction), the same pair as
+    entry 0 of a batch of 8 on lg_gemm_kernel / lg_attn_kernel: every output of the pair must be bit-identical (one k-ordered
+    chain per output in both linears; the same chain of matrix steps, maxima, exponentials and sums in both attentions)."""
     from importlib import import_module
     N = pkg.native
     PairBatch = import_module(pkg.__name__ + ".core.modules.matchers._batched").PairBatch
@@ -259,6 +260,12 @@ def test_lightglue_small_grid_kernels_equal_the_large_grid_kernels(n, m):
     assert torch.equal(one.ref0[0, :n], big.ref0[0, :n]) and torch.equal(one.ref1[0, :m], big.ref1[0, :m])
     assert torch.equal(one.la[0, :n, :m], big.la[0, :n, :m])
     assert int((one.matches0[0, :n] > -1).sum()) > 0
+    # two pairs: the attention's latency form with 32 queries per workgroup (round 5: lg_attn16_kernel<32>; one pair runs <16>)
+    two = N.lightglue(w, batch(k0, d0, n, 2), batch(k1, d1, m, 2), want_la=True, want_ref=True)
+    for i in range(2):
+        assert torch.equal(two.matches0[i, :n], big.matches0[i, :n]) and torch.equal(two.scores0[i, :n], big.scores0[i, :n])
+        assert torch.equal(two.ref0[i, :n], big.ref0[i, :n]) and torch.equal(two.ref1[i, :m], big.ref1[i, :m])
+        assert torch.equal(two.la[i, :n, :m], big.la[i, :n, :m])
 
 
 # ------------------------------------------------------------------ whole forwards at odd geometries (small-grid kernels, forked heads, ragged tiles)
