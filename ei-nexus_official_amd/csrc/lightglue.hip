@@ -578,29 +578,35 @@ constexpr int A16_KP = 68;  // K rows: [slot k = 0..3][g = 0..15] + 4 floats of 
 constexpr int A16_VP = 68;  // V rows: 64 dims + 4
 constexpr int A16_SP = 33;  // S / P rows: 32 queries + 1
 
-// (Measured and not kept: phase A one block ahead with double-buffered K / V / S and one barrier per block, 44 -> 47 us per launch;
-// 16 queries per workgroup and two workgroups per CU, 44 -> 44 us -- profiles/r05_notes.md 5.)
-__global__ __launch_bounds__(256) void lg_attn16_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ks[32 * A16_KP];
-  __shared__ __attribute__((aligned(16))) float Vs[32 * A16_VP];
-  __shared__ float Ss[32 * A16_SP];
+// Eight waves, two teams: waves 4-7 compute the S^T quadrants of block i + 1 (a chain of 16 dependent matrix steps) while waves
+// 0-3 run the softmax and the O^T tiles of block i -- two waves per SIMD whose stalls cover each other; K, V and S are
+// double-buffered and a block costs one workgroup barrier.  (Measured on the way, per launch at one pair: all phases in four
+// waves with three barriers per block 44 us; the same with phase A moved one block ahead in the SAME waves 47 us; 16 queries per
+// workgroup, two workgroups per CU 44 us; lg_attn_kernel 76 us -- profiles/r05_notes.md 5.)
+__global__ __launch_bounds__(512) void lg_attn16_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[2][32 * A16_KP];
+  __shared__ __attribute__((aligned(16))) float Vs[2][32 * A16_VP];
+  __shared__ float Ss[2][32 * A16_SP];
   __shared__ float Ps[4][32 * A16_SP];
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int bk = a.kv_shift ? (b + a.kv_shift) % a.Btot : b;
   const int nq = min(a.nq[b], a.capq), nk = min(a.nk[bk], a.capk);
   const int q0 = qb * 32;
   if (q0 >= nq || nk <= 0) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool team_a = wave >= 4;
+  const int w4 = wave & 3;
   const int half = lane >> 5, l31 = lane & 31;  // phase B layout
   const int k4 = lane >> 4, c = lane & 15;      // MFMA 16x16x4 layout: K slot, row / column
-  const int kq = wave >> 1, qq = wave & 1;      // phase A quadrant: keys 16 kq.., queries 16 qq..
+  const int kq = w4 >> 1, qq = w4 & 1;          // phase A quadrant: keys 16 kq.., queries 16 qq..
   // Q fragment of phase A: query q0 + 16 qq + c, dims of slot k4 in step order: (k4 & 1) * 32 + 2 g + (k4 >> 1)
   float qf[16];
   {
     const int q = min(q0 + 16 * qq + c, nq - 1);
     const float* Qrow = a.Q + ((size_t)b * a.capq + q) * D + h * DH + (k4 & 1) * 32 + (k4 >> 1);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) qf[g] = Qrow[2 * g];
+    for (int g = 0; g < 16; ++g) qf[g] = team_a ? Qrow[2 * g] : 0.0f;
   }
   const float* Kb = a.K + (size_t)bk * a.capk * D + h * DH;
   const float* Vb = a.V + (size_t)bk * a.capk * D + h * DH;
@@ -612,27 +618,20 @@ __global__ __launch_bounds__(256) void lg_attn16_kernel(const AttnArgs a) {
   const float NEG = -einx_u2f(0x7f800000u);
   const float sl2 = a.scale * 1.44269504088896341f;
   float m_run = NEG, l_run = 0.0f;
-  // staging: 32 keys x 16 float4 per operand = 2 float4 per thread and operand; rows past nk repeat row nk - 1 (masked in B)
-  const int srow = tid >> 4, sc4 = tid & 15;  // + 16 rows for the second float4
-  auto load_rows = [&](const float* base, int kb0, f32x4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const f32x4*>(base + (size_t)min(kb0 + srow + 16 * i, nk - 1) * D + sc4 * 4);
+  // staging: 32 keys x 16 float4 per operand = one float4 per thread and operand; rows past nk repeat row nk - 1 (masked in B)
+  const int srow = tid >> 4, sc4 = tid & 15;
+  auto load_row = [&](const float* base, int kb0) {
+    return *reinterpret_cast<const f32x4*>(base + (size_t)min(kb0 + srow, nk - 1) * D + sc4 * 4);
   };
-  auto commit_k = [&](float* dst, const f32x4* r) {  // dims d0 .. d0+3 (d0 = 4 sc4): slot (d >= 32) + 2 (d & 1), position (d & 31) >> 1
+  auto commit_k = [&](float* dst, const f32x4& r) {  // dims d0 .. d0+3 (d0 = 4 sc4): slot (d >= 32) + 2 (d & 1), position (d & 31) >> 1
     const int hi = sc4 >> 3, g0 = (sc4 & 7) * 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float* kr = dst + (srow + 16 * i) * A16_KP;
-      kr[hi * 16 + g0] = r[i][0];
-      kr[hi * 16 + g0 + 1] = r[i][2];
-      kr[(hi + 2) * 16 + g0] = r[i][1];
-      kr[(hi + 2) * 16 + g0 + 1] = r[i][3];
-    }
+    float* kr = dst + srow * A16_KP;
+    kr[hi * 16 + g0] = r[0];
+    kr[hi * 16 + g0 + 1] = r[2];
+    kr[(hi + 2) * 16 + g0] = r[1];
+    kr[(hi + 2) * 16 + g0 + 1] = r[3];
   };
-  auto commit_v = [&](float* dst, const f32x4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(dst + (srow + 16 * i) * A16_VP + sc4 * 4) = r[i];
-  };
+  auto commit_v = [&](float* dst, const f32x4& r) { *reinterpret_cast<f32x4*>(dst + srow * A16_VP + sc4 * 4) = r; };
   // phase A of one block: this wave's S^T quadrant from ks into ss
   auto phase_a = [&](const float* ks, float* ss) {
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -645,81 +644,112 @@ __global__ __launch_bounds__(256) void lg_attn16_kernel(const AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ss[(16 * kq + 4 * k4 + i) * A16_SP + 16 * qq + c] = acc[i];
   };
-  f32x4 rk[2], rv[2];
-  load_rows(Kb, 0, rk);
-  load_rows(Vb, 0, rv);
-  float* Pw = Ps[wave];
-  for (int kbase = 0; kbase < nk; kbase += 32) {
-    __syncthreads();  // the previous block's readers of Ks / Vs / Ss are done
-    commit_k(Ks, rk);
-    commit_v(Vs, rv);
+  const int nblk = (nk + 31) >> 5;
+  // K / V rows travel global -> registers -> LDS with TWO blocks of flight time (a block is ~1 us, an L2 round trip under this
+  // access pattern about as long: with one block of distance the loop waited ~9 us per launch for its loads)
+  f32x4 rk, rv, rk_new, rv_new;
+  {  // prologue: K(0), V(0), K(1) staged, K(2) and V(1) requested; S(0) computed
+    const f32x4 r0 = load_row(Kb, 0);
+    rv = load_row(Vb, 0);
+    rk = load_row(Kb, 32);
+    commit_k(Ks[0], r0);
+    commit_v(Vs[0], rv);
+    commit_k(Ks[1], rk);
+    rk = load_row(Kb, 64);
+    rv = load_row(Vb, 32);
     __syncthreads();
-    if (kbase + 32 < nk) {  // in flight under this block's work
-      load_rows(Kb, kbase + 32, rk);
-      load_rows(Vb, kbase + 32, rv);
-    }
-    // ---- A: this wave's S^T quadrant
-    phase_a(Ks, Ss);
+    if (team_a) phase_a(Ks[0], Ss[0]);
     __syncthreads();
-    // ---- B: the block's online softmax, as in lg_attn_kernel (lane = query l31, keys crow(r, half))
-    const float* ss = Ss;
-    float s[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = ss[crow(r, half) * A16_SP + l31];
-    float mx = NEG;
-    if (kbase + 32 <= nk) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = s[r] * sl2;
-        mx = fmaxf(mx, s[r]);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kbase + crow(r, half);
-        s[r] = key < nk ? s[r] * sl2 : NEG;
-        mx = fmaxf(mx, s[r]);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float psum = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-      psum += s[r];
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Pw[crow(r, half) * A16_SP + l31] = s[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes -> its own reads (in-order LDS)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- C: O^T tiles (dims 16 wave .., queries 16 t ..)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float al = __shfl(alpha, 16 * t + c, 64);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[t][i] *= al;
-    }
-    const float* vs = Vs;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int key = crow(2 * g + (k4 >> 1), k4 & 1);
-      const float vf = vs[key * A16_VP + 16 * wave + c];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, Pw[key * A16_SP + 16 * t + c], o[t], 0, 0, 0);
-    }
   }
+  float* Pw = Ps[w4];
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int cur = blk & 1, nxt = cur ^ 1;
+    const int kbase = blk * 32;
+    // requested one block ago, committed at the end of this one: K(blk + 2) -> Ks[cur], V(blk + 1) -> Vs[nxt]; requested now for
+    // the next iteration's commit: K(blk + 3), V(blk + 2)
+    const bool more1 = blk + 1 < nblk, more2 = blk + 2 < nblk;
+    rk_new = load_row(Kb, kbase + 96);
+    rv_new = load_row(Vb, kbase + 64);
+    if (team_a) {
+      // ---- A of the NEXT block
+      if (more1) phase_a(Ks[nxt], Ss[nxt]);
+    } else {
+      // ---- B: the block's online softmax, as in lg_attn_kernel (lane = query l31, keys crow(r, half)); every wave of the team
+      // redoes it for all 32 queries (no exchange of state)
+      const float* ss = Ss[cur];
+      float s[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = ss[crow(r, half) * A16_SP + l31];
+      // phase C's V operands do not depend on the softmax: requested with the S values (one LDS round trip for both)
+      const float* vs = Vs[cur];
+      float vfr[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) vfr[g] = vs[crow(2 * g + (k4 >> 1), k4 & 1) * A16_VP + 16 * w4 + c];
+      __builtin_amdgcn_sched_barrier(0);
+      float mx = NEG;
+      if (kbase + 32 <= nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = s[r] * sl2;
+          mx = fmaxf(mx, s[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + crow(r, half);
+          s[r] = key < nk ? s[r] * sl2 : NEG;
+          mx = fmaxf(mx, s[r]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        psum += s[r];
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Pw[crow(r, half) * A16_SP + l31] = s[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes -> its own reads (in-order LDS)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- C: O^T tiles (dims 16 w4 .., queries 16 t ..)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float al = __shfl(alpha, 16 * t + c, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[t][i] *= al;
+      }
+      float pr[8][2];  // all P operands in one batch (the chain of matrix steps then runs without LDS waits)
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pr[g][t] = Pw[crow(2 * g + (k4 >> 1), k4 & 1) * A16_SP + 16 * t + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vfr[g], pr[g][t], o[t], 0, 0, 0);
+    }
+    // Ks[cur] was last read by phase A of THIS block (previous iteration, before its barrier); Vs[nxt] by phase C of the previous block
+    if (more2) commit_k(Ks[cur], rk);
+    if (more1) commit_v(Vs[nxt], rv);
+    rk = rk_new;
+    rv = rv_new;
+    __syncthreads();
+  }
+  if (team_a) return;
   const float l = l_run + __shfl_xor(l_run, 32, 64);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const float lq = __shfl(l, 16 * t + c, 64);
     const int q = q0 + 16 * t + c;
     if (q < nq) {
-      float* orow = a.O + ((size_t)b * a.capq + q) * D + h * DH + 16 * wave + 4 * k4;
+      float* orow = a.O + ((size_t)b * a.capq + q) * D + h * DH + 16 * w4 + 4 * k4;
       *reinterpret_cast<f32x4*>(orow) = f32x4{o[t][0] / lq, o[t][1] / lq, o[t][2] / lq, o[t][3] / lq};
     }
   }
@@ -1043,7 +1073,7 @@ int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* n
   const dim3 grid((unsigned)einx_cdiv(capq, 128), (unsigned)dm.heads, (unsigned)B);
   EINX_PROF("lg_attn_kernel", st);
   if (dm.shipped() && (long)grid.x * grid.y * grid.z < 256) {  // fewer workgroups than CUs: the latency form (same bits)
-    hipLaunchKernelGGL(lg_attn16_kernel, dim3((unsigned)einx_cdiv(capq, 32), (unsigned)dm.heads, (unsigned)B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lg_attn16_kernel, dim3((unsigned)einx_cdiv(capq, 32), (unsigned)dm.heads, (unsigned)B), dim3(512), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   if (dm.shipped()) hipLaunchKernelGGL((lg_attn_kernel<64, D>), grid, dim3(256), 0, st, a);
