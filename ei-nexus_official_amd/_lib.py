@@ -51,7 +51,7 @@ class MetricParams(ctypes.Structure):
 
 class LgLayer(ctypes.Structure):
     _names = ("Wqkv", "bqkv", "Wo", "bo", "sf0_w", "sf0_b", "sln_g", "sln_b", "sf3_w", "sf3_b",
-              "Wqk", "bqk", "Wv", "bv", "Wco", "bco", "cf0_w", "cf0_b", "cln_g", "cln_b", "cf3_w", "cf3_b")
+              "Wqk", "bqk", "Wv", "bv", "Wco", "bco", "cf0_w", "cf0_b", "cln_g", "cln_b", "cf3_w", "cf3_b", "Wqk_v", "bqk_v")
     _fields_ = [(n, c_void_p) for n in _names]
 
 

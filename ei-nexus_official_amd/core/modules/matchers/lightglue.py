@@ -117,6 +117,7 @@ class LightGlue(nn.Module):
         self.token_confidence = nn.ModuleList([TokenConfidence(d) for _ in range(n - 1)])
         self.want_log_assignment = True
         self.fold_message_projection = True  # inference-time weight folding (see _pack); False = layer by layer as written
+        self.merge_qk_v = True  # CrossBlock.to_qk and to_v as one launch over a merged weight image (same results); False = two launches
         self._packed = None
         self._sig = None
         self._sig_tensors = None
@@ -174,6 +175,11 @@ class LightGlue(nn.Module):
             s, x, L = tl.self_attn, tl.cross_attn, layers[i]
             L.Wqkv, L.bqkv = p(s.Wqkv.weight), p(s.Wqkv.bias)
             L.Wqk, L.bqk, L.Wv, L.bv = p(x.to_qk.weight), p(x.to_qk.bias), p(x.to_v.weight), p(x.to_v.bias)
+            if self.merge_qk_v and c.descriptor_dim == 256 and c.num_heads == 4:  # one launch for to_qk | to_v (copies, like the folds)
+                L.Wqk_v = p(torch.cat([x.to_qk.weight.detach(), x.to_v.weight.detach()], 0).contiguous())
+                L.bqk_v = p(torch.cat([x.to_qk.bias.detach(), x.to_v.bias.detach()], 0).contiguous())
+            else:
+                L.Wqk_v, L.bqk_v = None, None
             if self.fold_message_projection:
                 sw, sb = fold(s.ffn[0], s.out_proj)
                 xw, xb = fold(x.ffn[0], x.to_out)

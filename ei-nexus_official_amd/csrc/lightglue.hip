@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
 
 // ------------------------------------------------------------------------------------------
 // fused attention: out[b,q,h*HD:(h+1)*HD] = softmax_j(scale * Q_h[q] . K_h[j]) V_h[j]
-// HD: head dim (32 / 64 / 128); DD: row width d of Q / K / V / O as a compile-time constant (256: the shipped instantiation) or 0 = a.d
+// HD: head dim (32 / 64 / 128); DD: row width d of Q / K / V / O as a compile-time constant (256: the shipped instantiation) or 0 = a.d;
+// LD: row stride of Q / K / V when they are column blocks of a wider buffer (the merged to_qk | to_v projection: 512), 0 = the width
 // ------------------------------------------------------------------------------------------
 struct AttnArgs {
   const float* Q;
@@ -406,7 +407,7 @@ struct AttnArgs {
 };
 
 constexpr int AKB = 32;   // keys staged per round (32: 124 VGPRs -> three workgroups per CU; 64: 151 -> two)
-template <int HD, int DD>
+template <int HD, int DD, int LD = 0>
 __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   constexpr int KPITCH = HD + 4;  // K rows padded by 4 floats (64-wide heads: 68): 16-byte aligned for ds_read_b128, and the 32 rows a
                                   // half-wave reads start on 16 distinct 4-bank groups (conflict-free)
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[AKB * KPITCH];
   __shared__ __attribute__((aligned(16))) float Vs[AKB * DH];
   const int D = DD ? DD : a.d;
+  const int DL = LD ? LD : D;  // row stride of Q / K / V
   // the query blocks of one (pair, head) read the same K / V: keep them on one XCD (see xcd_contiguous)
   const int gx = (int)gridDim.x, gy = (int)gridDim.y;
   int item = xcd_contiguous((int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z)), gx * gy * (int)gridDim.z);
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   const bool qv = q < nq;
   // MFMA K-step t pairs head dims (t, t + DH/2): lane half h supplies dim t + (DH/2) h, so a lane's K fragments
   // for four consecutive steps are one 16-byte LDS read
-  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * D + h * DH + (DH / 2) * half;
+  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * DL + h * DH + (DH / 2) * half;
   float qreg[DH / 2];
 #pragma unroll
   for (int t = 0; t < DH / 2; t += 4) {
@@ -439,8 +441,8 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
     qreg[t + 2] = v[2];
     qreg[t + 3] = v[3];
   }
-  const float* Kb = a.K + (size_t)bk * a.capk * D + h * DH;
-  const float* Vb = a.V + (size_t)bk * a.capk * D + h * DH;
+  const float* Kb = a.K + (size_t)bk * a.capk * DL + h * DH;
+  const float* Vb = a.V + (size_t)bk * a.capk * DL + h * DH;
   constexpr int OT = DH / 32;  // 32-wide blocks of the output row
   f32x16 o[OT];
 #pragma unroll
@@ -462,8 +464,8 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       const int fidx = tid + i * 256;
       const int row = fidx / R4, c4 = fidx % R4;
       const int key = min(kb0 + row, nk - 1);  // clamped: rows past nk are masked after the QK product
-      rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * D + c4 * 4);
-      rv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * D + c4 * 4);
+      rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * DL + c4 * 4);
+      rv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * DL + c4 * 4);
     }
   };
   auto commit = [&]() {
@@ -583,6 +585,7 @@ constexpr int A16_SP = 33;  // S / P rows: 32 queries + 1
 // double-buffered and a block costs one workgroup barrier.  (Measured on the way, per launch at one pair: all phases in four
 // waves with three barriers per block 44 us; the same with phase A moved one block ahead in the SAME waves 47 us; 16 queries per
 // workgroup, two workgroups per CU 44 us; lg_attn_kernel 76 us -- profiles/r05_notes.md 5.)
+template <int LD>  // row stride of Q / K / V: 256, or 512 when they are column blocks of the merged to_qk | to_v projection
 __global__ __launch_bounds__(512) void lg_attn16_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * A16_KP];
   __shared__ __attribute__((aligned(16))) float Vs[2][32 * A16_VP];
@@ -604,12 +607,12 @@ __global__ __launch_bounds__(512) void lg_attn16_kernel(const AttnArgs a) {
   float qf[16];
   {
     const int q = min(q0 + 16 * qq + c, nq - 1);
-    const float* Qrow = a.Q + ((size_t)b * a.capq + q) * D + h * DH + (k4 & 1) * 32 + (k4 >> 1);
+    const float* Qrow = a.Q + ((size_t)b * a.capq + q) * LD + h * DH + (k4 & 1) * 32 + (k4 >> 1);
 #pragma unroll
     for (int g = 0; g < 16; ++g) qf[g] = team_a ? Qrow[2 * g] : 0.0f;
   }
-  const float* Kb = a.K + (size_t)bk * a.capk * D + h * DH;
-  const float* Vb = a.V + (size_t)bk * a.capk * D + h * DH;
+  const float* Kb = a.K + (size_t)bk * a.capk * LD + h * DH;
+  const float* Vb = a.V + (size_t)bk * a.capk * LD + h * DH;
   f32x4 o[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(512) void lg_attn16_kernel(const AttnArgs a) {
   // staging: 32 keys x 16 float4 per operand = one float4 per thread and operand; rows past nk repeat row nk - 1 (masked in B)
   const int srow = tid >> 4, sc4 = tid & 15;
   auto load_row = [&](const float* base, int kb0) {
-    return *reinterpret_cast<const f32x4*>(base + (size_t)min(kb0 + srow, nk - 1) * D + sc4 * 4);
+    return *reinterpret_cast<const f32x4*>(base + (size_t)min(kb0 + srow, nk - 1) * LD + sc4 * 4);
   };
   auto commit_k = [&](float* dst, const f32x4& r) {  // dims d0 .. d0+3 (d0 = 4 sc4): slot (d >= 32) + 2 (d & 1), position (d & 31) >> 1
     const int hi = sc4 >> 3, g0 = (sc4 & 7) * 2;
@@ -1055,8 +1058,9 @@ int gemm_qkv_rope(hipStream_t st, const Side& s, int B, const Dims& dm, const fl
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// merged: Q, K, V are column blocks of a [.., 2 d] buffer (row stride 512; shipped widths only)
 int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* nq, int capq, const float* K, const float* V, const int32_t* nk,
-         int capk, float* O, int kv_shift = 0) {
+         int capk, float* O, int kv_shift = 0, bool merged = false) {
   AttnArgs a;
   a.kv_shift = kv_shift;
   a.Btot = B;
@@ -1073,10 +1077,14 @@ int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* n
   const dim3 grid((unsigned)einx_cdiv(capq, 128), (unsigned)dm.heads, (unsigned)B);
   EINX_PROF("lg_attn_kernel", st);
   if (dm.shipped() && (long)grid.x * grid.y * grid.z < 256) {  // fewer workgroups than CUs: the latency form (same bits)
-    hipLaunchKernelGGL(lg_attn16_kernel, dim3((unsigned)einx_cdiv(capq, 32), (unsigned)dm.heads, (unsigned)B), dim3(512), 0, st, a);
+    const dim3 g16((unsigned)einx_cdiv(capq, 32), (unsigned)dm.heads, (unsigned)B);
+    if (merged) hipLaunchKernelGGL(lg_attn16_kernel<2 * D>, g16, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(lg_attn16_kernel<D>, g16, dim3(512), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
-  if (dm.shipped()) hipLaunchKernelGGL((lg_attn_kernel<64, D>), grid, dim3(256), 0, st, a);
+  if (merged && !dm.shipped()) return -1;
+  if (merged) hipLaunchKernelGGL((lg_attn_kernel<64, D, 2 * D>), grid, dim3(256), 0, st, a);
+  else if (dm.shipped()) hipLaunchKernelGGL((lg_attn_kernel<64, D>), grid, dim3(256), 0, st, a);
   else if (dm.dh == 64) hipLaunchKernelGGL((lg_attn_kernel<64, 0>), grid, dim3(256), 0, st, a);
   else if (dm.dh == 32) hipLaunchKernelGGL((lg_attn_kernel<32, 0>), grid, dim3(256), 0, st, a);
   else if (dm.dh == 128) hipLaunchKernelGGL((lg_attn_kernel<128, 0>), grid, dim3(256), 0, st, a);
@@ -1241,13 +1249,25 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
         LG_CHECK(ffn(st, s, Br, dm, s.ctx, L.sf0_w, L.sf0_b, L.sln_g, L.sln_b, L.sf3_w, L.sf3_b));
       }
     }
+    // to_qk and to_v read the same rows: with the merged weight image [Wqk; Wv] (shipped widths) they are ONE launch writing
+    // qk | v side by side into the FFN's hidden buffer (free until ffn.0 runs), and the attention reads them at row stride 2 d --
+    // the same k-ordered chain and bias per output, one launch less per layer
+    const bool merged = L.Wqk_v && L.bqk_v && dm.shipped();
     for (int sd = 0; sd < nrun; ++sd) {
       Side& s = *run[sd];
-      LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqk, L.bqk, D, s.q, D));
-      LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wv, L.bv, D, s.v, D));
+      if (merged) {
+        LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqk_v, L.bqk_v, 2 * D, s.h, 2 * D));
+      } else {
+        LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wqk, L.bqk, D, s.q, D));
+        LG_CHECK(gemm(st, EPI_BIAS, s, Br, s.x, D, nullptr, 0, 0x7fffffff, D, L.Wv, L.bv, D, s.v, D));
+      }
     }
     if (stacked) {  // entry b attends to the keys / values of its partner entry (b + B) mod 2B
-      LG_CHECK(attn(st, Br, dm, sb.q, sb.cnt, sb.cap, sb.q, sb.v, sb.cnt, sb.cap, sb.ctx, B));
+      if (merged) LG_CHECK(attn(st, Br, dm, sb.h, sb.cnt, sb.cap, sb.h, sb.h + D, sb.cnt, sb.cap, sb.ctx, B, true));
+      else LG_CHECK(attn(st, Br, dm, sb.q, sb.cnt, sb.cap, sb.q, sb.v, sb.cnt, sb.cap, sb.ctx, B));
+    } else if (merged) {
+      LG_CHECK(attn(st, B, dm, s0.h, s0.cnt, s0.cap, s1.h, s1.h + D, s1.cnt, s1.cap, s0.ctx, 0, true));
+      LG_CHECK(attn(st, B, dm, s1.h, s1.cnt, s1.cap, s0.h, s0.h + D, s0.cnt, s0.cap, s1.ctx, 0, true));
     } else {
       LG_CHECK(attn(st, B, dm, s0.q, s0.cnt, s0.cap, s1.q, s1.v, s1.cnt, s1.cap, s0.ctx));
       LG_CHECK(attn(st, B, dm, s1.q, s1.cnt, s1.cap, s0.q, s0.v, s0.cnt, s0.cap, s1.ctx));

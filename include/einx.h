@@ -240,6 +240,9 @@ typedef struct einx_lg_layer {
   const float *Wqkv, *bqkv, *Wo, *bo, *sf0_w, *sf0_b, *sln_g, *sln_b, *sf3_w, *sf3_b;
   /* CrossBlock (:275-330) */
   const float *Wqk, *bqk, *Wv, *bv, *Wco, *bco, *cf0_w, *cf0_b, *cln_g, *cln_b, *cf3_w, *cf3_b;
+  /* optional (NULL: two launches): the rows of Wqk followed by the rows of Wv as ONE [2d, d] matrix, and [bqk | bv] -- to_qk and
+   * to_v then run as one launch (d = 256 with 64-wide heads; same results) */
+  const float *Wqk_v, *bqk_v;
 } einx_lg_layer;
 
 typedef struct einx_lg_weights {

@@ -338,3 +338,45 @@ def test_extractors_with_other_detector_parameters_vs_oracle(oracle, cfg_name, r
             assert np.array_equal(got["sparse_positions"][b].cpu().numpy(), exp["sparse_positions"][b]), f"image {b}"
             assert np.array_equal(got["sparse_descriptors"][b].cpu().numpy(), exp["sparse_descriptors"][b])
     assert sum(len(p) for p in oe["sparse_positions"]) > 0
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_lightglue_merged_qk_v_projection_equals_two_launches(B):
+    """Round 5: CrossBlock.to_qk and to_v as ONE launch over the merged weight image [Wqk; Wv] (qk | v side by side in the FFN's
+    hidden buffer, the attention reads them at row stride 512) against the two separate launches: bit-identical, on the
+    single-pair kernels (lg_gemm_small_kernel / lg_attn16_kernel<512>) and on the batch kernels (lg_gemm_kernel / lg_attn_kernel<64,256,512>)."""
+    from importlib import import_module
+    PairBatch = import_module(pkg.__name__ + ".core.modules.matchers._batched").PairBatch
+    LG = import_module(pkg.__name__ + ".core.modules.matchers.lightglue").LightGlue
+    lg = LG({"input_dim": 256}).to(DEV).eval()
+    sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in lg.state_dict().items()], seed=79)
+    lg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    n, m, cap = 1000, 1024, 1024
+    rng = np.random.default_rng(B)
+
+    def side(cnt):
+        pb = PairBatch()
+        k = np.zeros((B, cap, 3), np.float32)
+        d = np.zeros((B, cap, 256), np.float32)
+        k[:, :cnt, 0] = rng.uniform(0, 260, (B, cnt))
+        k[:, :cnt, 1] = rng.uniform(0, 346, (B, cnt))
+        v = rng.standard_normal((B, cnt, 256)).astype(np.float32)
+        d[:, :cnt] = v / np.linalg.norm(v, axis=-1, keepdims=True)
+        pb.kpts, pb.desc = _t(k), _t(d)
+        pb.counts = torch.full((B,), cnt, dtype=torch.int32, device=DEV)
+        pb.cap, pb.B, pb.image_size, pb.counts_host = cap, B, (260, 346), None
+        return pb
+
+    pb0, pb1 = side(n), side(m)
+    outs = []
+    for merged in (True, False):
+        lg.merge_qk_v = merged
+        lg.refresh()
+        w = lg._pack()[0]
+        assert bool(w.layers[0].Wqk_v) == merged
+        outs.append(pkg.native.lightglue(w, pb0, pb1, want_la=True, want_ref=True))
+    a, b = outs
+    assert torch.equal(a.matches0[:, :n], b.matches0[:, :n]) and torch.equal(a.scores0[:, :n], b.scores0[:, :n])
+    assert torch.equal(a.ref0[:, :n], b.ref0[:, :n]) and torch.equal(a.ref1[:, :m], b.ref1[:, :m])
+    assert torch.equal(a.la[:, :n, :m], b.la[:, :n, :m])
+    assert int((a.matches0[:, :n] > -1).sum()) > 0
