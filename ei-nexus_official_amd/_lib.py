@@ -73,6 +73,7 @@ SIGNATURES = {
     "einx_profile_report": (c_int, [c_char_p, c_size_t]),
     "einx_extractor_create": (c_void_p, [ctypes.POINTER(ExtractorDesc)]),
     "einx_extractor_destroy": (None, [c_void_p]),
+    "einx_fork_stream_prepare": (c_int, [c_void_p]),
     "einx_extract_shapes": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(ExtractShapes)]),
     "einx_extract_ws_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "einx_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, ctypes.POINTER(ExtractOut), c_void_p]),

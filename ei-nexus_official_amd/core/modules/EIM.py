@@ -4,6 +4,7 @@ Same constructor, checkpoint-prefix loading and `forward` contract.  The differe
 schedule: both extractors (on two HIP streams) and the matcher are enqueued for the whole batch,
 and the host only waits for two small read-backs: the keypoint counts and the match counts that
 shape the returned Python lists."""
+import ctypes
 import os
 
 import torch
@@ -56,7 +57,14 @@ class EIM(nn.Module):
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         st = EIM._side_streams.get(key)
         if st is None:
+            cur = torch.cuda.current_stream(device)
             st = EIM._side_streams[key] = torch.cuda.Stream(device=device)
+            # the native fork streams of both callers right behind them in HIP's creation order (einx.h::einx_fork_stream_prepare:
+            # created later -- after a loader's copy streams, say -- they can land on their caller's compute pipe)
+            from ..._lib import check
+            from ... import _native as N
+            for s_ in (cur, st):
+                check(N.lib().einx_fork_stream_prepare(ctypes.c_void_p(s_.cuda_stream)), "einx_fork_stream_prepare")
         return st
 
     @on_input_device

@@ -23,9 +23,13 @@
 
 #include "einx_common.h"
 
-// One library-owned side stream + fork / join events per (device, caller stream) that has forked through this handle:
-// created on first use, owned by the handle, released by einx_extractor_destroy.  `mu` is held while a call enqueues its
-// fork .. join section, so two host threads that enqueue on one stream through one handle cannot interleave on the events.
+// One library-owned side stream + fork / join events per (device, caller stream), shared by EVERY extractor handle of the
+// process (round 5; rounds 3-4 kept one per handle): HIP maps streams onto its few hardware queues in creation order, so the
+// streams of the fifth or sixth handle of a process landed on the queue of a caller's stream and the fork serialised -- bench.py's
+// single-pair leg ran 1.06 instead of 0.77 ms per forward once two more streams had been created before its model
+// (tools/experiments/r5_eager_after_run2.py).  Created on first use, never destroyed (a process forks from a handful of streams).
+// `mu` is held while a call enqueues its fork .. join section, so two host threads that enqueue on one stream cannot interleave
+// on the events; re-recording an event does not disturb waits that were enqueued on its earlier record.
 struct EinxSide {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -37,16 +41,6 @@ struct einx_extractor {
   std::vector<einx_conv_desc> backbone, det, desc;
   bool has_merged = false;  // det[0] + desc[0] as one layer (see einx_extractor_desc::merged_head0)
   einx_conv_desc merged;
-  mutable std::mutex sides_mu;
-  mutable std::map<std::pair<int, hipStream_t>, EinxSide> sides;
-  ~einx_extractor() {
-    for (auto& kv : sides) {
-      EinxSide& sd = kv.second;
-      if (sd.stream) (void)hipStreamDestroy(sd.stream);
-      if (sd.fork) (void)hipEventDestroy(sd.fork);
-      if (sd.join) (void)hipEventDestroy(sd.join);
-    }
-  }
 };
 
 namespace {
@@ -76,8 +70,11 @@ EinxSide* side_for(const einx_extractor* e, hipStream_t caller) {
   } else if (hipGetDevice(&dev) != hipSuccess) {
     return nullptr;
   }
-  std::lock_guard<std::mutex> lk(e->sides_mu);
-  EinxSide& sd = e->sides[{dev, caller}];
+  (void)e;
+  static std::mutex sides_mu;
+  static std::map<std::pair<int, hipStream_t>, EinxSide>* sides = new std::map<std::pair<int, hipStream_t>, EinxSide>();  // (leaked: see EinxSide)
+  std::lock_guard<std::mutex> lk(sides_mu);
+  EinxSide& sd = (*sides)[{dev, caller}];
   if (!sd.stream) {
     int cur = 0;
     const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
@@ -212,6 +209,14 @@ EINX_EXPORT einx_extractor* einx_extractor_create(const einx_extractor_desc* d) 
 }
 
 EINX_EXPORT void einx_extractor_destroy(einx_extractor* e) { delete e; }
+
+EINX_EXPORT int einx_fork_stream_prepare(void* stream) {
+  if (!side_for(nullptr, (hipStream_t)stream)) {
+    einx_set_error("einx_fork_stream_prepare: could not create the side stream / events");
+    return EINX_ERR_LAUNCH;
+  }
+  return EINX_OK;
+}
 
 EINX_EXPORT int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* s) {
   EINX_CHECK_ARG(e && s, "null pointer");

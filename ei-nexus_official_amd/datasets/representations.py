@@ -17,13 +17,20 @@ class EventStage:
     that an evaluation loop can pack and upload batch i + 1 while the device still works on batch i
     (harness.SameTimeEvaluator.run).  The arrays grow to the largest batch seen.  A stage must not be packed into again
     before the work that reads its previous contents has finished."""
+    _copy_streams = {}
     _FIELDS = (("x", np.float32, torch.float32), ("y", np.float32, torch.float32), ("t", np.float64, torch.float64), ("p", np.float32, torch.float32))
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.cap = 0
         self.host, self.dev = {}, {}
-        self.copy_stream = torch.cuda.Stream(self.device)  # the transfer overlaps the work already queued on the caller's stream
+        # the transfer overlaps the work already queued on the caller's stream; ONE copy stream per device for the whole process
+        # (HIP deals streams onto four compute pipes in creation order: every further stream is one more that can land on the
+        # pipe of a stream that matters, einx.h::einx_fork_stream_prepare)
+        key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+        if key not in EventStage._copy_streams:
+            EventStage._copy_streams[key] = torch.cuda.Stream(self.device)
+        self.copy_stream = EventStage._copy_streams[key]
 
     def _reserve(self, n):
         if n <= self.cap:

@@ -11,8 +11,8 @@
  *   - the caller makes the device of `stream` and of the buffers the current HIP device (hipSetDevice) before a call;
  *   - return 0 on success, negative on error (einx_last_error() gives the text);
  *   - no device-memory allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.  Two documented pieces of
- *     library-owned state: (a) an einx_extractor handle lazily creates ONE side stream + two events per caller stream that
- *     forks through it (small batches, see einx_extract) and releases them in einx_extractor_destroy; (b) einx_voxel_grid /
+ *     library-owned state: (a) einx_extract lazily creates ONE side stream + two events per (device, caller stream) that
+ *     forks (small batches, see einx_extract), shared by every handle of the process and kept until it exits; (b) einx_voxel_grid /
  *     einx_events_mask keep a few hundred bytes of pinned staging per host thread for the host offsets array;
  *   - einx_build_flags() tells a shipped library from a timing-only experiment build (see below).
  * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
@@ -368,6 +368,13 @@ typedef struct einx_extract_out {
 
 einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
 void einx_extractor_destroy(einx_extractor* e);
+/* Optional: create the library's side stream + fork / join events of `stream` NOW instead of at the first small-batch
+ * einx_extract on it.  HIP deals streams onto the GPU's compute pipes in creation order (four pipes: the fifth stream of a
+ * process shares a pipe with the first), so a fork stream created right after its caller's stream runs beside it, one created
+ * after several unrelated streams may land on the caller's own pipe and the fork serialises (single pair: 0.77 -> 1.06 ms).  A
+ * host that creates further streams of its own calls this once per caller stream first; the Python package does so when a model
+ * is first used on a device. */
+int einx_fork_stream_prepare(void* stream);
 int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* shapes);
 /* nms_iters: NMS pass budget per call (see einx_detect); <= 0 selects the default (8) in BOTH functions below.  The
  * workspace size depends on it (B x nms_iters convergence flags), so query and call must pass the same value. */
