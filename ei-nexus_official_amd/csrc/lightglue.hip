@@ -1076,7 +1076,10 @@ int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* n
   a.scale = 1.0f / sqrtf((float)dm.dh);  // SDPA scale (self) = (dh^-1/4)^2 (cross, lightglue.py:316); 64-wide heads: exactly 0.125
   const dim3 grid((unsigned)einx_cdiv(capq, 128), (unsigned)dm.heads, (unsigned)B);
   EINX_PROF("lg_attn_kernel", st);
-  if (dm.shipped() && (long)grid.x * grid.y * grid.z < 256) {  // fewer workgroups than CUs: the latency form (same bits)
+  // the latency form (same bits) while ITS grid fits the chip twice: fewer wide workgroups than CUs alone is not enough -- three
+  // pairs of 1024 keypoints (768 latency-form workgroups of eight waves, 1.5 rounds) ran 3.67 instead of 3.26 ms; one pair
+  // 1.82 instead of 2.39 ms, two pairs 2.51 instead of 2.68 (tools/lg_bench.py --batch 1 / 2 / 3 --skip-linear)
+  if (dm.shipped() && (long)grid.x * grid.y * grid.z < 256 && (long)einx_cdiv(capq, 32) * dm.heads * B <= 512) {
     const dim3 g16((unsigned)einx_cdiv(capq, 32), (unsigned)dm.heads, (unsigned)B);
     if (merged) hipLaunchKernelGGL(lg_attn16_kernel<2 * D>, g16, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(lg_attn16_kernel<D>, g16, dim3(512), 0, st, a);
