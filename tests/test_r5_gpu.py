@@ -407,3 +407,40 @@ def test_harness_run_streams_batches_with_the_results_of_step():
     ra, rb = a.result(), b.result()  # b saw every batch three times: same means
     for k in ra:
         assert (ra[k] != ra[k] and rb[k] != rb[k]) or abs(ra[k] - rb[k]) <= 1e-12 * max(1.0, abs(ra[k])), k
+
+
+def test_forwards_on_other_caller_streams_share_the_process_wide_fork_streams():
+    """Round 5: the small-batch head fork uses ONE library-owned side stream per (device, caller stream) for the whole process
+    (HIP deals streams onto four compute pipes in creation order: per-handle fork streams created late landed on their callers'
+    pipes).  Single pairs from two models, on the default stream and on a stream of the caller's own, prepared explicitly or
+    not, give the results of the first call; a second prepare of the same stream is a no-op."""
+    import ctypes
+    from helpers import synth
+    cfg = pkg.default_config("SP_MNN", event_channels=5)
+    models = []
+    for seed in (51, 51):
+        m = pkg.EIM(cfg, device=DEV).eval()
+        sd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=seed)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        models.append(m)
+    ev, mask = synth.synth_events(97, 1, 5)
+    img = synth.synth_image(97, 1)
+    ref = models[0](_t(ev), _t(img.copy()), _t(mask))
+    own = torch.cuda.Stream(DEV)
+    L = pkg.native.lib()
+    assert L.einx_fork_stream_prepare(ctypes.c_void_p(own.cuda_stream)) == 0
+    assert L.einx_fork_stream_prepare(ctypes.c_void_p(own.cuda_stream)) == 0
+    other = torch.cuda.Stream(DEV)  # not prepared: created at its first fork
+    for m, stream in ((models[1], own), (models[0], other), (models[1], None)):
+        e_, i_, k_ = _t(ev), _t(img.copy()), _t(mask)
+        torch.cuda.synchronize()
+        if stream is None:
+            out = m(e_, i_, k_)
+        else:
+            with torch.cuda.stream(stream):
+                out = m(e_, i_, k_)
+            stream.synchronize()
+        for a, b in zip(ref[:2], out[:2]):
+            assert torch.equal(a["sparse_positions"][0], b["sparse_positions"][0])
+            assert torch.equal(a["sparse_descriptors"][0], b["sparse_descriptors"][0])
+        assert torch.equal(ref[2]["matches0"][0], out[2]["matches0"][0])
