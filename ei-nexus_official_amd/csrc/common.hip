@@ -64,6 +64,8 @@ EinxProfScope::~EinxProfScope() {
   if (gen_ == g_prof_gen && idx_ < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx_].e1, stream_);
 }
 
+bool einx_profile_active() { return g_prof_on != 0; }
+
 EINX_EXPORT int einx_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof_recs) {

@@ -45,6 +45,7 @@ class EinxProfScope {
 };
 
 #define EINX_PROF(name, stream) EinxProfScope einx_prof_scope_(name, (hipStream_t)(stream))
+bool einx_profile_active();  // the per-launch scopes are recording: kernels are meant to be timed alone (no concurrent branches)
 
 // Workgroups are dealt round-robin over the 8 XCDs in linear dispatch order (observed placement: speed only, never
 // correctness), each XCD with its own L2.  xcd_contiguous() turns the linear workgroup id into a work-item id such that every

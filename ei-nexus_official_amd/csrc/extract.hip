@@ -59,8 +59,12 @@ struct Plan {
 // normalisation) does not depend on the detector branch (head convs, score map, NMS passes, selection) until the sparse
 // sampling, so it is enqueued on a second, library-owned stream between a fork and a join event: at B=1 ~90 us of ~540 per
 // network leave the critical path.  The rule depends only on the arguments that size the workspace (a second head scratch).
-constexpr long kForkMaxCells = 8192;  // B x head pixels up to which the two head branches run concurrently (B <= 5 at 33x44)
-bool fork_heads(const einx_extractor* e, const Plan& pl, int B) { return (long)B * pl.hc * pl.wc <= kForkMaxCells; }
+// Round 5: the networks with 1/8-resolution heads fork at EVERY batch size -- at B = 32 the detector branch's latency-bound tail
+// (score map, eight NMS passes, selection) then runs beside the descriptor head's convolutions of the same network as well as
+// beside the other extractor: SP+MNN 8.52-8.60 -> 8.43-8.47 ms per step, SP+LightGlue B = 64 62.2 -> 61.6 (A/B on one box,
+// alternating libraries).  The full-resolution networks (SiLK family) measured the same either way at B = 32 and keep the limit.
+constexpr long kForkMaxCells = 8192;  // B x head pixels up to which the two head branches of a full-resolution network run concurrently
+bool fork_heads(const einx_extractor* e, const Plan& pl, int B) { return e->d.cell == 8 || (long)B * pl.hc * pl.wc <= kForkMaxCells; }
 
 // the side of `caller` (keyed on the stream's OWN device, not on the current one)
 EinxSide* side_for(const einx_extractor* e, hipStream_t caller) {
@@ -270,7 +274,8 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
   p += align256(pl.buf_elems[1] * B * sizeof(float));
   float* head = (float*)p;
   p += align256(pl.head_elems * B * sizeof(float));
-  bool fork = fork_heads(e, pl, B);
+  // (while einx_profile_enable(1) records per-launch times the branches stay in line: its numbers are kernels ALONE on the chip)
+  bool fork = fork_heads(e, pl, B) && !einx_profile_active();
   {  // a fork nested inside a caller's own fork crashes hipStreamEndCapture (ROCm 7.2): under capture the branches stay in line
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (fork && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fork = false;

@@ -12,7 +12,7 @@
  *   - return 0 on success, negative on error (einx_last_error() gives the text);
  *   - no device-memory allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.  Two documented pieces of
  *     library-owned state: (a) einx_extract lazily creates ONE side stream + two events per (device, caller stream) that
- *     forks (small batches, see einx_extract), shared by every handle of the process and kept until it exits; (b) einx_voxel_grid /
+ *     forks (see einx_extract), shared by every handle of the process and kept until it exits; (b) einx_voxel_grid /
  *     einx_events_mask keep a few hundred bytes of pinned staging per host thread for the host offsets array;
  *   - einx_build_flags() tells a shipped library from a timing-only experiment build (see below).
  * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
@@ -56,7 +56,8 @@ int einx_params_hash(const int64_t* table, int n, uint64_t* hash, const uint64_t
  * whole forwards, test_events-image_same-time.py:196-208): while enabled, every kernel launch of
  * this library is bracketed by HIP events recorded on the launch stream.  einx_profile_report
  * waits for them and writes one text line per kernel class, "name calls total_ms\n", into `buf`
- * (host memory).  einx_profile_enable(0|1) also clears the collected records. */
+ * (host memory).  einx_profile_enable(0|1) also clears the collected records.  While enabled einx_extract keeps its two head
+ * branches in line (no fork), so that every number is a kernel alone on the chip. */
 int einx_profile_enable(int on);
 int einx_profile_report(char* buf, size_t cap);
 
@@ -381,12 +382,13 @@ int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shap
 size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int cap, int nms_iters);
 /* in [B,cin,H,W] (modified in place only when input_div is set); mask [B,1,H,W] uint8 or NULL;
  * ws: device scratch, ws_bytes >= einx_extract_ws_bytes(e, B, H, W, out->cap, nms_iters) (checked).
- * Small batches (B x head pixels <= 8192) enqueue the descriptor branch on a library-owned side stream between a fork and
- * a join event of `stream`; every return path has `stream` wait for the join.  The side stream and its two events are created
- * on the FIRST such call for a (device, stream) pair and belong to the handle -- so make one un-captured call per stream
- * before capturing einx_extract into a hipGraph (stream / event creation is not capturable), and destroy the handle only
- * after the streams it served have drained.  While `stream` is being captured the branches are enqueued in line (no fork: a
- * fork nested in a caller's own fork / join makes hipStreamEndCapture of ROCm 7.2 crash).  Calls through one handle on one stream are serialised on a mutex. */
+ * Networks with 1/8-resolution heads (cell == 8; full-resolution networks while B x head pixels <= 8192) enqueue the descriptor
+ * branch on a library-owned side stream between a fork and a join event of `stream`; every return path has `stream` wait for the
+ * join.  The side stream and its two events are created on the FIRST such call for a (device, stream) pair (or by
+ * einx_fork_stream_prepare) and are shared by every handle of the process -- so make one un-captured call (or the prepare call) per
+ * stream before capturing einx_extract into a hipGraph (stream / event creation is not capturable).  While `stream` is being
+ * captured the branches are enqueued in line (no fork: a fork nested in a caller's own fork / join makes hipStreamEndCapture of
+ * ROCm 7.2 crash).  Calls that fork from one stream are serialised on a mutex. */
 int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
                  size_t ws_bytes, const einx_extract_out* out, void* stream);
 
