@@ -349,12 +349,25 @@ def record_flips(tag, got, exp, la=None):
     return int(bad.size)
 
 
-def check_flips_with_margins(tag, got, ref, desc_rows, desc_cols, tol=2e-5, max_flips=2):
-    """`got` vs the reference's `ref` (arg-max match indices of the rows of desc_rows against desc_cols, -1 = unmatched).  The
-    reference accumulates its similarities in MKL's order, the kernels as a k-ordered fmaf chain, so an arg-max may
-    legitimately differ where the two best candidates are closer than the fp32 dot-product noise.  EVERY differing row must
-    be such a near-tie under the EXACT (float64) similarity: best minus second best of its row, or of one of the two candidate
-    columns (the mutual check), below `tol`.  Rows and margins go to the parity record; returns the number of flips."""
+_MNNSTAB = None
+
+
+def ref_unstable(case, key):
+    """{row: set(values)}: the rows of `key` (matches0 / matches1, indices into the per-case concatenation of e2e.npz) at which
+    the REFERENCE differs from itself -- 1 vs 8 torch threads, oneDNN off, sample by sample, the whole model in float64, its
+    matcher alone on permuted keypoints / in float64 (tests/golden/gen_golden.py::gen_mnnstab) -- with the values those runs gave."""
+    global _MNNSTAB
+    if _MNNSTAB is None:
+        _MNNSTAB = np.load(os.path.join(GOLDEN, "mnnstab.npz"))
+    rows = _MNNSTAB[f"{case}.{key}.ref_unstable_rows"]
+    alt = _MNNSTAB[f"{case}.{key}.ref_unstable_alt"]
+    return {int(r): {int(v) for v in alt[i] if v != -2} for i, r in enumerate(rows)}
+
+
+def check_matches_vs_reference(tag, case, key, got, ref):
+    """`got` vs the reference's stored `ref` (both the per-case concatenation over the batch, -1 = unmatched): equal, except
+    at rows where the reference is recorded as unstable against ITSELF, and there `got` must be one of the values the
+    reference's own alternative evaluations gave.  No tolerance, no count budget.  Returns the differing rows."""
     got, ref = np.asarray(got).reshape(-1), np.asarray(ref).reshape(-1)
     assert got.shape == ref.shape, (tag, got.shape, ref.shape)
     bad = np.nonzero(got != ref)[0]
@@ -362,21 +375,27 @@ def check_flips_with_margins(tag, got, ref, desc_rows, desc_cols, tol=2e-5, max_
     rec["compared"] += int(got.size)
     rec["matched"] += int((ref > -1).sum())
     rec["flips"] += int(bad.size)
-    assert bad.size <= max_flips, f"{tag}: {bad.size} match indices differ from the reference"
-    if bad.size:
-        d0, d1 = np.asarray(desc_rows, np.float64), np.asarray(desc_cols, np.float64)
-        for i in bad:
-            row = np.sort(d1 @ d0[i])[::-1]
-            gaps = [float(row[0] - row[1])] if row.size > 1 else []
-            for j in (got[i], ref[i]):
-                if j >= 0:
-                    col = np.sort(d0 @ d1[j])[::-1]
-                    if col.size > 1:
-                        gaps.append(float(col[0] - col[1]))
-            gap = min(gaps) if gaps else None
-            rec["margins"].append({"row": int(i), "got": int(got[i]), "exp": int(ref[i]), "min_gap": gap})
-            assert gap is not None and gap < tol, f"{tag}: row {i} differs from the reference ({got[i]} vs {ref[i]}) with an exact-similarity margin of {gap}"
-    return int(bad.size)
+    allowed = ref_unstable(case, key)
+    for i in bad:
+        rec["margins"].append({"row": int(i), "got": int(got[i]), "exp": int(ref[i]), "reference_unstable": int(i) in allowed,
+                               "reference_alternatives": sorted(allowed.get(int(i), ()))})
+        assert int(i) in allowed, f"{tag}: row {i} differs from the reference ({got[i]} vs {ref[i]}) and the reference is stable there"
+        assert int(got[i]) in allowed[int(i)], f"{tag}: row {i} = {got[i]}, the reference's own evaluations give {ref[i]} or {sorted(allowed[int(i)])}"
+    return bad
+
+
+def record_only(tag, got, exp, bound):
+    """Records max |got - exp| next to `bound` WITHOUT gating on it (end-to-end log_assignment against the reference: the bound
+    carries the reference's input sensitivity and is too loose to be a gate; the gate is the same-input comparison with the
+    oracle, helpers.la_bound)."""
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    assert got.shape == exp.shape, (tag, got.shape, exp.shape)
+    err = float(np.abs(got - exp).max()) if got.size else 0.0
+    rec = _ERRORS.setdefault(tag, {"max_abs_err": 0.0, "max_abs_ref": 0.0, "atol": bound, "rtol": 0.0, "n": 0, "gate": False})
+    rec["max_abs_err"] = max(rec["max_abs_err"], err)
+    rec["max_abs_ref"] = max(rec["max_abs_ref"], float(np.abs(exp).max()) if exp.size else 0.0)
+    rec["n"] += int(got.size)
+    return err
 
 
 def row_checksums(raw):

@@ -4,7 +4,7 @@ of BASELINE.json's north_star) where conv/GEMM accumulation order legitimately d
 import numpy as np
 import pytest
 
-from helpers import (Golden, la_bound, la_bound_e2e, upstream_deviation, lg_inputs, lg_noise, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth, train_inputs,
+from helpers import (Golden, check_matches_vs_reference, la_bound, la_bound_e2e, upstream_deviation, lg_inputs, lg_noise, mnn_inputs, score_map, split, state_dict_for, sub_dict, synth, train_inputs,
                      twin_inputs, twin_state_dict_for)
 
 FTOL = 1e-4
@@ -331,37 +331,32 @@ def test_e2e_full_size(oracle, name):
     _check_feats(f"{name}.ev", ef, E2E)
     _check_feats(f"{name}.im", imf, E2E)
     ms = _match_lists(oracle, c["cfg"], sd, ef, imf)
-    exact = True
+    # match indices: equal to the reference's, except at rows where the reference is recorded as differing from ITSELF
+    # (tests/golden/mnnstab.npz: other thread counts, oneDNN off, float64, permuted keypoints), and there the value must be one
+    # of those its own alternative evaluations gave.  No tolerance, no count budget.
+    dropped = [set() for _ in ms]  # per pair: rows of side 0 the reference matched and this run left unmatched
     for key in ("matches0", "matches1"):
-        exp = split(E2E[f"{name}.m.{key}"], E2E[f"{name}.m.{key}.lens"])
-        for b, r in enumerate(ms):
-            bad = np.nonzero(r[key] != exp[b])[0]
-            if bad.size == 0:
-                continue
-            # An arg-max may legitimately flip between the reference's (MKL) and the oracle's
-            # (k-ordered fmaf) accumulation order when the two best similarities are closer than
-            # the fp32 dot-product noise.  Accept ONLY such rows/columns, and only a handful.
-            exact = False
-            assert r.get("similarity") is not None and bad.size <= 2, f"{key}: {bad.size} mismatches for pair {b}"
-            sim = r["similarity"] if key == "matches0" else r["similarity"].T
+        got = np.concatenate([np.asarray(r[key]).reshape(-1) for r in ms])
+        if c["matcher"] == "MNN":
+            bad = check_matches_vs_reference(f"oracle e2e.{name}.{key} vs reference", name, key, got, E2E[f"{name}.m.{key}"])
+        else:
+            bad = np.nonzero(got != E2E[f"{name}.m.{key}"])[0]
+            assert bad.size == 0, f"{key}: rows {bad.tolist()} differ from the reference"
+        if key == "matches0":
+            starts = np.concatenate([[0], np.cumsum(E2E[f"{name}.m.{key}.lens"])])
             for i in bad:
-                cand = [v for v in (r[key][i], exp[b][i]) if v >= 0]
-                top = np.sort(sim[i])[::-1][:2]
-                gap_row = top[0] - top[1]
-                gap_col = np.inf
-                if cand:
-                    t2 = np.sort(sim[:, cand[0]])[::-1][:2]
-                    gap_col = t2[0] - t2[1]
-                assert min(gap_row, gap_col) < 2e-5, (key, b, i, gap_row, gap_col)
+                b = int(np.searchsorted(starts, i, side="right") - 1)
+                assert got[i] == -1  # (an alternative that is another index would need a value comparison below)
+                dropped[b].add(int(i - starts[b]))
     for key in ("matched_kpts0", "matched_kpts1"):
         lens = E2E[f"{name}.m.{key}.lens"]
         exp = split(E2E[f"{name}.m.{key}"], lens)
+        ref0 = split(E2E[f"{name}.m.matches0"], E2E[f"{name}.m.matches0.lens"])
         for b, r in enumerate(ms):
-            if not exact:
-                assert abs(r[key].shape[0] - exp[b].shape[0]) <= 2
-                continue
-            assert r[key].shape == exp[b].shape
-            np.testing.assert_allclose(r[key], exp[b], atol=FTOL)
+            rows = np.nonzero(ref0[b] > -1)[0]  # the reference lists its matched keypoints in row order of side 0
+            keep = np.array([int(i) not in dropped[b] for i in rows], bool)
+            assert r[key].shape == exp[b][keep].shape
+            np.testing.assert_allclose(r[key], exp[b][keep], atol=FTOL)
     for b, r in enumerate(ms):
         la = r["log_assignment"]
         assert list(la[None].shape) == E2E[f"{name}.m.la_shapes"][b].tolist()

@@ -198,16 +198,18 @@ def test_baseline_batch_sampled_pairs_vs_oracle_lightglue(oracle):
                              oi["sparse_positions"][0], oi["sparse_descriptors"][0])
         g0, e0 = _np(m["matches0"][b])[0], np.asarray(r["matches0"]).reshape(-1)
         assert int((e0 > -1).sum()) >= 100, f"pair {b}: the calibrated workload should match hundreds of keypoints, got {int((e0 > -1).sum())}"
-        nflip = record_flips("B64 sp_lg (same scene) matches0 vs oracle", g0, e0, r["log_assignment"])
-        if nflip:
-            # flash-style attention sums in a different order than the oracle: an assignment may flip only where the
-            # oracle's own decision margin is inside the float noise
-            la = r["log_assignment"]
-            bad = np.nonzero(g0 != e0)[0]
-            assert len(bad) <= 2, f"pair {b}: {len(bad)} assignments differ"
-            for i in bad:
-                row = np.sort(la[i, :-1])[::-1]
-                assert row[0] - row[1] < bound, f"pair {b}: row {i} differs with margin {row[0] - row[1]}"
+        record_flips("B64 sp_lg (same scene) matches0 vs oracle", g0, e0, r["log_assignment"])
+        # flash-style attention sums in a different order than the oracle: an assignment may differ ONLY at rows of the
+        # allow-list built from the oracle's own decision margins (best minus second best of the row, or of the chosen column,
+        # inside the same-input log_assignment bound); no count budget
+        la = np.asarray(r["log_assignment"])[:-1, :-1]
+        top2r = np.sort(la, axis=1)[:, -2:]
+        top2c = np.sort(la, axis=0)[-2:, :]
+        row_gap = top2r[:, 1] - top2r[:, 0]
+        col_gap = top2c[1] - top2c[0]
+        allow = {int(i) for i in np.nonzero((row_gap < bound) | (col_gap[np.argmax(la, axis=1)] < bound))[0]}
+        bad = np.nonzero(g0 != e0)[0]
+        assert {int(i) for i in bad} <= allow, f"pair {b}: rows {sorted({int(i) for i in bad} - allow)} differ outside the oracle's near-tie rows"
         gla = _np(m["log_assignment"][b])[0] if m["log_assignment"][b] is not None else None
         if gla is not None:
             close_and_record("B64 sp_lg (same scene) log_assignment vs oracle", gla[::53, ::47], r["log_assignment"][::53, ::47], atol=bound)
