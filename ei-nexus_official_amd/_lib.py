@@ -83,6 +83,8 @@ SIGNATURES = {
     "einx_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "einx_conv_block": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
     "einx_div_inplace": (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
+    "einx_image_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
+                           c_float, c_void_p, c_void_p]),
     "einx_score_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, c_void_p]),
     "einx_remove_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

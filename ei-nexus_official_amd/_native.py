@@ -182,6 +182,21 @@ def div_inplace(x, divisor):
     return x
 
 
+def image_prepare(image, divisor):
+    """SuperPointv1's input handling for RGB / non-contiguous images (superpoint_extractor.py:372-376): `image /= divisor` in
+    place THROUGH the tensor's strides, and the network's contiguous single-channel input (C == 3: kornia's rgb_to_grayscale of
+    the scaled image) as a new tensor.  divisor 1.0 = the image has been scaled by an earlier call (x / 1 == x)."""
+    _dev_check(image)
+    if image.dtype != F32:
+        raise TypeError("einx extractors compute in fp32; pass a float32 tensor")
+    B, C, H, W = image.shape
+    gray = torch.empty((B, 1, H, W), dtype=F32, device=image.device)
+    if gray.numel():
+        sb, sc, sh, sw = image.stride()
+        check(lib().einx_image_prepare(_ptr(image), B, C, H, W, sb, sc, sh, sw, float(divisor), _ptr(gray), _stream(image)), "einx_image_prepare")
+    return gray
+
+
 # ------------------------------------------------------------------------------ detector
 def score_map(logits, mask=None, pads=(0, 0, 0, 0), dilate=False, border=0):
     """-> (probability [B,C,hc,wc], score [B,1,Hp,Wp])."""
@@ -371,7 +386,7 @@ def lightglue(weights, pb0, pb1, want_la=True, want_ref=False, all_layers=False)
     d = int(weights.d)
     nbytes = L.einx_lg_ws_bytes_heads(B, cap0, cap1, d, int(weights.heads), int(weights.input_dim))
     if not nbytes:
-        raise NotImplementedError("einx LightGlue: descriptor_dim must be num_heads x head_dim with head_dim 32, 64 or 128")
+        raise NotImplementedError("einx LightGlue: descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 128")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     r = MatchResult()
     r.matches0 = torch.empty((B, cap0), dtype=torch.int64, device=dev)

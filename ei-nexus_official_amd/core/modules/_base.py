@@ -127,6 +127,13 @@ class NativeExtractor(nn.Module):
     def _prepare_input(self, x):
         return x
 
+    def _network_input(self, x, prepared):
+        """-> (the tensor the network reads, the divisor einx_extract applies to it IN PLACE).  prepared=True: an in-place input
+        scaling has already been applied by an earlier call of the same forward and must not run twice."""
+        if not (prepared and self.input_div):
+            x = self._prepare_input(x)
+        return x, (0.0 if prepared else self.input_div)
+
     def _pooled_padding0_error(self, x, score_mask):
         """VGGExtractor(padding=0) (pooled, un-padded 3x3 layers) constructs in the reference but no forward of it can complete
         (measured with the reference, tests/golden/gen_pad0_pooled.py): its score map is smaller than the padded input (eight valid
@@ -162,15 +169,14 @@ class NativeExtractor(nn.Module):
             raise RuntimeError("the native path implements eval-mode BatchNorm (running statistics) only; call .eval() first")
         if getattr(self, "padding", 1) == 0 and self.cell_size == 8:
             self._pooled_padding0_error(x, score_mask)
-        if not (prepared and self.input_div):
-            x = self._prepare_input(x)
+        x, input_div = self._network_input(x, prepared)
         eng = self.engine()
         if self._scale_host is None:  # one device read per engine build, not one host sync per forward
             self._scale_host = float(self.descriptor_scale_factor.detach())
         scale = self._scale_host
         # (the engine's weight watch runs inside the call and reports through bit 1 of det.not_converged[0])
         return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
-                       nms_iters=nms_iters, input_div=0.0 if prepared else self.input_div, defer_dense=defer_dense)
+                       nms_iters=nms_iters, input_div=input_div, defer_dense=defer_dense)
 
     @on_input_device
     def forward(self, x, score_mask=None, **kwargs):

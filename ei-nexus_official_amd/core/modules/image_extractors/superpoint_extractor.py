@@ -5,6 +5,7 @@ same constructor, `conv1a..convDb` state_dict keys, output dict and the in-place
 side effect (:372).  The reference downloads pretrained weights in its constructor (:316-317);
 this build has no network access by design -- load them with `load_state_dict`.
 """
+import torch
 from torch import nn
 
 from .... import _native as N
@@ -53,11 +54,19 @@ class SuperPointv1(NativeExtractor):
               ((self.conv3a, True), False), ((self.conv3b, True), True), ((self.conv4a, True), False), ((self.conv4b, True), False)]
         return bb, [(self.convPa, True), (self.convPb, False)], [(self.convDa, True), (self.convDb, False)]
 
-    def _prepare_input(self, image):
+    def _network_input(self, image, prepared):
+        """`image /= 255.0` on the CALLER's tensor, then `rgb_to_grayscale` for 3-channel images (:372-376).  Contiguous
+        single-channel images (what the EI-Nexus pipelines feed) are scaled in place inside einx_extract; RGB and / or
+        non-contiguous images go through einx_image_prepare: scaled in place through their strides -- the caller sees the scaled
+        tensor afterwards, as with the reference -- and the network reads a contiguous gray copy (kornia 0.7.1's weights)."""
         if image.dim() != 4:
             raise AssertionError(f"Expected 4D tensor, got {image.dim()}D tensor instead.")
-        if image.shape[1] != 1:
-            raise NotImplementedError("einx SuperPointv1 takes single-channel images (the EI-Nexus pipelines feed grayscale)")
-        if not image.is_contiguous():
-            raise RuntimeError("einx: image must be contiguous (it is scaled in place like the reference does)")
-        return image  # `image /= 255.0` happens in place inside the extractor call (input_div)
+        C = image.shape[1]
+        if C == 1 and image.is_contiguous():
+            return image, (0.0 if prepared else self.input_div)
+        if C not in (1, 3):  # the reference scales in place, then conv1a refuses the tensor
+            if not prepared and image.is_contiguous() and image.dtype is torch.float32 and image.device.type == "cuda":
+                N.div_inplace(image, self.input_div)
+            raise RuntimeError(f"Given groups=1, weight of size [64, 1, 3, 3], expected input{list(image.shape)} to have 1 channels, "
+                               f"but got {C} channels instead")
+        return N.image_prepare(image, 1.0 if prepared else self.input_div), 0.0

@@ -144,6 +144,56 @@ EINX_EXPORT int einx_div_inplace(float* x, size_t n, float divisor, void* stream
 
 
 // ------------------------------------------------------------------------------------------
+// SuperPointv1's input handling for what the contiguous single-channel fast path (einx_extract's input_div) does not cover:
+//   image /= 255.0                      in place on the CALLER's tensor, through its strides (superpoint_extractor.py:372)
+//   if C == 3: rgb_to_grayscale(image)  kornia 0.7.1 (requirements.txt:56; absent here): (w_r r + w_g g) + w_b b with the fp32
+//                                       weights (0.299, 0.587, 0.114), each product and sum rounded on its own (:375-376)
+// One pass: every element is divided where it lies (the caller sees the scaled RGB / strided image afterwards, as with the
+// reference) and the network's contiguous [B,1,H,W] input is written beside it.  A thread owns one pixel: four pixels of a row
+// per thread when the rows are contiguous and 16-byte aligned would be faster, but this is 0.36 MB per image on a path the
+// shipped pipelines (grayscale, contiguous) never take.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void image_prepare_kernel(float* img, int C, int H, int W, long long sB, long long sC, long long sH, long long sW,
+                                                            float d, float* gray, long long npix) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const int x = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  const long long b = p / ((long long)W * H);
+  float* q = img + b * sB + (long long)y * sH + (long long)x * sW;
+  if (C == 1) {
+    const float v = q[0] / d;
+    q[0] = v;
+    gray[p] = v;
+  } else {
+    const float r = q[0] / d, g = q[sC] / d, bl = q[2 * sC] / d;
+    q[0] = r;
+    q[sC] = g;
+    q[2 * sC] = bl;
+    gray[p] = (0.299f * r + 0.587f * g) + 0.114f * bl;  // -ffp-contract=off: three products, two sums, each rounded to fp32
+  }
+}
+}  // namespace
+
+EINX_EXPORT int einx_image_prepare(float* image, int B, int C, int H, int W, long long stride_b, long long stride_c, long long stride_h,
+                                   long long stride_w, float divisor, float* gray, void* stream) {
+  EINX_CHECK_ARG(image && gray, "null pointer");
+  EINX_CHECK_ARG(C == 1 || C == 3, "1 (gray) or 3 (RGB) channels");
+  EINX_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad shape");
+  EINX_CHECK_ARG(divisor != 0.0f, "divisor must not be zero");
+  const long long npix = (long long)B * H * W;
+  const long long blocks = (npix + 255) / 256;
+  EINX_CHECK_ARG(blocks < (1ll << 31), "tensor too large");
+  EINX_PROF("image_prepare_kernel", (hipStream_t)stream);
+  hipLaunchKernelGGL(image_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image, C, H, W, stride_b, stride_c, stride_h,
+                     stride_w, divisor, gray, npix);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Content watch of a module's weights (round 4).  The reference's modules are plain nn.Modules: an in-place edit of a
 // weight through `p.data` takes effect at the next forward.  Here weights are repacked / folded into kernel-native images,
 // and `.data` edits do not move the version counters the host-side cache keys on.  One 64-lane wave per table row hashes every

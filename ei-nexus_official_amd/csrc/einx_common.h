@@ -69,12 +69,22 @@ struct EinxWatch {
 #ifdef __HIPCC__
 // one 64-lane wave hashes EVERY word of table row t (round 5; round 4 sampled 65 words per tensor).  Rows are chunks of at most
 // a few thousand words (the host cuts the tensors, einx.h: EINX_WATCH_CHUNK_WORDS), so the loads of a row are all in flight
-// at once.  term(word, position) = ((position << 32) + word) * odd constant is injective in (word, position); the wrap-around
-// sum over a row is order independent, so any edit of any word changes the row's hash (up to a 2^-64 cancellation).
+// at once.  term(word, position) = mix64((position << 32) | word): a bijective, NON-LINEAR finaliser (multiply, xor-shift,
+// multiply, xor-shift) of the injective (position, word) code, summed with wrap-around (order independent).  Round 5 used
+// ((position << 32) + word) * constant, which is linear: the row hash only depended on the SUM of the words, so a permutation
+// inside a row or a +5 / -5 edit of two words went unseen.  Now any single-word edit changes the hash for certain
+// and multi-word edits collide with probability ~2^-64, wherever the words sit.
+__device__ __forceinline__ unsigned long long einx_watch_term(unsigned long long pos, uint32_t word) {
+  unsigned long long x = (pos << 32) | word;
+  x *= 0x9E3779B97F4A7C15ull;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 32;
+  return x;
+}
 __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int lane) {
   const uint32_t* p = reinterpret_cast<const uint32_t*>((uintptr_t)w.table[2 * t]);
   const long long n = w.table[2 * t + 1];
-  constexpr unsigned long long MIX = 0x9E3779B97F4A7C15ull;
   unsigned long long h = 0;
   long long i0 = 0;
   if ((((uintptr_t)p) & 15) == 0) {  // 16-byte loads, eight per lane in flight
@@ -93,13 +103,13 @@ __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int
         const long long j = j0 + lane + 64 * u;
         if (j < n4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h += ((((unsigned long long)(4 * j + e)) << 32) + v[u][e]) * MIX;
+          for (int e = 0; e < 4; ++e) h += einx_watch_term((unsigned long long)(4 * j + e), v[u][e]);
         }
       }
     }
     i0 = n4 << 2;
   }
-  for (long long i = i0 + lane; i < n; i += 64) h += ((((unsigned long long)i) << 32) + p[i]) * MIX;
+  for (long long i = i0 + lane; i < n; i += 64) h += einx_watch_term((unsigned long long)i, p[i]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off, 64);  // wrap-around sum: order independent
   if (lane == 0) {

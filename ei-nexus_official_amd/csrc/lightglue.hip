@@ -77,7 +77,7 @@ struct GemmArgs {
   // rotary encoding to q and k in the epilogue and writes the three [B,cap,d] buffers directly
   const float* enc;  // [B,cap,2 dh]: cos(dh) | sin(dh)
   float *Yq, *Yk, *Yv;
-  int d, dh;  // read by EPI_ROPE_ANY only (dh a power of two)
+  int d, dh;  // read by EPI_ROPE_ANY only (dh even: rotary pairs are adjacent columns)
 };
 
 // Persistent workgroups: the launch holds as many workgroups as the chip runs at once (a multiple
@@ -166,8 +166,9 @@ __global__ __launch_bounds__(THREADS, 2 * THREADS / 256) void lg_gemm_kernel(con
               const float* e = encb + (size_t)(i < n ? i : n - 1) * (2 * rdh);
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                cs[r][nt] = e[hc[nt] & (rdh - 1)];
-                sn[r][nt] = e[rdh + (hc[nt] & (rdh - 1))];
+                const int hd = EPI == EPI_ROPE ? (hc[nt] & (DH - 1)) : hc[nt] % rdh;  // column inside its head (any even head width)
+                cs[r][nt] = e[hd];
+                sn[r][nt] = e[rdh + hd];
               }
             }
           }
@@ -358,8 +359,9 @@ __global__ __launch_bounds__(256) void lg_gemm_small_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float* e = encb + (size_t)min(rows[r], n - 1) * (2 * rdh);
-        cs[r] = e[col & (rdh - 1)];
-        sn[r] = e[rdh + (col & (rdh - 1))];
+        const int hd = EPI == EPI_ROPE ? (col & (DH - 1)) : col % rdh;
+        cs[r] = e[hd];
+        sn[r] = e[rdh + hd];
       }
     }
 #pragma unroll
@@ -404,6 +406,7 @@ struct AttnArgs {
   float scale;
   int kv_shift, Btot;  // keys / values of batch entry b come from entry (b + kv_shift) % Btot (cross attention over the two sides stacked in one buffer)
   int d;               // row width (heads * head dim); read when the kernel's DD is 0
+  int dh;              // head width when the kernel's DD is 0: <= HD, a multiple of 4; dims dh .. HD - 1 are zero padding
 };
 
 constexpr int AKB = 32;   // keys staged per round (32: 124 VGPRs -> three workgroups per CU; 64: 151 -> two)
@@ -431,18 +434,22 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   const bool qv = q < nq;
   // MFMA K-step t pairs head dims (t, t + DH/2): lane half h supplies dim t + (DH/2) h, so a lane's K fragments
   // for four consecutive steps are one 16-byte LDS read
-  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * DL + h * DH + (DH / 2) * half;
+  // Head widths that are not 32 / 64 / 128 (lightglue.py:456-461 takes any descriptor_dim // num_heads) run the next larger
+  // instantiation on zero-padded heads (DD == 0 only): dims dhr .. HD - 1 of Q, K and V read as 0 -- exact zeros add nothing
+  // to a dot product -- and are not stored.  The head's columns start at h * dhr.
+  const int dhr = DD ? DH : a.dh;
+  const float* Qrow = a.Q + ((size_t)b * a.capq + (qv ? q : nq - 1)) * DL + h * dhr + (DH / 2) * half;
   float qreg[DH / 2];
 #pragma unroll
   for (int t = 0; t < DH / 2; t += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(Qrow + t);
+    const f32x4 v = (DD || (DH / 2) * half + t < dhr) ? *reinterpret_cast<const f32x4*>(Qrow + t) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     qreg[t] = v[0];
     qreg[t + 1] = v[1];
     qreg[t + 2] = v[2];
     qreg[t + 3] = v[3];
   }
-  const float* Kb = a.K + (size_t)bk * a.capk * DL + h * DH;
-  const float* Vb = a.V + (size_t)bk * a.capk * DL + h * DH;
+  const float* Kb = a.K + (size_t)bk * a.capk * DL + h * dhr;
+  const float* Vb = a.V + (size_t)bk * a.capk * DL + h * dhr;
   constexpr int OT = DH / 32;  // 32-wide blocks of the output row
   f32x16 o[OT];
 #pragma unroll
@@ -464,8 +471,12 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
       const int fidx = tid + i * 256;
       const int row = fidx / R4, c4 = fidx % R4;
       const int key = min(kb0 + row, nk - 1);  // clamped: rows past nk are masked after the QK product
-      rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * DL + c4 * 4);
-      rv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * DL + c4 * 4);
+      if (DD || c4 * 4 < dhr) {
+        rk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)key * DL + c4 * 4);
+        rv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key * DL + c4 * 4);
+      } else {
+        rk[i] = rv[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
     }
   };
   auto commit = [&]() {
@@ -556,11 +567,12 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
   }
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   if (qv) {
-    float* orow = a.O + ((size_t)b * a.capq + q) * D + h * DH;
+    float* orow = a.O + ((size_t)b * a.capq + q) * D + h * dhr;
 #pragma unroll
     for (int mt = 0; mt < OT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) orow[mt * 32 + crow(r, half)] = o[mt][r] / l;
+      for (int r = 0; r < 16; ++r)
+        if (DD || mt * 32 + crow(r, half) < dhr) orow[mt * 32 + crow(r, half)] = o[mt][r] / l;
   }
 }
 
@@ -1073,6 +1085,7 @@ int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* n
   a.capq = capq;
   a.capk = capk;
   a.d = dm.d;
+  a.dh = dm.dh;
   a.scale = 1.0f / sqrtf((float)dm.dh);  // SDPA scale (self) = (dh^-1/4)^2 (cross, lightglue.py:316); 64-wide heads: exactly 0.125
   const dim3 grid((unsigned)einx_cdiv(capq, 128), (unsigned)dm.heads, (unsigned)B);
   EINX_PROF("lg_attn_kernel", st);
@@ -1088,9 +1101,9 @@ int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* n
   if (merged && !dm.shipped()) return -1;
   if (merged) hipLaunchKernelGGL((lg_attn_kernel<64, D, 2 * D>), grid, dim3(256), 0, st, a);
   else if (dm.shipped()) hipLaunchKernelGGL((lg_attn_kernel<64, D>), grid, dim3(256), 0, st, a);
-  else if (dm.dh == 64) hipLaunchKernelGGL((lg_attn_kernel<64, 0>), grid, dim3(256), 0, st, a);
-  else if (dm.dh == 32) hipLaunchKernelGGL((lg_attn_kernel<32, 0>), grid, dim3(256), 0, st, a);
-  else if (dm.dh == 128) hipLaunchKernelGGL((lg_attn_kernel<128, 0>), grid, dim3(256), 0, st, a);
+  else if (dm.dh <= 32) hipLaunchKernelGGL((lg_attn_kernel<32, 0>), grid, dim3(256), 0, st, a);  // (narrower heads: zero padded)
+  else if (dm.dh <= 64) hipLaunchKernelGGL((lg_attn_kernel<64, 0>), grid, dim3(256), 0, st, a);
+  else if (dm.dh <= 128) hipLaunchKernelGGL((lg_attn_kernel<128, 0>), grid, dim3(256), 0, st, a);
   else return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1150,13 +1163,15 @@ EINX_EXPORT int einx_normalize_keypoints(const float* kpts, int rows, int cols, 
 }
 
 namespace {
-// lightglue.py:456-461: head_dim = descriptor_dim // num_heads.  The attention kernel is instantiated for 32-, 64- and 128-wide heads.
+// lightglue.py:456-461: head_dim = descriptor_dim // num_heads.  The attention kernel is instantiated for 32-, 64- and 128-wide
+// heads; other widths run the next larger one on zero-padded heads (round 6).  Multiples of 4 (16-byte rows of a head; the
+// rotary encoding needs an even width anyway) up to 128.
 bool dims_of(int d, int heads, Dims& dm) {
   if (d <= 0 || heads <= 0 || d % heads != 0) return false;
   dm.d = d;
   dm.heads = heads;
   dm.dh = d / heads;
-  return dm.dh == 32 || dm.dh == 64 || dm.dh == 128;
+  return dm.dh % 4 == 0 && dm.dh <= 128;
 }
 }  // namespace
 
@@ -1177,7 +1192,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
                                float* ref0, float* ref1, int ref_layers, void* stream) {
   EINX_CHECK_ARG(w && kpts0 && desc0 && n && kpts1 && desc1 && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
   Dims dm;
-  EINX_CHECK_ARG(dims_of(w->d, w->heads, dm), "descriptor_dim must be num_heads x head_dim with head_dim 32, 64 or 128");
+  EINX_CHECK_ARG(dims_of(w->d, w->heads, dm), "descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 128");
   const int D = dm.d;  // (shadows the file-level constant: every width below is the model's)
   EINX_CHECK_ARG(w->n_layers >= 1 && w->layers, "no layers");
   EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0, "bad shape");

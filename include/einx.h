@@ -107,6 +107,14 @@ const char* einx_conv_last_kernel(void);
 /* x /= divisor in place (SuperPointv1.forward `image /= 255.0`, superpoint_extractor.py:372) */
 int einx_div_inplace(float* x, size_t n, float divisor, void* stream);
 
+/* SuperPointv1.forward's input handling for RGB and / or non-contiguous images (superpoint_extractor.py:372-376):
+ *   image /= divisor in place on the caller's [B,C,H,W] tensor THROUGH ITS ELEMENT STRIDES (the caller sees the scaled tensor
+ *   afterwards, as with the reference), and the network's contiguous [B,1,H,W] input written to `gray`:
+ *   C == 1: the scaled value; C == 3: kornia.color.rgb_to_grayscale (kornia 0.7.1) = (0.299 r + 0.587 g) + 0.114 b in fp32,
+ *   every product and sum rounded separately.  Overlapping strides (expanded tensors) are the caller's problem, as in torch. */
+int einx_image_prepare(float* image, int B, int C, int H, int W, long long stride_b, long long stride_c, long long stride_h,
+                       long long stride_w, float divisor, float* gray, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Detector head post-processing  (K3, K4, K5)
  * ---------------------------------------------------------------------------------------- */
@@ -264,7 +272,8 @@ typedef struct einx_lg_weights {
  * LightGlue call returns matched keypoints in these coordinates (lightglue.py:677-687). */
 int einx_normalize_keypoints(const float* kpts, int rows, int cols, float h, float w, float* out, int out_cols, void* stream);
 
-/* Model widths (lightglue.py:456-461): d = descriptor_dim = heads x head_dim with head_dim 32, 64 or 128 (anything else is refused);
+/* Model widths (lightglue.py:456-461): d = descriptor_dim = heads x head_dim, head_dim any multiple of 4 up to 128 (the attention
+ * kernel is instantiated for 32 / 64 / 128; other widths run the next larger one on zero-padded heads; anything else is refused);
  * Wr is [head_dim/2, 2].  d = 256 with 4 heads of 64 -- every EI-Nexus configuration -- runs kernels instantiated for those widths.
  * einx_lg_ws_bytes assumes 64-wide heads (heads = d / 64); 0 = unsupported widths. */
 size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);

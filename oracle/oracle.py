@@ -315,7 +315,13 @@ def extractor_forward(kind, sd, x, mask, *, top_k, radius=4, border=4, det_thr=1
     if kind == "silk":
         mask = None  # SiLKModel.forward(self, image, *args, **kwargs) never looks at the mask it is handed (silk_extractor.py:177)
     if kind == "superpointv1":
-        np.divide(x, np.float32(255.0), out=x)
+        np.divide(x, np.float32(255.0), out=x)  # in place, through the array's strides (superpoint_extractor.py:372)
+        if x.shape[1] == 3:
+            # rgb_to_grayscale (:375-376; kornia 0.7.1, kornia/color/gray.py: `w_r * r + w_g * g + w_b * b` with the fp32
+            # weights (0.299, 0.587, 0.114)): three fp32 products, summed left to right, every operation rounded to fp32
+            r, g, b_ = x[:, 0:1], x[:, 1:2], x[:, 2:3]
+            x = (np.float32(0.299) * r + np.float32(0.587) * g) + np.float32(0.114) * b_
+        x = np.ascontiguousarray(x)
     elif kind == "silk":
         x = x / np.float32(255.0)
     pads = padder_pads(H, W, cell)

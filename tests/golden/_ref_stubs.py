@@ -3,7 +3,9 @@ this container.  TEST INFRASTRUCTURE ONLY: used by ``gen_golden.py`` to capture
 golden vectors.  Nothing here travels into the product path, and nothing here
 performs arithmetic on the hot path except ``torchvision...resize`` which is
 expressed as the exact ``F.interpolate`` call torchvision 0.17 makes for
-float tensors (only used for the dense ``normalized_descriptors`` output).
+float tensors (only used for the dense ``normalized_descriptors`` output) and
+``kornia.color.rgb_to_grayscale`` (round 6), restated from kornia 0.7.1 -- the
+reference's pinned version -- for float inputs (only reached by 3-channel images).
 
 Packages the reference imports at module import time but which are absent
 here (requirements.txt of the reference): omegaconf, hydra, kornia, cv2,
@@ -81,7 +83,16 @@ def install():
     _mod("omegaconf", OmegaConf=_OmegaConf, DictConfig=AttrDict, ListConfig=list, _einx_stub=True)
     _mod("cv2")
     k = _mod("kornia")
-    kc = _mod("kornia.color", rgb_to_grayscale=lambda x: x)
+    def rgb_to_grayscale(image, rgb_weights=None):
+        # kornia 0.7.1 (the reference's pin, requirements.txt:56), kornia/color/gray.py, float inputs: weights
+        # tensor([0.299, 0.587, 0.114]) of the image's dtype, `w_r * r + w_g * g + w_b * b` on the [..., 3, H, W] tensor
+        if image.shape[-3] != 3:
+            raise ValueError(f"Input size must have a shape of (*, 3, H, W). Got {image.shape}")
+        w_r, w_g, w_b = torch.tensor([0.299, 0.587, 0.114], device=image.device, dtype=image.dtype).unbind()
+        r, g, b = image[..., 0:1, :, :], image[..., 1:2, :, :], image[..., 2:3, :, :]
+        return w_r * r + w_g * g + w_b * b
+
+    kc = _mod("kornia.color", rgb_to_grayscale=rgb_to_grayscale)
     k.color = kc
     sk = _mod("skimage")
     sk.io = _mod("skimage.io")

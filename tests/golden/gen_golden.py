@@ -6,7 +6,7 @@ outputs as small .npz fixtures next to this file.
 
 Run ONLY in the build container (the reference does not exist on the GPU box):
 
-    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii lgcal mnnstab cfgsweep lgcfg
+    python tests/golden/gen_golden.py [group ...]     # groups: train metrics events post desc mnn conv lg e2e r2 ii lgcal mnnstab rgb cfgsweep lgcfg
 
 The fixtures are data (recipes, shapes, expected outputs); no reference source
 text is stored.  torch version and seeds are recorded in each file's `meta`.
@@ -1249,6 +1249,61 @@ GROUPS["mnnstab"] = gen_mnnstab
 
 
 # =========================================================================================
+# rgb: what SuperPointv1 accepts beside contiguous grayscale (superpoint_extractor.py:372-376): 3-channel images (scaled in
+# place, then kornia's rgb_to_grayscale -- restated from kornia 0.7.1 in _ref_stubs.py, the package is absent here) and
+# non-contiguous tensors (`image /= 255.0` works through the strides).  Stored: the extractor's outputs and the caller's
+# tensor as the call leaves it.
+# =========================================================================================
+RGB_CASES = [
+    dict(name="rgb_small", layout="rgb", H=37, W=45, B=2, k=20, wseed=71, iseed=81, mask=False),
+    dict(name="rgb_channels_last", layout="rgb_cl", H=40, W=48, B=1, k=20, wseed=72, iseed=82, mask=False),
+    dict(name="gray_strided", layout="gray_view", H=37, W=45, B=2, k=20, wseed=73, iseed=83, mask=False),
+    dict(name="rgb_full_mask", layout="rgb", H=260, W=346, B=1, k=1024, wseed=74, iseed=84, mask=True),
+]
+
+
+def rgb_input(c):
+    """numpy array with the case's memory layout (helpers.rgb_input rebuilds the same)"""
+    B, H, W = c["B"], c["H"], c["W"]
+    if c["layout"] == "gray_view":
+        big = np.zeros((B, 1, H + 3, W + 5), np.float32)
+        big[:, :, 1:H + 1, 2:W + 2] = synth.synth_image(c["iseed"], B, H, W)
+        return big[:, :, 1:H + 1, 2:W + 2]  # a view: rows W + 5 apart
+    chans = [synth.synth_image(c["iseed"] + 10 * ch, B, H, W)[:, 0] for ch in range(3)]
+    if c["layout"] == "rgb_cl":
+        return np.ascontiguousarray(np.stack(chans, -1)).transpose(0, 3, 1, 2)  # [B,H,W,3] memory seen as [B,3,H,W]
+    return np.ascontiguousarray(np.stack(chans, 1))
+
+
+def gen_rgb():
+    out, cases = {}, []
+    for c in RGB_CASES:
+        cfg = model_cfg("vgg", "superpointv1", "MNN", 5, c["k"])
+        model, keys = build_eim(cfg, c["wseed"])
+        x = rgb_input(c)
+        t = torch.from_numpy(x)  # shares memory and strides with x
+        assert t.stride() == tuple(s_ // 4 for s_ in x.strides)
+        mask = None
+        if c["mask"]:
+            _, mk = synth.synth_events(c["iseed"], c["B"], 5, c["H"], c["W"])
+            mask = torch.from_numpy(mk)
+        with torch.no_grad():
+            imf = model.image_extractor(t, mask)
+        feats_summary(f"{c['name']}.im", imf, out, full=c["H"] < 100)
+        after = t.numpy()
+        out[f"{c['name']}.after"] = np.ascontiguousarray(after) if after.size < 70000 else np.ascontiguousarray(after).reshape(-1)[::7]
+        c = dict(c)
+        c["cfg"], c["state_keys"] = cfg, keys
+        cases.append(c)
+        print(c["name"], out[f"{c['name']}.im.counts"], "input after the call: max", float(after.max()))
+    out["meta"] = meta(cases=cases, kornia="0.7.1 rgb_to_grayscale restated in _ref_stubs.py (package absent)")
+    save("rgb.npz", **out)
+
+
+GROUPS["rgb"] = gen_rgb
+
+
+# =========================================================================================
 # cfgsweep: every model YAML the reference ships (configs/model/**), built by the reference's own classes on the CPU:
 # which class the scripts use for it (EIM when it has an event_extractor section, else ImageImageMatcher), the module tree
 # as state_dict names -> shapes, and the attributes the evaluation scripts read.  The YAML text is not stored; the test
@@ -1291,6 +1346,11 @@ LGCFG_CASES = [
     dict(name="h3_d192", seed=164, n=260, m=131, input_dim=128, descriptor_dim=192, num_heads=3, n_layers=3, wseed=18, shared=60),
     dict(name="h4_d512", seed=165, n=140, m=150, input_dim=256, descriptor_dim=512, num_heads=4, n_layers=2, wseed=19, shared=60),
     dict(name="h1_d64", seed=166, n=90, m=300, input_dim=64, descriptor_dim=64, num_heads=1, n_layers=3, wseed=20, shared=40),
+    # round 6: head widths that are not 32 / 64 / 128 (lightglue.py:456-461 takes any descriptor_dim // num_heads)
+    dict(name="h2_d96", seed=167, n=180, m=150, input_dim=96, descriptor_dim=96, num_heads=2, n_layers=3, wseed=21, shared=70),      # 2 x 48
+    dict(name="h4_d64", seed=168, n=130, m=170, input_dim=128, descriptor_dim=64, num_heads=4, n_layers=3, wseed=22, shared=60),     # 4 x 16
+    dict(name="h3_d240", seed=169, n=150, m=200, input_dim=240, descriptor_dim=240, num_heads=3, n_layers=2, wseed=23, shared=70),   # 3 x 80, d % 32 != 0
+    dict(name="h2_d200", seed=170, n=140, m=120, input_dim=200, descriptor_dim=200, num_heads=2, n_layers=2, wseed=24, shared=50),   # 2 x 100
 ]
 
 

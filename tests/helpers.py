@@ -196,6 +196,19 @@ def train_inputs(c):
     return p0, d0, p1, d1
 
 
+def rgb_input(c):
+    """Same recipe as tests/golden/gen_golden.py::rgb_input: the case's image with its MEMORY LAYOUT (a numpy view)."""
+    B, H, W = c["B"], c["H"], c["W"]
+    if c["layout"] == "gray_view":
+        big = np.zeros((B, 1, H + 3, W + 5), np.float32)
+        big[:, :, 1:H + 1, 2:W + 2] = synth.synth_image(c["iseed"], B, H, W)
+        return big[:, :, 1:H + 1, 2:W + 2]
+    chans = [synth.synth_image(c["iseed"] + 10 * ch, B, H, W)[:, 0] for ch in range(3)]
+    if c["layout"] == "rgb_cl":
+        return np.ascontiguousarray(np.stack(chans, -1)).transpose(0, 3, 1, 2)
+    return np.ascontiguousarray(np.stack(chans, 1))
+
+
 def split(flat, counts):
     out, o = [], 0
     for c in counts:

@@ -365,6 +365,29 @@ def test_e2e_full_size(oracle, name):
                                    atol=(la_bound_e2e(f"e2e.{name}", up) if c["matcher"] == "LightGlue" else 2e-5), rtol=0)
 
 
+# ------------------------------------------------------------------ RGB / non-contiguous images through SuperPointv1 (round 6)
+RGB = Golden("rgb")
+
+
+@pytest.mark.parametrize("name", list(RGB.cases))
+def test_superpoint_rgb_and_strided_inputs(oracle, name):
+    """superpoint_extractor.py:372-376: `image /= 255.0` on the caller's tensor through its strides, then kornia's
+    rgb_to_grayscale for 3-channel images; fixtures from the reference (tests/golden/gen_golden.py::gen_rgb)."""
+    from helpers import rgb_input
+    c = RGB.cases[name]
+    sd = state_dict_for(c, RGB)
+    x = rgb_input(c)
+    mask = synth.synth_events(c["iseed"], c["B"], 5, c["H"], c["W"])[1] if c["mask"] else None
+    icfg = c["cfg"]["image_extractor"]["superpointv1"]
+    imf = oracle.extractor_forward("superpointv1", sub_dict(sd, "image_extractor.extractor."), x, mask, top_k=icfg["detection_top_k"],
+                                   radius=icfg["nms_radius"], border=icfg["remove_borders"], det_thr=icfg["detection_threshold"],
+                                   scale=icfg["descriptor_scale_factor"])
+    _check_feats(f"{name}.im", imf, RGB)
+    after = np.ascontiguousarray(x)  # the caller's array as the call leaves it: scaled in place, still RGB / strided
+    exp = RGB[f"{name}.after"]
+    assert np.array_equal(after if exp.ndim == 4 else after.reshape(-1)[::7], exp)
+
+
 # ------------------------------------------------------------------ LightGlue end to end, non-degenerate regime (round 4)
 LGCAL = Golden("lgcal")
 
