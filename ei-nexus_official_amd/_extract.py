@@ -319,7 +319,7 @@ class ExtractorEngine:
         arr = lambda layers: (_lib.ConvDesc * len(layers))(*[l.desc for l in layers])  # noqa: E731
         bb, det, desc = arr(self.backbone), arr(self.det_head), arr(self.desc_head)
         mh = getattr(self, "merged_head0", None)
-        d = _lib.ExtractorDesc(self.cell, len(self.backbone), len(self.det_head), len(self.desc_head), bb, det, desc, int(bool(dilate_mask)),
+        d = _lib.ExtractorDesc(ctypes.sizeof(_lib.ExtractorDesc), self.cell, len(self.backbone), len(self.det_head), len(self.desc_head), bb, det, desc, int(bool(dilate_mask)),
                                int(self.border), int(self.radius), int(self.top_k or 0), float(self.det_thr), int(self.ordering == "xy"),
                                float(scale), float(input_div), ctypes.pointer(mh.desc) if mh is not None else None)
         h = L.einx_extractor_create(ctypes.byref(d))
@@ -366,9 +366,13 @@ class ExtractorEngine:
         out = _lib.ExtractOut(P(bf.feats), P(bf.logits), P(bf.raw), P(bf.prob), P(bf.score), P(bf.coarse), P(bf.raw_cl), P(det.nms),
                               P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap)
         wt = getattr(self, "watch", None)
-        if wt is not None and wt.n:  # `.data` edits of the weights: compared inside the call, bit 1 of not_converged[0]
-            out.watch_n, out.watch_table, out.watch_ref, out.watch_scratch = wt.n, P(wt.table), P(wt.ref), P(wt.scratch)
-        _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), nws, ctypes.byref(out), N._stream(x)), "einx_extract")
+        if wt is not None and wt.n:  # `.data` edits of the weights: compared inside the call, reported through the watch's own `stale` word
+            ww = _lib.WeightWatch(ctypes.sizeof(_lib.WeightWatch), wt.n, P(wt.table), P(wt.ref), P(wt.scratch), P(wt.stale))
+            _lib.check(L.einx_extract_watch(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), nws, ctypes.byref(out), ctypes.byref(ww), N._stream(x)),
+                       "einx_extract_watch")
+            det.stale = wt.stale
+        else:
+            _lib.check(L.einx_extract(h, P(x), P(m8), B, H, W, int(nms_iters), P(ws), nws, ctypes.byref(out), N._stream(x)), "einx_extract")
         if dense and not defer_dense:
             bf.run_dense()
         return bf
@@ -479,8 +483,8 @@ class ExtractorEngine:
         bf.feats, bf.logits, bf.raw, bf.prob, bf.score = feats, logits, raw, prob, score
         self.redetect(bf, nms_iters)
         wt = getattr(self, "watch", None)
-        if wt is not None and wt.n:  # op-level path (rare configurations): the weight watch as its own launch, same bit
-            bf.det.not_converged[:1].bitwise_or_(wt.check() * 2)
+        if wt is not None and wt.n:  # op-level path (rare configurations): the weight watch as its own launch, same word
+            bf.det.stale = wt.check()
         if dense and not defer_dense:
             bf.run_dense()
         return bf

@@ -26,7 +26,7 @@ class DetectParams(ctypes.Structure):
 
 
 class ExtractorDesc(ctypes.Structure):
-    _fields_ = [("cell", ctypes.c_int32), ("n_backbone", ctypes.c_int32), ("n_det", ctypes.c_int32), ("n_desc", ctypes.c_int32),
+    _fields_ = [("struct_size", c_size_t), ("cell", ctypes.c_int32), ("n_backbone", ctypes.c_int32), ("n_det", ctypes.c_int32), ("n_desc", ctypes.c_int32),
                 ("backbone", ctypes.POINTER(ConvDesc)), ("det_head", ctypes.POINTER(ConvDesc)), ("desc_head", ctypes.POINTER(ConvDesc)),
                 ("dilate_mask", ctypes.c_int32), ("border", ctypes.c_int32), ("nms_radius", ctypes.c_int32), ("top_k", ctypes.c_int32),
                 ("det_thr", c_float), ("ordering_xy", ctypes.c_int32), ("desc_scale", c_float), ("input_div", c_float),
@@ -40,8 +40,11 @@ class ExtractShapes(ctypes.Structure):
 class ExtractOut(ctypes.Structure):
     _names = ("feats", "logits", "raw", "prob", "score", "coarse", "raw_cl", "nms", "positions", "indices", "counts", "thr", "not_converged",
               "sparse_desc")
-    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32), ("watch_n", ctypes.c_int32), ("watch_table", c_void_p),
-                                                   ("watch_ref", c_void_p), ("watch_scratch", c_void_p)]
+    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32)]
+
+
+class WeightWatch(ctypes.Structure):
+    _fields_ = [("struct_size", c_size_t), ("n", ctypes.c_int32), ("table", c_void_p), ("ref", c_void_p), ("scratch", c_void_p), ("stale", c_void_p)]
 
 
 class MetricParams(ctypes.Structure):
@@ -56,7 +59,7 @@ class LgLayer(ctypes.Structure):
 
 
 class LgWeights(ctypes.Structure):
-    _fields_ = [("in_w", c_void_p), ("in_b", c_void_p), ("Wr", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
+    _fields_ = [("struct_size", c_size_t), ("layer_size", c_size_t), ("in_w", c_void_p), ("in_b", c_void_p), ("Wr", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
                 ("match_w", c_void_p), ("match_b", c_void_p), ("n_layers", ctypes.c_int32), ("heads", ctypes.c_int32),
                 ("d", ctypes.c_int32), ("input_dim", ctypes.c_int32), ("filter_threshold", c_float),
                 ("layers", ctypes.POINTER(LgLayer))]
@@ -65,6 +68,7 @@ class LgWeights(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/einx.h declares
 SIGNATURES = {
     "einx_version": (c_char_p, []),
+    "einx_abi_version": (c_int, []),
     "einx_build_flags": (c_char_p, []),
     "einx_params_hash": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "einx_last_error": (c_char_p, []),
@@ -74,9 +78,13 @@ SIGNATURES = {
     "einx_extractor_create": (c_void_p, [ctypes.POINTER(ExtractorDesc)]),
     "einx_extractor_destroy": (None, [c_void_p]),
     "einx_fork_stream_prepare": (c_int, [c_void_p]),
+    "einx_fork_stream_release": (c_int, [c_void_p]),
+    "einx_fork_stream_count": (c_int, []),
     "einx_extract_shapes": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(ExtractShapes)]),
     "einx_extract_ws_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "einx_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, ctypes.POINTER(ExtractOut), c_void_p]),
+    "einx_extract_watch": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, ctypes.POINTER(ExtractOut),
+                           ctypes.POINTER(WeightWatch), c_void_p]),
     "einx_conv_last_kernel": (c_char_p, []),
     "einx_conv_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -186,10 +186,11 @@ def image_prepare(image, divisor):
     """SuperPointv1's input handling for RGB / non-contiguous images (superpoint_extractor.py:372-376): `image /= divisor` in
     place THROUGH the tensor's strides, and the network's contiguous single-channel input (C == 3: kornia's rgb_to_grayscale of
     the scaled image) as a new tensor.  divisor 1.0 = the image has been scaled by an earlier call (x / 1 == x)."""
-    _dev_check(image)
+    if image.device.type != "cuda":
+        raise RuntimeError(f"einx: input must be on a HIP device (no CPU path), got {image.device}")
     if image.dtype != F32:
         raise TypeError("einx extractors compute in fp32; pass a float32 tensor")
-    B, C, H, W = image.shape
+    B, C, H, W = image.shape  # any strides: the kernel walks them
     gray = torch.empty((B, 1, H, W), dtype=F32, device=image.device)
     if gray.numel():
         sb, sc, sh, sw = image.stride()
@@ -240,7 +241,7 @@ def remove_border(score, border):
 
 class Detection:
     """Device-side result of einx_detect for a batch."""
-    __slots__ = ("positions", "indices", "counts", "thr", "not_converged", "nms", "cap", "padded", "pads")
+    __slots__ = ("positions", "indices", "counts", "thr", "not_converged", "nms", "cap", "padded", "pads", "stale")
 
 
 def detect(score, *, top_k, radius, det_thr, pads=(0, 0, 0, 0), ordering="yx", cap=None, nms_iters=8, want_nms=True):

@@ -114,10 +114,16 @@ class EIM(nn.Module):
         B = events.shape[0]
         p = {"B": B, "slot": slot}
 
+        def det_parts(ev, im):
+            # four rows of B words (counts and NMS "needs more passes" flags of both sides), then the extractors' weight-watch
+            # words (one each, when a watch rode on the call)
+            return [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged] + \
+                   [t for t in (getattr(ev.det, "stale", None), getattr(im.det, "stale", None)) if t is not None]
+
         def read_detection(ev, im):
-            # not_converged: bit 0 = the NMS fix-point needs more passes, bit 1 (element 0) = the extractor's weight watch
-            rows = torch.stack([ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged])
-            p["det_host"] = self._pinned(f"det{slot}", (4, B)).copy_(rows, non_blocking=True)
+            rows = torch.cat(det_parts(ev, im))
+            host = self._pinned(f"det{slot}", (int(rows.shape[0]),)).copy_(rows, non_blocking=True)
+            p["det_host"], p["stale_host"] = host[:4 * B].view(4, B), host[4 * B:]
             p["det_event"] = torch.cuda.Event()
             p["det_event"].record()
 
@@ -130,14 +136,15 @@ class EIM(nn.Module):
         p["args"] = (events, image, events_mask, image_mask)
         p["nm_event"] = None
         if one_readback:
-            parts = [ev.det.counts, im.det.counts, ev.det.not_converged, im.det.not_converged]
+            parts = det_parts(ev, im)
+            n_det = 4 * B + len(parts) - 4
             if mr is not None:
                 parts += [mr.nmatch] + ([] if getattr(mr, "stale", None) is None else [mr.stale])
             rows = torch.cat(parts)
             host = self._pinned(f"all{slot}", (int(rows.shape[0]),)).copy_(rows, non_blocking=True)
-            p["det_host"], p["det_event"] = host[:4 * B].view(4, B), torch.cuda.Event()
+            p["det_host"], p["stale_host"], p["det_event"] = host[:4 * B].view(4, B), host[4 * B:n_det], torch.cuda.Event()
             if mr is not None:
-                p["nm_host"] = host[4 * B:]
+                p["nm_host"] = host[n_det:]
             p["det_event"].record()
         elif mr is not None:
             nm = mr.nmatch if getattr(mr, "stale", None) is None else torch.cat([mr.nmatch, mr.stale])  # + the matcher's weight watch
@@ -161,7 +168,8 @@ class EIM(nn.Module):
         B = len(host[0])
         nm_host, nm_event = p.get("nm_host"), p["nm_event"]
         flags_ev, flags_im = _or_all(host[2]), _or_all(host[3])
-        stale = bool((flags_ev | flags_im) & 2)
+        sh = p.get("stale_host")
+        stale = bool(sh is not None and sh.numel() and any(sh.tolist()))  # an extractor's weight watch (its own word, not a bit of the NMS flags)
         if not stale and mr is not None and getattr(mr, "stale", None) is not None:
             if nm_event is not None:
                 nm_event.synchronize()
@@ -181,14 +189,14 @@ class EIM(nn.Module):
             self.reset_graphs()
             return self._finish(self._enqueue(*p["args"], slot=p["slot"], prepared=True), _rerun=True)
         retries = 0
-        while (flags_ev | flags_im) & 1:
+        while flags_ev | flags_im:
             retries += 1
             if retries > 8:  # 8 * 4**8 passes: cannot happen on a finite map (each pass removes at least one pixel or stops)
                 raise RuntimeError("einx: the NMS fix-point did not converge within the maximum pass budget")
             # the NMS fix-point of some image needed more passes than were enqueued: redo only the
             # detection tail (and the matcher) with a larger, remembered, pass budget (rare: blocking read-back)
             for flags, bf, wrapper in ((flags_ev, ev, self.event_extractor), (flags_im, im, self.image_extractor)):
-                if flags & 1:
+                if flags:
                     eng = wrapper.extractor.engine()
                     eng.redetect(bf, eng.grow_nms_iters())
             if mr is not None:
@@ -272,7 +280,7 @@ class EIM(nn.Module):
         cur.synchronize()
         p = g["p"]
         rows = p["det_host"].tolist()
-        if (_or_all(rows[2]) | _or_all(rows[3])) & 1:
+        if _or_all(rows[2]) | _or_all(rows[3]):
             # rare: the captured NMS pass budget was exceeded.  `_finish` redoes the detection tail and the matcher eagerly with
             # a larger, remembered budget on the graph's buffers (the replay has already scaled its own copy of the image);
             # this graph keeps the old budget, so it is dropped and the next call captures afresh

@@ -174,7 +174,7 @@ class NativeExtractor(nn.Module):
         if self._scale_host is None:  # one device read per engine build, not one host sync per forward
             self._scale_host = float(self.descriptor_scale_factor.detach())
         scale = self._scale_host
-        # (the engine's weight watch runs inside the call and reports through bit 1 of det.not_converged[0])
+        # (the engine's weight watch rides on the call and reports through its own device word, bf.det.stale)
         return eng.run(x, score_mask, scale=scale, dilate_mask=self.dilate_mask, dense=self.dense_outputs if dense is None else dense,
                        nms_iters=nms_iters, input_div=input_div, defer_dense=defer_dense)
 
@@ -182,14 +182,17 @@ class NativeExtractor(nn.Module):
     def forward(self, x, score_mask=None, **kwargs):
         bf = self.extract_batched(x, score_mask)
         for _ in range(12):
-            host = torch.stack([bf.det.counts, bf.det.not_converged]).cpu()
-            if bool((host[1] & 2).any()):
+            st = getattr(bf.det, "stale", None)
+            flat = torch.cat([bf.det.counts, bf.det.not_converged] + ([] if st is None else [st])).cpu()
+            B = bf.det.counts.shape[0]
+            host = flat[:2 * B].view(2, B)
+            if bool(flat[2 * B:].any()):
                 # a weight was edited through `.data` since the native images were built: rebuild them and run again (an input
                 # that was scaled in place -- SuperPointv1's `/= 255` -- is not scaled twice)
                 self.refresh()
                 bf = self.extract_batched(x, score_mask, prepared=True)
                 continue
-            if not bool((host[1] & 1).any()):
+            if not bool(host[1].any()):
                 self.engine().note_converged()
                 return bf.materialize(host[0].tolist())
             self.engine().redetect(bf, self.engine().grow_nms_iters())  # NMS fix-point needs more passes

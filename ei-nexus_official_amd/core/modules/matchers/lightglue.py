@@ -196,6 +196,7 @@ class LightGlue(nn.Module):
             L.cln_g, L.cln_b = p(x.ffn[1].weight), p(x.ffn[1].bias)
             L.cf3_w, L.cf3_b = p(x.ffn[3].weight), p(x.ffn[3].bias)
         w = _lib.LgWeights()
+        w.struct_size, w.layer_size = ctypes.sizeof(_lib.LgWeights), ctypes.sizeof(_lib.LgLayer)
         if isinstance(self.input_proj, nn.Linear):
             w.in_w, w.in_b = p(self.input_proj.weight), p(self.input_proj.bias)
         else:

@@ -19,7 +19,8 @@ void einx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-EINX_EXPORT const char* einx_version(void) { return "einx-hip 0.1 (gfx950)"; }
+EINX_EXPORT const char* einx_version(void) { return "einx-hip 0.6 (gfx950, ABI 6)"; }
+EINX_EXPORT int einx_abi_version(void) { return EINX_ABI_VERSION; }
 EINX_EXPORT const char* einx_last_error(void) { return g_err; }
 EINX_EXPORT const char* einx_build_flags(void) {
 #ifdef EINX_TIMING_ONLY_BUILD

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -27,13 +28,30 @@
 // process (round 5; rounds 3-4 kept one per handle): HIP maps streams onto its few hardware queues in creation order, so the
 // streams of the fifth or sixth handle of a process landed on the queue of a caller's stream and the fork serialised -- bench.py's
 // single-pair leg ran 1.06 instead of 0.77 ms per forward once two more streams had been created before its model
-// (tools/experiments/r5_eager_after_run2.py).  Created on first use, never destroyed (a process forks from a handful of streams).
+// (tools/experiments/r5_eager_after_run2.py).  Created on first use.  Round 6: BOUNDED -- at most EINX_FORK_STREAMS_MAX sides
+// exist; a call on a further stream evicts the least recently used side that no call holds (shared_ptr: a side in use outlives
+// its map entry and is destroyed by its last user), and einx_fork_stream_release drops one explicitly.  hipStreamDestroy /
+// hipEventDestroy on objects with enqueued work are deferred by the runtime until that work has drained.
 // `mu` is held while a call enqueues its fork .. join section, so two host threads that enqueue on one stream cannot interleave
 // on the events; re-recording an event does not disturb waits that were enqueued on its earlier record.
 struct EinxSide {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  int dev = 0;
+  unsigned long long last_use = 0;
   std::mutex mu;
+  EinxSide() = default;
+  EinxSide(const EinxSide&) = delete;
+  EinxSide& operator=(const EinxSide&) = delete;
+  ~EinxSide() {
+    int cur = 0;
+    const bool sw = (stream || fork || join) && hipGetDevice(&cur) == hipSuccess && cur != dev;
+    if (sw) (void)hipSetDevice(dev);
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (sw) (void)hipSetDevice(cur);
+  }
 };
 
 struct einx_extractor {
@@ -66,37 +84,55 @@ struct Plan {
 constexpr long kForkMaxCells = 8192;  // B x head pixels up to which the two head branches of a full-resolution network run concurrently
 bool fork_heads(const einx_extractor* e, const Plan& pl, int B) { return e->d.cell == 8 || (long)B * pl.hc * pl.wc <= kForkMaxCells; }
 
-// the side of `caller` (keyed on the stream's OWN device, not on the current one)
-EinxSide* side_for(const einx_extractor* e, hipStream_t caller) {
+// the sides of the process: (device, caller stream) -> side, with a use stamp for the LRU bound
+typedef std::map<std::pair<int, hipStream_t>, std::shared_ptr<EinxSide>> SideMap;
+std::mutex g_sides_mu;
+unsigned long long g_side_clock = 0;
+SideMap& side_map() {
+  static SideMap* m = new SideMap();  // (never destructed: no HIP calls at process exit)
+  return *m;
+}
+
+// the side of `caller` (keyed on the stream's OWN device, not on the current one); the returned reference keeps it alive
+std::shared_ptr<EinxSide> side_for(hipStream_t caller) {
   int dev = 0;
   if (caller) {
     if (hipStreamGetDevice(caller, &dev) != hipSuccess) return nullptr;
   } else if (hipGetDevice(&dev) != hipSuccess) {
     return nullptr;
   }
-  (void)e;
-  static std::mutex sides_mu;
-  static std::map<std::pair<int, hipStream_t>, EinxSide>* sides = new std::map<std::pair<int, hipStream_t>, EinxSide>();  // (leaked: see EinxSide)
-  std::lock_guard<std::mutex> lk(sides_mu);
-  EinxSide& sd = (*sides)[{dev, caller}];
-  if (!sd.stream) {
+  std::lock_guard<std::mutex> lk(g_sides_mu);
+  SideMap& sides = side_map();
+  std::shared_ptr<EinxSide>& slot = sides[{dev, caller}];
+  if (!slot) {
+    std::shared_ptr<EinxSide> sd = std::make_shared<EinxSide>();
+    sd->dev = dev;
     int cur = 0;
     const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
     if (sw) (void)hipSetDevice(dev);
-    const bool ok = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) == hipSuccess &&
-                    hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+    const bool ok = hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) == hipSuccess;
     if (sw) (void)hipSetDevice(cur);
     if (!ok) {
-      if (sd.stream) (void)hipStreamDestroy(sd.stream);
-      if (sd.fork) (void)hipEventDestroy(sd.fork);
-      if (sd.join) (void)hipEventDestroy(sd.join);
-      sd.stream = nullptr;
-      sd.fork = sd.join = nullptr;
-      return nullptr;
+      sides.erase({dev, caller});
+      return nullptr;  // (~EinxSide releases what was created)
     }
+    slot = sd;
+    // bound: evict least recently used sides nobody holds (use_count 1 = only the map)
+    while ((int)sides.size() > EINX_FORK_STREAMS_MAX) {
+      SideMap::iterator victim = sides.end();
+      for (SideMap::iterator it = sides.begin(); it != sides.end(); ++it)
+        if (it->second != sd && it->second.use_count() == 1 && (victim == sides.end() || it->second->last_use < victim->second->last_use)) victim = it;
+      if (victim == sides.end()) break;  // every other side is in use right now: over the bound until they return
+      sides.erase(victim);
+    }
+    std::shared_ptr<EinxSide> out = sd;
+    out->last_use = ++g_side_clock;
+    return out;
   }
-  return &sd;
+  slot->last_use = ++g_side_clock;
+  return slot;
 }
 
 // Padder.__init__ arithmetic (core/modules/utils/util.py:6-15)
@@ -169,6 +205,15 @@ void detect_params(const einx_extractor* e, const Plan& pl, int B, int H, int W,
 }  // namespace
 
 EINX_EXPORT einx_extractor* einx_extractor_create(const einx_extractor_desc* d) {
+  if (!d) {
+    einx_set_error("einx_extractor_create: null descriptor");
+    return nullptr;
+  }
+  if (d->struct_size != sizeof(einx_extractor_desc)) {
+    einx_set_error("einx_extractor_create: einx_extractor_desc::struct_size is %zu, this library's is %zu (header / library ABI mismatch: EINX_ABI_VERSION %d)",
+                   (size_t)d->struct_size, sizeof(einx_extractor_desc), EINX_ABI_VERSION);
+    return nullptr;
+  }
   if (!d || !d->backbone || !d->det_head || !d->desc_head || d->n_backbone <= 0 || d->n_det <= 0 || d->n_desc <= 0) {
     einx_set_error("einx_extractor_create: null / empty layer lists");
     return nullptr;
@@ -215,11 +260,33 @@ EINX_EXPORT einx_extractor* einx_extractor_create(const einx_extractor_desc* d) 
 EINX_EXPORT void einx_extractor_destroy(einx_extractor* e) { delete e; }
 
 EINX_EXPORT int einx_fork_stream_prepare(void* stream) {
-  if (!side_for(nullptr, (hipStream_t)stream)) {
+  if (!side_for((hipStream_t)stream)) {
     einx_set_error("einx_fork_stream_prepare: could not create the side stream / events");
     return EINX_ERR_LAUNCH;
   }
   return EINX_OK;
+}
+
+EINX_EXPORT int einx_fork_stream_release(void* stream) {
+  std::vector<std::shared_ptr<EinxSide>> dropped;  // destroyed after the map lock is released
+  {
+    std::lock_guard<std::mutex> lk(g_sides_mu);
+    SideMap& sides = side_map();
+    for (SideMap::iterator it = sides.begin(); it != sides.end();) {
+      if (it->first.second == (hipStream_t)stream) {
+        dropped.push_back(it->second);
+        it = sides.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  return EINX_OK;
+}
+
+EINX_EXPORT int einx_fork_stream_count(void) {
+  std::lock_guard<std::mutex> lk(g_sides_mu);
+  return (int)side_map().size();
 }
 
 EINX_EXPORT int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* s) {
@@ -257,7 +324,14 @@ EINX_EXPORT size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, 
 
 EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
                              size_t ws_bytes, const einx_extract_out* o, void* stream) {
+  return einx_extract_watch(e, in, mask, B, H, W, nms_iters, ws, ws_bytes, o, nullptr, stream);
+}
+
+EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
+                                   size_t ws_bytes, const einx_extract_out* o, const einx_weight_watch* ww, void* stream) {
   EINX_CHECK_ARG(e && in && ws && o, "null pointer");
+  EINX_CHECK_ARG(!ww || ww->struct_size == sizeof(einx_weight_watch), "einx_weight_watch::struct_size does not match this library (ABI mismatch)");
+  EINX_CHECK_ARG(!ww || ww->n == 0 || (ww->n > 0 && ww->table && ww->ref && ww->scratch && ww->stale), "weight watch with null pointers");
   EINX_CHECK_ARG(o->feats && o->logits && o->raw && o->prob && o->score && o->positions && o->indices && o->counts && o->thr &&
                      o->not_converged && o->sparse_desc,
                  "null output pointer");
@@ -335,7 +409,7 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
     if (e->d.cell == 8) r = einx_normalize_map(o->raw, B, D, h * w, e->d.desc_scale, o->coarse, o->raw_cl, st);
     return r;
   };
-  EinxSide* sd = fork ? side_for(e, (hipStream_t)stream) : nullptr;
+  const std::shared_ptr<EinxSide> sd = fork ? side_for((hipStream_t)stream) : nullptr;  // (held until the call returns)
   std::unique_lock<std::mutex> side_lock;
   if (sd) side_lock = std::unique_lock<std::mutex>(sd->mu);
   if (sd) {  // fork: the descriptor branch runs beside the detector branch
@@ -379,13 +453,13 @@ EINX_EXPORT int einx_extract(const einx_extractor* e, float* in, const uint8_t* 
   const bool bilinear = e->d.cell == 8;
   const bool use_cl = bilinear && D <= 512;
   EinxWatch watch;  // the weight watch rides on spare workgroups of the sampling kernel: no launch of its own
-  const bool on = o->watch_n > 0 && o->watch_table && o->watch_ref && o->watch_scratch;
-  watch.table = on ? o->watch_table : nullptr;
-  watch.ref = (const unsigned long long*)o->watch_ref;
-  watch.hash = (unsigned long long*)o->watch_scratch;
-  watch.flag = o->not_converged;
-  watch.n = on ? o->watch_n : 0;
-  watch.bit = 2;
+  const bool on = ww && ww->n > 0;
+  watch.table = on ? ww->table : nullptr;
+  watch.ref = on ? (const unsigned long long*)ww->ref : nullptr;
+  watch.hash = on ? (unsigned long long*)ww->scratch : nullptr;
+  watch.flag = on ? ww->stale : nullptr;
+  watch.n = on ? ww->n : 0;
+  watch.bit = 1;
   return einx_desc_sample_watch(use_cl ? o->raw_cl : o->raw, B, D, h, w, pl.Hp, pl.Wp, bilinear ? 1 : 0, use_cl ? 1 : 0, o->indices, o->counts,
                                 o->cap, e->d.desc_scale, o->sparse_desc, watch, stream);
 }

@@ -1194,6 +1194,8 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
   Dims dm;
   EINX_CHECK_ARG(dims_of(w->d, w->heads, dm), "descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 128");
   const int D = dm.d;  // (shadows the file-level constant: every width below is the model's)
+  EINX_CHECK_ARG(w->struct_size == sizeof(einx_lg_weights) && w->layer_size == sizeof(einx_lg_layer),
+                 "einx_lg_weights::struct_size / layer_size do not match this library (header / library ABI mismatch)");
   EINX_CHECK_ARG(w->n_layers >= 1 && w->layers, "no layers");
   EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0, "bad shape");
   EINX_CHECK_ARG(w->input_dim % 4 == 0 && w->input_dim > 0, "input_dim must be a multiple of 4");

@@ -137,6 +137,7 @@ static Net make_net(int cin, bool bn, bool dilate, float input_div, hipStream_t 
   n.desc.push_back(make_layer(128, 256, 3, true, bn, false, st).d);
   n.desc.push_back(make_layer(256, 256, 1, false, bn, false, st).d);
   einx_extractor_desc d{};
+  d.struct_size = sizeof d;  // checked by the library: a header / library mismatch is an error, not garbage
   d.cell = 8;
   d.n_backbone = (int)n.bb.size();
   d.n_det = (int)n.det.size();
@@ -195,6 +196,8 @@ static void make_lightglue(LgModel& m, int n_layers, int heads, int d, int input
     lin(L.Wco, L.bco, d, d, a1);
     ffn(L.cf0_w, L.cf0_b, L.cln_g, L.cln_b, L.cf3_w, L.cf3_b);
   }
+  m.w.struct_size = sizeof(einx_lg_weights);
+  m.w.layer_size = sizeof(einx_lg_layer);
   m.w.in_w = m.w.in_b = nullptr;  // input_dim == d: Identity
   m.w.Wr = lg_array((size_t)(d / heads / 2) * 2, 1.0f);  // posenc.Wr [head_dim/2, 2]
   lin(m.w.proj_w, m.w.proj_b, d, d, a1);                 // log_assignment[last].final_proj
@@ -249,6 +252,10 @@ int main(int argc, char** argv) {
     return 2;
   }
   printf("%s, %d HIP device(s)\n", einx_version(), einx_device_count());
+  if (einx_abi_version() != EINX_ABI_VERSION) {
+    fprintf(stderr, "libeinx_hip.so speaks ABI %d, this host was built against %d\n", einx_abi_version(), EINX_ABI_VERSION);
+    return 1;
+  }
   if (einx_device_count() < 1) {
     fprintf(stderr, "no HIP device: the library has no CPU path\n");
     return 1;

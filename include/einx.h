@@ -12,7 +12,8 @@
  *   - return 0 on success, negative on error (einx_last_error() gives the text);
  *   - no device-memory allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.  Two documented pieces of
  *     library-owned state: (a) einx_extract lazily creates ONE side stream + two events per (device, caller stream) that
- *     forks (see einx_extract), shared by every handle of the process and kept until it exits; (b) einx_voxel_grid /
+ *     forks (see einx_extract), shared by every handle of the process; at most EINX_FORK_STREAMS_MAX of them exist at a time
+ *     (least recently used first out; einx_fork_stream_release drops one explicitly); (b) einx_voxel_grid /
  *     einx_events_mask keep a few hundred bytes of pinned staging per host thread for the host offsets array;
  *   - einx_build_flags() tells a shipped library from a timing-only experiment build (see below).
  * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
@@ -32,6 +33,12 @@ extern "C" {
 #define EINX_ERR_LAUNCH (-2)
 #define EINX_ERR_NO_DEVICE (-3)
 
+/* ABI revision of this header.  The public structs change layout between revisions (6: struct_size members, the weight watch out
+ * of einx_extract_out, einx_lg_layer::Wqk_v); a host compares einx_abi_version() with the EINX_ABI_VERSION it was compiled
+ * against before anything else, and every struct that is read by the library starts with `struct_size` = sizeof(the struct),
+ * which the library checks (EINX_ERR_ARG on a mismatch instead of reading garbage from a shorter / longer struct). */
+#define EINX_ABI_VERSION 6
+int einx_abi_version(void);
 const char* einx_version(void);
 const char* einx_last_error(void);
 /* Compile-time switches of this binary as a space-separated string ("" for the shipped build).  Experiment builds
@@ -255,6 +262,8 @@ typedef struct einx_lg_layer {
 } einx_lg_layer;
 
 typedef struct einx_lg_weights {
+  size_t struct_size; /* sizeof(einx_lg_weights) of the caller's header (checked) */
+  size_t layer_size;  /* sizeof(einx_lg_layer): the stride of `layers` (checked) */
   const float* in_w; /* input_proj [d,input_dim] or NULL (Identity) */
   const float* in_b;
   const float* Wr;   /* posenc.Wr [head_dim/2,2] */
@@ -325,6 +334,7 @@ int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host
 typedef struct einx_extractor einx_extractor; /* opaque */
 
 typedef struct einx_extractor_desc {
+  size_t struct_size;  /* sizeof(einx_extractor_desc) of the caller's header (checked by einx_extractor_create) */
   int32_t cell;        /* 8: SuperPoint-shaped (65-channel detector head, coarse descriptors); 1: SiLK-shaped */
   int32_t n_backbone, n_det, n_desc;
   const einx_conv_desc* backbone; /* host arrays, copied by einx_extractor_create */
@@ -365,16 +375,24 @@ typedef struct einx_extract_out {
   int32_t* indices; /* [B,cap] */
   int32_t* counts;  /* [B] */
   float* thr;       /* [B] */
-  int32_t* not_converged; /* [B] bit 0: see einx_detect; bit 1 of element 0: weight watch (below) */
+  int32_t* not_converged; /* [B] 1: the NMS fix-point of this image needs more passes than were enqueued (see einx_detect) */
   float* sparse_desc;     /* [B,cap,desc_dim] */
   int32_t cap;
-  /* optional content watch of the network's weights (einx_params_hash; watch_n == 0: off): compared at the end of the call,
-   * a difference raises bit 1 (value 2) of not_converged[0] -- the flag reaches the host with the read-back of that array */
-  int32_t watch_n;
-  const int64_t* watch_table;  /* device [watch_n][2] */
-  const uint64_t* watch_ref;   /* device [watch_n] hashes stored when the native weight images were built */
-  uint64_t* watch_scratch;     /* device [watch_n] */
 } einx_extract_out;
+
+/* Optional content watch of a network's weights riding on an einx_extract_watch call (what einx_params_hash does as a launch
+ * of its own): the rows of `table` are hashed by spare workgroups of the call's last kernel and compared with `ref`; a
+ * difference ORs 1 into *stale.  The library never clears *stale: it belongs to whoever recorded `ref` (a stale watch stays
+ * stale until its owner re-records the hashes and zeroes the word).  A torch-free host that never edits weights behind the
+ * library's back has no use for it and calls einx_extract. */
+typedef struct einx_weight_watch {
+  size_t struct_size;     /* sizeof(einx_weight_watch) */
+  int32_t n;              /* rows (0: off) */
+  const int64_t* table;   /* device [n][2]: (pointer, number of 32-bit words) per row, as einx_params_hash */
+  const uint64_t* ref;    /* device [n] hashes stored when the native weight images were built */
+  uint64_t* scratch;      /* device [n] */
+  int32_t* stale;         /* device int32, OR-ed with 1 on a mismatch */
+} einx_weight_watch;
 
 einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
 void einx_extractor_destroy(einx_extractor* e);
@@ -385,6 +403,14 @@ void einx_extractor_destroy(einx_extractor* e);
  * host that creates further streams of its own calls this once per caller stream first; the Python package does so when a model
  * is first used on a device. */
 int einx_fork_stream_prepare(void* stream);
+/* The library keeps at most EINX_FORK_STREAMS_MAX (device, caller stream) sides; a call on a further stream evicts the least
+ * recently used one that no call is using at that moment (its side stream and events are destroyed once their enqueued work has
+ * drained), so a server that creates a stream per request does not grow HIP streams / events without bound.
+ * einx_fork_stream_release drops the side of `stream` now (a host that destroys a stream it has made calls on; optional).
+ * einx_fork_stream_count: sides alive at the moment (tests, diagnostics). */
+#define EINX_FORK_STREAMS_MAX 16
+int einx_fork_stream_release(void* stream);
+int einx_fork_stream_count(void);
 int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* shapes);
 /* nms_iters: NMS pass budget per call (see einx_detect); <= 0 selects the default (8) in BOTH functions below.  The
  * workspace size depends on it (B x nms_iters convergence flags), so query and call must pass the same value. */
@@ -394,12 +420,15 @@ size_t einx_extract_ws_bytes(const einx_extractor* e, int B, int H, int W, int c
  * Networks with 1/8-resolution heads (cell == 8; full-resolution networks while B x head pixels <= 8192) enqueue the descriptor
  * branch on a library-owned side stream between a fork and a join event of `stream`; every return path has `stream` wait for the
  * join.  The side stream and its two events are created on the FIRST such call for a (device, stream) pair (or by
- * einx_fork_stream_prepare) and are shared by every handle of the process -- so make one un-captured call (or the prepare call) per
+ * einx_fork_stream_prepare), shared by every handle of the process and bounded in number (einx_fork_stream_release) -- so make one un-captured call (or the prepare call) per
  * stream before capturing einx_extract into a hipGraph (stream / event creation is not capturable).  While `stream` is being
  * captured the branches are enqueued in line (no fork: a fork nested in a caller's own fork / join makes hipStreamEndCapture of
  * ROCm 7.2 crash).  Calls that fork from one stream are serialised on a mutex. */
 int einx_extract(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
                  size_t ws_bytes, const einx_extract_out* out, void* stream);
+/* the same call with the weight watch riding on it (watch == NULL or watch->n == 0: exactly einx_extract) */
+int einx_extract_watch(const einx_extractor* e, float* in, const uint8_t* mask, int B, int H, int W, int nms_iters, void* ws,
+                       size_t ws_bytes, const einx_extract_out* out, const einx_weight_watch* watch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics of the reference's test harness (the step after the path)

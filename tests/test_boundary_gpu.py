@@ -158,3 +158,60 @@ def test_superpoint_wrong_channel_count_raises_like_conv1a():
     cfg, model, _ = _model("SP_MNN", 5)
     with pytest.raises(RuntimeError, match="to have 1 channels, but got 2 channels instead"):
         model.image_extractor.extractor(torch.zeros(1, 2, 40, 48, device=DEV))
+
+
+# ------------------------------------------------------------------ library-owned side streams are bounded
+def test_fork_streams_stay_bounded_over_many_caller_streams():
+    """einx_extract forks its descriptor branch onto a library-owned side stream per (device, caller stream).  Round 5 kept every
+    side for the life of the process: a server that creates a stream per request grew HIP streams + events without bound.  Now at
+    most EINX_FORK_STREAMS_MAX sides exist (least recently used first out, never one that a call is using), and
+    einx_fork_stream_release drops one explicitly.  64 short-lived caller streams: the count stays bounded, every result equals
+    the first one bit for bit."""
+    import ctypes
+    L = pkg.native.lib()
+    cap = 16  # EINX_FORK_STREAMS_MAX (include/einx.h)
+    cfg, model, _ = _model("SP_MNN", 51)
+    ev, mask = synth.synth_events(65, 1, 5)
+    img = synth.synth_image(65, 1)
+    evt, mt, src = _t(ev), _t(mask), _t(img)
+    ref = model(evt, src.clone(), mt)
+    torch.cuda.synchronize()
+    seen = []
+    for i in range(64):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            got = model(evt, src.clone(), mt)
+        s.synchronize()
+        for side in (0, 1):
+            assert torch.equal(got[side]["sparse_positions"][0], ref[side]["sparse_positions"][0]), i
+            assert torch.equal(got[side]["sparse_descriptors"][0], ref[side]["sparse_descriptors"][0]), i
+        assert torch.equal(got[2]["matches0"][0], ref[2]["matches0"][0]), i
+        seen.append(L.einx_fork_stream_count())
+        assert seen[-1] <= cap, seen
+        if i % 3 == 0:  # a host that tears its stream down tells the library
+            before = L.einx_fork_stream_count()
+            assert L.einx_fork_stream_release(ctypes.c_void_p(s.cuda_stream)) == 0
+            assert L.einx_fork_stream_count() <= before
+        del s
+    assert max(seen) <= cap and L.einx_fork_stream_count() <= cap
+    # releasing a stream that has no side is a no-op; the current stream's side comes back on demand
+    assert L.einx_fork_stream_release(ctypes.c_void_p(12345)) == 0
+    cur = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.einx_fork_stream_release(cur) == 0
+    got = model(evt, src.clone(), mt)
+    assert torch.equal(got[0]["sparse_descriptors"][0], ref[0]["sparse_descriptors"][0])
+
+
+def test_abi_version_and_struct_size_guards():
+    """the public structs changed layout with no guard.  Now einx_abi_version() == EINX_ABI_VERSION, and a struct whose
+    struct_size does not match the library's is refused with an error instead of being read as garbage."""
+    import ctypes
+    from importlib import import_module
+    _lib = import_module(pkg.__name__ + "._lib")
+    L = pkg.native.lib()
+    assert L.einx_abi_version() == 6 and b"ABI 6" in L.einx_version()
+    d = _lib.ExtractorDesc()
+    d.struct_size = ctypes.sizeof(_lib.ExtractorDesc) - 8  # a host built against a shorter header
+    assert not L.einx_extractor_create(ctypes.byref(d))
+    assert b"struct_size" in L.einx_last_error()
