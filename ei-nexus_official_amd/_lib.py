@@ -52,6 +52,11 @@ class MetricParams(ctypes.Structure):
                [("mma_thr", c_float * 4), ("vdd_thr", c_float * 4), ("rep_nan_if_empty", ctypes.c_int32)]
 
 
+class EventArrays(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("t", c_void_p), ("p", c_void_p), ("x_type", ctypes.c_int32), ("y_type", ctypes.c_int32),
+                ("t_type", ctypes.c_int32), ("p_type", ctypes.c_int32), ("n", ctypes.c_int64)]
+
+
 class LgLayer(ctypes.Structure):
     _names = ("Wqkv", "bqkv", "Wo", "bo", "sf0_w", "sf0_b", "sln_g", "sln_b", "sf3_w", "sf3_b",
               "Wqk", "bqk", "Wv", "bv", "Wco", "bco", "cf0_w", "cf0_b", "cln_g", "cln_b", "cf3_w", "cf3_b", "Wqk_v", "bqk_v")
@@ -117,6 +122,7 @@ SIGNATURES = {
     "einx_voxel_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
     "einx_events_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "einx_events_pack": (c_int, [ctypes.POINTER(EventArrays), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "einx_metrics_ws_bytes": (c_size_t, [ctypes.POINTER(MetricParams)]),
     "einx_pair_metrics": (c_int, [ctypes.POINTER(MetricParams)] + [c_void_p] * 13),
     "einx_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

@@ -13,6 +13,10 @@
 // by ONE wave, which walks its events in order and resolves the collisions inside a 64-event batch in lane order.  Two runs
 // are bit-identical and `raw` is bit-equal to the oracle at every size.  The count image uses integer atomics (exact).
 #include <mutex>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include <string.h>
 
 #include "einx_common.h"
 
@@ -470,14 +474,21 @@ EINX_EXPORT size_t einx_events_ws_bytes(int B, int H, int W) {
 namespace {
 // The caller's offsets array is pageable memory that it may free as soon as the call returns, so it is first copied
 // (synchronously, a few hundred bytes) into a library-owned PINNED staging buffer; the asynchronous host-to-device
-// copy then reads that.  One buffer per host thread, reused once the previous copy's event has completed.
+// copy then reads that.  A RING of kOffSlots slots per (host thread, device), each with its own event: a call takes the next
+// slot and only waits for the copy that used THAT slot kOffSlots calls ago.  (Rounds 2-5 had one slot: the second call of a
+// batch -- einx_events_mask after einx_voxel_grid -- waited for the first call's copy, which an evaluation loop had queued
+// behind the previous batch's whole forward, so the host could not run ahead of the device)
+constexpr int kOffSlots = 8;
 struct PinnedOffsets {
-  int64_t* p = nullptr;
-  size_t cap = 0;
-  hipEvent_t done = nullptr;
+  int64_t* p[kOffSlots] = {nullptr};
+  size_t cap[kOffSlots] = {0};
+  hipEvent_t done[kOffSlots] = {nullptr};
+  unsigned next = 0;
   ~PinnedOffsets() {
-    if (p) (void)hipHostFree(p);
-    if (done) (void)hipEventDestroy(done);
+    for (int i = 0; i < kOffSlots; ++i) {
+      if (p[i]) (void)hipHostFree(p[i]);
+      if (done[i]) (void)hipEventDestroy(done[i]);
+    }
   }
 };
 // one staging state per (host thread, device): an event can only be recorded on a stream of the device it was created on
@@ -495,19 +506,20 @@ long long stage_offsets(const int64_t* offsets_host, int B, int64_t* p, hipStrea
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= kMaxDev) return -2;
   PinnedOffsets& st = g_offs[devid];
+  const int k = (int)(st.next++ % kOffSlots);
   const size_t need = (size_t)B + 1;
-  if (st.done && hipEventSynchronize(st.done) != hipSuccess) return -2;  // the previous call's copy has left the buffer
-  if (need > st.cap) {
-    if (st.p) (void)hipHostFree(st.p);
-    st.p = nullptr;
-    st.cap = 0;
-    if (hipHostMalloc((void**)&st.p, need * 2 * sizeof(int64_t), hipHostMallocPortable) != hipSuccess) return -2;
-    st.cap = need * 2;
+  if (st.done[k] && hipEventSynchronize(st.done[k]) != hipSuccess) return -2;  // the copy that used this slot kOffSlots calls ago has left it
+  if (need > st.cap[k]) {
+    if (st.p[k]) (void)hipHostFree(st.p[k]);
+    st.p[k] = nullptr;
+    st.cap[k] = 0;
+    if (hipHostMalloc((void**)&st.p[k], need * 2 * sizeof(int64_t), hipHostMallocPortable) != hipSuccess) return -2;
+    st.cap[k] = need * 2;
   }
-  if (!st.done && hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return -2;
-  for (size_t i = 0; i < need; ++i) st.p[i] = offsets_host[i];
-  if (hipMemcpyAsync(p, st.p, need * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
-  if (hipEventRecord(st.done, s) != hipSuccess) return -2;
+  if (!st.done[k] && hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming) != hipSuccess) return -2;
+  for (size_t i = 0; i < need; ++i) st.p[k][i] = offsets_host[i];
+  if (hipMemcpyAsync(p, st.p[k], need * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+  if (hipEventRecord(st.done[k], s) != hipSuccess) return -2;
   return mx;
 }
 
@@ -641,5 +653,86 @@ EINX_EXPORT int einx_events_mask(const float* x, const float* y, const int64_t* 
   EINX_CHECK_LAUNCH();
   hipLaunchKernelGGL(events_mask_kernel, dim3((unsigned)einx_cdiv(n, 256), (unsigned)B), dim3(256), 0, s, cnt, n, mm, mask);
   EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Host-side helper, no kernel: concatenate the per-sample event arrays of a batch (the reference's dataset hands one dict of
+// numpy arrays per sample, datasets/representations.py:67-80 turns each into tensors) into the four flat arrays the kernels
+// read, converting to their types on the way, with `threads` host threads.  A Python host did this with four np.concatenate
+// passes on one thread: ~4 ms for 32 x 60k events, half of a B = 32 forward (the harness ran at 0.86 of the forward-only rate).
+// The destination is normally page-locked memory that the caller uploads with one asynchronous copy per array.
+// ------------------------------------------------------------------------------------------
+namespace {
+template <typename D, typename S>
+void convert_run(D* dst, const void* src, long long i0, long long i1) {
+  const S* s_ = (const S*)src;
+  for (long long i = i0; i < i1; ++i) dst[i] = (D)s_[i];
+}
+template <typename D>
+bool convert_any(D* dst, const void* src, int type, long long i0, long long i1) {
+  switch (type) {
+    case EINX_EV_F32:
+      if (sizeof(D) == 4) memcpy(dst + i0, (const float*)src + i0, (size_t)(i1 - i0) * 4);
+      else convert_run<D, float>(dst, src, i0, i1);
+      return true;
+    case EINX_EV_F64:
+      if (sizeof(D) == 8) memcpy(dst + i0, (const double*)src + i0, (size_t)(i1 - i0) * 8);
+      else convert_run<D, double>(dst, src, i0, i1);
+      return true;
+    case EINX_EV_I64: convert_run<D, int64_t>(dst, src, i0, i1); return true;
+    case EINX_EV_I32: convert_run<D, int32_t>(dst, src, i0, i1); return true;
+    case EINX_EV_I16: convert_run<D, int16_t>(dst, src, i0, i1); return true;
+    case EINX_EV_U16: convert_run<D, uint16_t>(dst, src, i0, i1); return true;
+    case EINX_EV_I8: convert_run<D, int8_t>(dst, src, i0, i1); return true;
+    case EINX_EV_U8: convert_run<D, uint8_t>(dst, src, i0, i1); return true;
+    case EINX_EV_U32: convert_run<D, uint32_t>(dst, src, i0, i1); return true;
+    case EINX_EV_U64: convert_run<D, uint64_t>(dst, src, i0, i1); return true;
+    default: return false;
+  }
+}
+}  // namespace
+
+EINX_EXPORT int einx_events_pack(const einx_event_arrays* samples, int B, float* x, float* y, double* t, float* p, int64_t* offsets,
+                                 int threads) {
+  EINX_CHECK_ARG(samples && offsets && B > 0, "null pointer / empty batch");
+  long long total = 0;
+  offsets[0] = 0;
+  for (int b = 0; b < B; ++b) {
+    const einx_event_arrays& e = samples[b];
+    EINX_CHECK_ARG(e.n >= 0 && (e.n == 0 || (e.x && e.y && e.t && e.p)), "sample with null arrays");
+    for (int ty : {e.x_type, e.y_type, e.t_type, e.p_type}) EINX_CHECK_ARG(ty >= 0 && ty <= EINX_EV_U64, "unknown element type");
+    total += e.n;
+    offsets[b + 1] = total;
+  }
+  if (total == 0) return EINX_OK;
+  EINX_CHECK_ARG(x && y && t && p, "null destination");
+  // work items: (sample, field) pieces of at most 64k elements, dealt round-robin to the threads
+  struct Item {
+    int b, f;
+    long long i0, i1;
+  };
+  std::vector<Item> items;
+  constexpr long long kPiece = 65536;
+  for (int b = 0; b < B; ++b)
+    for (long long i0 = 0; i0 < samples[b].n; i0 += kPiece)
+      for (int f = 0; f < 4; ++f) items.push_back({b, f, i0, std::min((long long)samples[b].n, i0 + kPiece)});
+  const int nt = std::max(1, std::min(threads, (int)items.size()));
+  auto work = [&](int tid) {
+    for (size_t k = (size_t)tid; k < items.size(); k += (size_t)nt) {
+      const Item& it = items[k];
+      const einx_event_arrays& e = samples[it.b];
+      const long long o = offsets[it.b];
+      if (it.f == 0) convert_any<float>(x + o, e.x, e.x_type, it.i0, it.i1);
+      else if (it.f == 1) convert_any<float>(y + o, e.y, e.y_type, it.i0, it.i1);
+      else if (it.f == 2) convert_any<double>(t + o, e.t, e.t_type, it.i0, it.i1);
+      else convert_any<float>(p + o, e.p, e.p_type, it.i0, it.i1);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int i = 1; i < nt; ++i) pool.emplace_back(work, i);
+  work(0);
+  for (auto& th : pool) th.join();
   return EINX_OK;
 }

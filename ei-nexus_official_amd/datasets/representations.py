@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from .. import _lib
 from .._lib import check
 
 
@@ -40,19 +41,55 @@ class EventStage:
             self.host[name] = torch.empty(self.cap, dtype=tdt, pin_memory=True)
             self.dev[name] = torch.empty(self.cap, dtype=tdt, device=self.device)
 
+    # element types einx_events_pack converts from (include/einx.h: EINX_EV_*); anything else goes through float64 first
+    _EV_TYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int64): 2, np.dtype(np.int32): 3, np.dtype(np.int16): 4,
+                 np.dtype(np.uint16): 5, np.dtype(np.int8): 6, np.dtype(np.uint8): 7, np.dtype(np.uint32): 8, np.dtype(np.uint64): 9,
+                 np.dtype(np.bool_): 7}
+    _threads = None
+
+    @classmethod
+    def pack_threads(cls):
+        """host threads of the packing helper: what the process may keep busy (affinity, cgroup quota) less the two that drive
+        Python and the HIP runtime, at most 8 (38 MB of copies saturate the memory system long before that)"""
+        if cls._threads is None:
+            from ..placement import pool_threads
+            cls._threads = max(1, min(8, int(pool_threads())))
+        return cls._threads
+
     def pack(self, events_list):
-        offs = np.zeros(len(events_list) + 1, np.int64)
-        np.cumsum([len(ev["x"]) for ev in events_list], out=offs[1:])
-        n = int(offs[-1])
+        """One pass: the per-sample arrays are converted and concatenated straight into the page-locked arrays by the library's
+        host-side helper on several threads (einx_events_pack; round 5 made four np.concatenate passes on one thread: ~4 ms of a
+        9.8 ms batch), then uploaded with one non-blocking copy per array on the copy stream."""
+        B = len(events_list)
+        arr = (_lib.EventArrays * B)()
+        keep = []
+        n = 0
+        for b, ev in enumerate(events_list):
+            fields = []
+            for name in ("x", "y", "t", "p"):
+                a = np.asarray(ev[name])
+                code = self._EV_TYPES.get(a.dtype)
+                if code is None or not a.flags["C_CONTIGUOUS"]:
+                    a = np.ascontiguousarray(a, None if code is not None else np.float64)
+                    code = self._EV_TYPES[a.dtype]
+                keep.append(a)
+                fields.append((a.ctypes.data, code))
+            ln = len(keep[-4])
+            if not all(len(k) == ln for k in keep[-4:]):
+                raise ValueError(f"sample {b}: x / y / t / p differ in length")
+            arr[b] = _lib.EventArrays(fields[0][0], fields[1][0], fields[2][0], fields[3][0], fields[0][1], fields[1][1], fields[2][1], fields[3][1], ln)
+            n += ln
         if n == 0:
             return None
         self._reserve(n)
+        offs = np.zeros(B + 1, np.int64)
+        hp = [ctypes.c_void_p(self.host[name].data_ptr()) for name, _, _ in self._FIELDS]
+        check(N.lib().einx_events_pack(arr, B, hp[0], hp[1], hp[2], hp[3], offs.ctypes.data_as(ctypes.c_void_p), self.pack_threads()),
+              "einx_events_pack")
         out = []
-        for name, _, _ in self._FIELDS:
-            h = self.host[name][:n]
-            np.concatenate([np.asarray(ev[name]) for ev in events_list], out=h.numpy(), casting="unsafe")
-            with torch.cuda.stream(self.copy_stream):
-                out.append(self.dev[name][:n].copy_(h, non_blocking=True))
+        with torch.cuda.stream(self.copy_stream):
+            for name, _, _ in self._FIELDS:
+                out.append(self.dev[name][:n].copy_(self.host[name][:n], non_blocking=True))
         done = torch.cuda.Event()
         done.record(self.copy_stream)
         torch.cuda.current_stream(self.device).wait_event(done)  # the kernels that read the arrays are enqueued behind the copies

@@ -32,7 +32,13 @@ class SameTimeEvaluator:
         (scaled in place by SuperPoint exactly like the reference).  Returns the per-pair metric rows [B,K] (device)."""
         W, H = self.resolution
         dev = images.device
-        events_rep, events_mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev)
+        if not hasattr(self, "_stages"):
+            self._stages = {}
+        stage = self._stages.get(("step", dev))
+        if stage is None:  # page-locked upload path (the call is synchronous: the stage is free again when it returns)
+            with torch.cuda.device(dev):
+                stage = self._stages[("step", dev)] = EventStage(dev)
+        events_rep, events_mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage)
         self.last_inputs = (events_rep, events_mask)  # what the extractors saw (deterministic since round 4: bit-equal run to run)
         ef, imf, matches = self.model(events_rep, images, events_mask)
         return self._account(ef, imf, matches, homography)

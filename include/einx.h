@@ -321,6 +321,19 @@ int einx_voxel_grid(const float* x, const float* y, const double* t, const float
 int einx_events_mask(const float* x, const float* y, const int64_t* offsets_host, int B, int H, int W, void* ws, uint8_t* mask,
                      void* stream);
 
+/* Host-side helper (no kernel, no device access): concatenates the B per-sample event arrays of a batch into the flat
+ * x / y / p (fp32) and t (fp64) HOST arrays einx_voxel_grid / einx_events_mask read after an upload, converting element types
+ * (C casts: the rounding of numpy's astype), and writes offsets[B + 1].  `threads` host threads share the copy (page-locked
+ * destinations make the upload one asynchronous copy per array).  Replaces the per-sample tensor building of
+ * datasets/representations.py:67-80 + a Python host's np.concatenate passes. */
+enum { EINX_EV_F32 = 0, EINX_EV_F64, EINX_EV_I64, EINX_EV_I32, EINX_EV_I16, EINX_EV_U16, EINX_EV_I8, EINX_EV_U8, EINX_EV_U32, EINX_EV_U64 };
+typedef struct einx_event_arrays {
+  const void *x, *y, *t, *p;                 /* host arrays of n elements each */
+  int32_t x_type, y_type, t_type, p_type;    /* EINX_EV_* */
+  int64_t n;
+} einx_event_arrays;
+int einx_events_pack(const einx_event_arrays* samples, int B, float* x, float* y, double* t, float* p, int64_t* offsets, int threads);
+
 /* ------------------------------------------------------------------------------------------
  * Handle-level extractor: ONE call enqueues a whole network (SURVEY.md 8b's coarse ABI)
  * replaces: VGGExtractor.forward / VGGExtractorNP.forward

@@ -287,3 +287,40 @@ def test_lightglue_other_widths_have_the_references_parameter_tree():
             pkg.LightGlue(conf)
     with pytest.raises(AssertionError):
         pkg.LightGlue({"descriptor_dim": 256, "num_heads": 3})
+
+
+def test_events_pack_host_helper_converts_and_concatenates_like_numpy():
+    """einx_events_pack (host side of libeinx_hip.so, no kernel): B ragged samples with the element types datasets hand out
+    (float32 / float64 / int64 / uint16 / bool ...) -> the flat fp32 x / y / p and fp64 t arrays + offsets, equal to
+    np.concatenate(...).astype(...) for every thread count."""
+    import ctypes
+    from importlib import import_module
+    _lib = import_module(pkg.__name__ + "._lib")
+    L = pkg.native.lib()
+    rng = np.random.default_rng(3)
+    codes = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int64): 2, np.dtype(np.int32): 3, np.dtype(np.int16): 4,
+             np.dtype(np.uint16): 5, np.dtype(np.int8): 6, np.dtype(np.uint8): 7, np.dtype(np.uint32): 8, np.dtype(np.uint64): 9, np.dtype(np.bool_): 7}
+    xt = [np.float32, np.uint16, np.int64, np.float64, np.int32, np.int16, np.uint32, np.uint64]
+    pt = [np.float32, np.bool_, np.int8, np.uint8, np.float64]
+    evs = []
+    for b, n in enumerate([0, 1, 70001, 5, 65536, 131073, 0, 999]):
+        t = 1.5e9 + np.cumsum(rng.random(n))
+        evs.append({"x": rng.integers(0, 346, n).astype(xt[b % len(xt)]), "y": rng.integers(0, 260, n).astype(xt[(b + 3) % len(xt)]),
+                    "t": t if b % 2 else t.astype(np.float32), "p": (rng.random(n) < 0.5).astype(pt[b % len(pt)])})
+    B = len(evs)
+    arr = (_lib.EventArrays * B)()
+    for b, e in enumerate(evs):
+        arr[b] = _lib.EventArrays(e["x"].ctypes.data, e["y"].ctypes.data, e["t"].ctypes.data, e["p"].ctypes.data, codes[e["x"].dtype],
+                                  codes[e["y"].dtype], codes[e["t"].dtype], codes[e["p"].dtype], len(e["x"]))
+    N = sum(len(e["x"]) for e in evs)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for threads in (1, 3, 8):
+        x, y, p = (np.full(N, -7, np.float32) for _ in range(3))
+        t = np.full(N, -7, np.float64)
+        offs = np.full(B + 1, -1, np.int64)
+        assert L.einx_events_pack(arr, B, P(x), P(y), P(t), P(p), P(offs), threads) == 0
+        assert offs.tolist() == np.concatenate([[0], np.cumsum([len(e["x"]) for e in evs])]).tolist()
+        for name, got, dt in (("x", x, np.float32), ("y", y, np.float32), ("t", t, np.float64), ("p", p, np.float32)):
+            assert np.array_equal(got, np.concatenate([e[name].astype(dt) for e in evs])), (name, threads)
+    bad = _lib.EventArrays(0, 0, 0, 0, 0, 0, 99, 0, 0)
+    assert L.einx_events_pack(ctypes.byref(bad), 1, None, None, None, None, P(offs), 1) != 0  # unknown element type
