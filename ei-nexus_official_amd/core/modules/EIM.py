@@ -68,12 +68,18 @@ class EIM(nn.Module):
         return st
 
     @on_input_device
-    def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False, before_match=None):
+    def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False, before_match=None,
+                        image_feats=None):
         """Enqueue the whole pipeline; returns device-side results without synchronising.
         The event and image extractors share nothing, so the event side is enqueued on a second HIP
         stream: its small late layers and its latency-bound NMS/selection kernels overlap the other
-        side's convolutions instead of leaving most of the 256 CUs idle."""
-        if self.overlap_extractors and events.device.type == "cuda":
+        side's convolutions instead of leaving most of the 256 CUs idle.
+        image_feats: the image side has been enqueued on this stream already (`enqueue_image`: a host that still has to build
+        the events -- packing raw events takes milliseconds -- starts the image network first and packs under it)."""
+        if image_feats is not None:
+            ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
+            im = image_feats
+        elif self.overlap_extractors and events.device.type == "cuda":
             cur = torch.cuda.current_stream(events.device)
             side = self._side_stream(events.device)
             side.wait_stream(cur)
@@ -107,7 +113,12 @@ class EIM(nn.Module):
         return buf
 
     @on_input_device
-    def _enqueue(self, events, image, events_mask=None, image_mask=None, slot=0, prepared=False):
+    def enqueue_image(self, image, image_mask=None):
+        """The image extractor alone, enqueued on the current stream; hand the result to `_enqueue(..., image_feats=)`."""
+        return self.image_extractor.extract_batched(image, image_mask)
+
+    @on_input_device
+    def _enqueue(self, events, image, events_mask=None, image_mask=None, slot=0, prepared=False, image_feats=None):
         """Device side of one forward, nothing waits: both extractors, the matcher, the two small count read-backs
         (non-blocking copies into pinned buffers of `slot`, each followed by an event) and every output that does
         not depend on the counts."""
@@ -131,7 +142,7 @@ class EIM(nn.Module):
         # read-back (which lets `forward` build the feature lists while the matcher still runs) and the match-count read-back
         one_readback = slot == "g"
         ev, im, mr = self.forward_batched(events, image, events_mask, image_mask, before_match=None if one_readback else read_detection,
-                                          prepared=prepared)
+                                          prepared=prepared, image_feats=image_feats)
         p["ev"], p["im"], p["mr"] = ev, im, mr
         p["args"] = (events, image, events_mask, image_mask)
         p["nm_event"] = None

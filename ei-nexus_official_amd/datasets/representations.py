@@ -56,7 +56,7 @@ class EventStage:
             cls._threads = max(1, min(8, int(pool_threads())))
         return cls._threads
 
-    def pack(self, events_list):
+    def pack(self, events_list, defer_join=False):
         """One pass: the per-sample arrays are converted and concatenated straight into the page-locked arrays by the library's
         host-side helper on several threads (einx_events_pack; round 5 made four np.concatenate passes on one thread: ~4 ms of a
         9.8 ms batch), then uploaded with one non-blocking copy per array on the copy stream."""
@@ -90,15 +90,20 @@ class EventStage:
         with torch.cuda.stream(self.copy_stream):
             for name, _, _ in self._FIELDS:
                 out.append(self.dev[name][:n].copy_(self.host[name][:n], non_blocking=True))
+        if not defer_join:
+            self.join()
+        return (*out, offs)
+
+    def join(self):
+        """the current stream waits for everything enqueued on the stage's stream so far"""
         done = torch.cuda.Event()
         done.record(self.copy_stream)
         torch.cuda.current_stream(self.device).wait_event(done)  # the kernels that read the arrays are enqueued behind the copies
-        return (*out, offs)
 
 
-def _pack(events_list, device, stage=None):
+def _pack(events_list, device, stage=None, defer_join=False):
     if stage is not None:
-        packed = stage.pack(events_list)
+        packed = stage.pack(events_list, defer_join=defer_join)
         if packed is not None:
             return packed
     xs, ys, ts, ps, offs = [], [], [], [], [0]
@@ -145,11 +150,23 @@ def events_mask_batch(events_list, resolution, device="cuda", packed=None):
     return mask.view(torch.bool)
 
 
-def events_representation_batch(events_list, input_size, normalize=True, device="cuda", stage=None):
+def events_representation_batch(events_list, input_size, normalize=True, device="cuda", stage=None, on_stage_stream=False):
     """voxel grids [B,bins,H,W] and events masks [B,1,H,W] of B samples from ONE host-side packing and upload of the raw
     event arrays (what test_events-image_same-time.py:130-140 builds per sample with two passes over the events).
-    stage: an EventStage -- the upload goes through its page-locked arrays without blocking the host."""
+    stage: an EventStage -- the upload goes through its page-locked arrays without blocking the host.
+    on_stage_stream: the two representation kernels are enqueued on the stage's stream behind the copies as well (an evaluation
+    loop: they then run beside the previous batch's forward); the current stream waits for them before it goes on."""
     bins, H, W = (int(v) for v in input_size)
+    if stage is not None and on_stage_stream:
+        packed = _pack(events_list, device, stage, defer_join=True)
+        cur = torch.cuda.current_stream(stage.device)
+        with torch.cuda.stream(stage.copy_stream):
+            grid = events_to_voxel_grid_batch(events_list, input_size, normalize, device, packed=packed)
+            mask = events_mask_batch(events_list, (W, H), device, packed=packed)
+        for t in (grid, mask):
+            t.record_stream(cur)  # allocated on the stage's stream, consumed on the caller's
+        stage.join()
+        return grid, mask
     packed = _pack(events_list, device, stage)
     return (events_to_voxel_grid_batch(events_list, input_size, normalize, device, packed=packed),
             events_mask_batch(events_list, (W, H), device, packed=packed))

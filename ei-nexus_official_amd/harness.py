@@ -34,13 +34,16 @@ class SameTimeEvaluator:
         dev = images.device
         if not hasattr(self, "_stages"):
             self._stages = {}
-        stage = self._stages.get(("step", dev))
-        if stage is None:  # page-locked upload path (the call is synchronous: the stage is free again when it returns)
-            with torch.cuda.device(dev):
+        with torch.cuda.device(dev):
+            stage = self._stages.get(("step", dev))
+            if stage is None:  # page-locked upload path (the call is synchronous: the stage is free again when it returns)
                 stage = self._stages[("step", dev)] = EventStage(dev)
-        events_rep, events_mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage)
-        self.last_inputs = (events_rep, events_mask)  # what the extractors saw (deterministic since round 4: bit-equal run to run)
-        ef, imf, matches = self.model(events_rep, images, events_mask)
+            # the image network does not depend on the events: it is enqueued FIRST and the host packs / uploads the raw events
+            # (38 MB, ~2.5 ms) under its ~4 ms of device work; the event network follows (round 6: 11.7 -> see profiles/r06_notes.md)
+            im = self.model.enqueue_image(images, None)
+            events_rep, events_mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage)
+            self.last_inputs = (events_rep, events_mask)  # what the extractors saw (deterministic since round 4: bit-equal run to run)
+            ef, imf, matches = self.model._finish(self.model._enqueue(events_rep, images, events_mask, image_feats=im))
         return self._account(ef, imf, matches, homography)
 
     def _account(self, ef, imf, matches, homography):
@@ -67,6 +70,11 @@ class SameTimeEvaluator:
         if not hasattr(self, "_stages"):
             self._stages = {}
         k = 0
+
+        def finish(entry):
+            p, hom = entry
+            return self._account(*self.model._finish(p), hom)
+
         for item in batches:
             events_list, images = item[0], item[1]
             homography = item[2] if len(item) > 2 else None
@@ -76,16 +84,18 @@ class SameTimeEvaluator:
                 stage = self._stages.get((slot, dev))
                 if stage is None:
                     stage = self._stages[(slot, dev)] = EventStage(dev)
-                rep, mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage)
+                # upload AND representation kernels of batch i + 1 on the stage's own stream: they run beside batch i's
+                # convolutions (0.3 ms of memory- / latency-bound kernels per batch leave the main stream's chain).  (Every
+                # in-flight slot on a stream of its own, so that batch i's tail could overlap batch i + 1's head, measured the
+                # same: 8.89 vs 8.84 ms per batch, profiles/r06_notes.md.)
+                rep, mask = events_representation_batch(events_list, (self.bins, H, W), normalize=True, device=dev, stage=stage, on_stage_stream=True)
                 self.last_inputs = (rep, mask)  # of the batch enqueued last (results lag by up to depth - 1 batches)
                 pending.append((self.model._enqueue(rep, images, mask, slot=slot), homography))
             k += 1
             if len(pending) >= depth:
-                p, hom = pending.popleft()
-                yield self._account(*self.model._finish(p), hom)
+                yield finish(pending.popleft())
         while pending:
-            p, hom = pending.popleft()
-            yield self._account(*self.model._finish(p), hom)
+            yield finish(pending.popleft())
 
     def result(self):
         """Mean of every metric over the pairs seen so far; sums are all-reduced when a process group is up."""

@@ -144,8 +144,10 @@ def _core_of(cpu, sys_root="/sys"):
 
 
 def plan(local_rank, world, allowed=None, sys_root="/sys"):
-    """{gpu, numa_node, cpus, physical_cores, threads, source} for the rank that drives local GPU `local_rank` of `world` on
-    this host.  `allowed`: CPUs this process may use (default: its current affinity mask)."""
+    """{gpu, numa_node, cpus, physical_cores, threads, source} for the rank that drives local GPU `local_rank` of the `world`
+    ranks ON THIS HOST (placement.local_world: LOCAL_WORLD_SIZE, not the global WORLD_SIZE).  `allowed`: CPUs this process may use
+    (default: its current affinity mask).  The GPU -> NUMA node map assumes that HIP enumerates devices in KFD topology order
+    (true on the single-vendor nodes this targets, not guaranteed by ROCm): the record says so in `source`, best effort."""
     if allowed is None:
         try:
             allowed = sorted(os.sched_getaffinity(0))
@@ -156,8 +158,8 @@ def plan(local_rank, world, allowed=None, sys_root="/sys"):
     topo = gpu_topology(sys_root)
     vis = _visible(len(topo))
     node_of = {}  # local index -> numa node
-    for loc in range(world):
-        node_of[loc] = topo[vis[loc]][0] if loc < len(vis) else -1
+    for loc in range(min(world, len(vis)) if vis else 0):  # (ranks beyond the visible GPUs have no node)
+        node_of[loc] = topo[vis[loc]][0]
     my_node = node_of.get(local_rank, -1)
     source = "even split of the allowed CPUs (GPU topology not readable)"
     cpus = None
@@ -174,7 +176,7 @@ def plan(local_rank, world, allowed=None, sys_root="/sys"):
             lo, hi = k * len(cores) // n, (k + 1) * len(cores) // n
             if hi > lo:
                 cpus = sorted(c for core in cores[lo:hi] for c in by_core[core])
-                source = f"NUMA node {my_node} of the GPU, share {k + 1} of {n}"
+                source = f"NUMA node {my_node} of the GPU (KFD topology order assumed = HIP device order), share {k + 1} of {n}"
     if not cpus:
         lo, hi = local_rank * len(allowed) // world, (local_rank + 1) * len(allowed) // world
         cpus = allowed[lo:hi] if hi > lo else [allowed[local_rank % len(allowed)]]
@@ -202,5 +204,19 @@ def apply(p):
     return p
 
 
-def place_rank(local_rank, world):
-    return apply(plan(local_rank, world))
+def local_world(world=None):
+    """ranks on THIS host: LOCAL_WORLD_SIZE (torchrun sets it), else the given / global world size (single-node launchers).
+    Every per-host division (cores of a NUMA node, the cgroup's CPU quota) is by this number, not by the global WORLD_SIZE: on a
+    2 x 8 torchrun the global figure would pin every rank to 1/16 of its node's cores."""
+    v = os.environ.get("LOCAL_WORLD_SIZE")
+    if v and v.isdigit() and int(v) > 0:
+        return int(v)
+    if world is None:
+        v = os.environ.get("WORLD_SIZE")
+        world = int(v) if v and v.isdigit() else 1
+    return max(1, int(world))
+
+
+def place_rank(local_rank, world=None):
+    """`world`: ranks on this host (default: LOCAL_WORLD_SIZE, else WORLD_SIZE)."""
+    return apply(plan(local_rank, local_world(world)))

@@ -198,3 +198,18 @@ def test_gpu_max_hw_queues_defaults_inside_ranks():
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout.strip() == "8"
     env["GPU_MAX_HW_QUEUES"] = "2"
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout.strip() == "2"
+
+
+def test_placement_divides_by_the_ranks_on_this_host(monkeypatch):
+    """on a multi-node torchrun (2 x 8) the per-host divisions must use LOCAL_WORLD_SIZE, not the global WORLD_SIZE."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("einx_placement", os.path.join(ROOT, "ei-nexus_official_amd", "placement.py"))
+    plc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(plc)
+    monkeypatch.setenv("WORLD_SIZE", "16")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert plc.local_world() == 8 and plc.local_world(16) == 8
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert plc.local_world() == 16 and plc.local_world(4) == 4
+    monkeypatch.delenv("WORLD_SIZE")
+    assert plc.local_world() == 1
