@@ -59,7 +59,7 @@ class NativeExtractor(nn.Module):
         (round 5: a hash over EVERY word of every fp32 parameter / buffer, checked by every forward, which then rebuilds the
         images and runs again).  REPLACING a Parameter object is invisible to both (the watch holds the old storage);
         `refresh()` covers that (tests/test_host_cpu.py::test_data_alias_edits_need_refresh,
-        tests/test_r4_gpu.py::test_data_edits_of_weights_take_effect_at_the_next_forward).  The flat tensor list is cached (walking the module
+        tests/test_boundary_gpu.py::test_data_edits_of_weights_take_effect_at_the_next_forward).  The flat tensor list is cached (walking the module
         tree costs 50-450 us per call); `_apply`, `load_state_dict` and `refresh()` drop it."""
         ts = self._sig_tensors
         if ts is None:

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void lg_attn_kernel(const AttnArgs a) {
 //      16 keys crow(r, lane / 32)): same scale, mask, maxima, exponentials, per-half sums -- redundantly, no exchange of state
 //   C  O^T tiles (16 dims x 16 queries), two per wave: K-step g feeds keys (crow(2g,0), crow(2g,1), crow(2g+1,0), crow(2g+1,1))
 //      = steps 2g, 2g+1 of the wide kernel; the running rescale by alpha is a separate multiplication there and here.
-// Bit-identical to lg_attn_kernel<64, 256> (tests/test_r3_gpu.py::test_lightglue_small_grid_kernels_equal_the_large_grid_kernels).
+// Bit-identical to lg_attn_kernel<64, 256> (tests/test_lightglue_gpu.py::test_lightglue_small_grid_kernels_equal_the_large_grid_kernels).
 // ------------------------------------------------------------------------------------------
 constexpr int A16_KP = 68;  // K rows: [slot k = 0..3][g = 0..15] + 4 floats of padding
 constexpr int A16_VP = 68;  // V rows: 64 dims + 4

@@ -11,7 +11,7 @@
 // With IN.bin / OUT.bin every weight tensor and input is read from IN.bin instead (raw little-endian fp32 / uint8 arrays in
 // exactly the order this program would otherwise draw them: per network, per layer w, b, [gamma, beta, mean, var]; then events,
 // mask, image) and the results are written to OUT.bin (per side counts, positions, sparse descriptors; then matches0 and the
-// match counts): tests/test_r5_gpu.py writes IN.bin from a seeded state dict and compares OUT.bin bit for bit with the oracle.
+// match counts): tests/test_boundary_gpu.py writes IN.bin from a seeded state dict and compares OUT.bin bit for bit with the oracle.
 // With a fourth argument `lg` the same features also go through a 3-layer LightGlue (einx_lightglue: lightglue.py:522-716; the
 // structs of einx.h filled in from C): its weights follow the inputs in IN.bin (per layer the fields of einx_lg_layer in their
 // order, each matrix then its bias; then posenc.Wr, final_proj, matchability) and OUT.bin ends with its matches0 / matches1 / scores0.

@@ -28,6 +28,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(autouse=True)
+def _gpu_tests_need_a_device(request):
+    """every -m gpu test: a HIP device must be there (no CPU fallback to pass on), and the device is idle again afterwards"""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    yield
+    torch.cuda.synchronize()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc

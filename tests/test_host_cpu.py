@@ -115,7 +115,7 @@ def test_parent_load_state_dict_invalidates_native_weight_images():
 def test_data_alias_edits_need_refresh():
     """`p.data` is an alias with its own version counter, so `p.data.copy_()` / `p.data.mul_()` leave `p._version`
     (what the HOST-side weight-image caches key on) unchanged: refresh() (and a parent's load_state_dict) drops every native
-    image.  Since round 4 the device-side content watch catches such edits at the next forward (tests/test_r4_gpu.py); this
+    image.  Since round 4 the device-side content watch catches such edits at the next forward (tests/test_boundary_gpu.py); this
     test pins the torch semantics that make the watch necessary."""
     model = pkg.EIM(pkg.default_config("SP_LG"), device="cpu").eval()
     ev, lg = model.event_extractor.extractor, model.matcher.matcher
