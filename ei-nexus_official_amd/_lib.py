@@ -77,6 +77,7 @@ SIGNATURES = {
     "einx_build_flags": (c_char_p, []),
     "einx_params_hash": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "einx_last_error": (c_char_p, []),
+    "einx_math_eval": (c_int, [c_int, c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
     "einx_device_count": (c_int, []),
     "einx_profile_enable": (c_int, [c_int]),
     "einx_profile_report": (c_int, [c_char_p, c_size_t]),

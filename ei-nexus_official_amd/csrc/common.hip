@@ -195,6 +195,40 @@ EINX_EXPORT int einx_image_prepare(float* image, int B, int C, int H, int W, lon
 
 
 // ------------------------------------------------------------------------------------------
+// The numeric contract on the device (tests): y[i] = f(x[i]) with the functions of include/einx_math.h as hipcc compiles them
+// for gfx950 -- bit-equal to what gcc makes of the same header for the oracle (oracle/einx_oracle.c::orc_math_eval).
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void math_eval_kernel(int fn, const float* x, long long n, float* y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float sn, cs, r = 0.0f;
+  switch (fn) {
+    case 0: r = einx_expf(x[i]); break;
+    case 1: r = einx_logf(x[i]); break;
+    case 2: einx_sincosf(x[i], &sn, &cs); r = sn; break;
+    case 3: einx_sincosf(x[i], &sn, &cs); r = cs; break;
+    case 4: r = einx_erff(x[i]); break;
+    case 5: r = einx_sigmoidf(x[i]); break;
+    case 6: r = einx_logsigmoidf(x[i]); break;
+    case 7: r = einx_geluf(x[i]); break;
+    default: r = einx_acosf(x[i]); break;
+  }
+  y[i] = r;
+}
+}  // namespace
+
+EINX_EXPORT int einx_math_eval(int fn, const float* x, long long n, float* y, void* stream) {
+  EINX_CHECK_ARG(x && y && n > 0 && fn >= 0 && fn <= 8, "bad arguments");
+  const long long blocks = (n + 255) / 256;
+  EINX_CHECK_ARG(blocks < (1ll << 31), "too many values");
+  hipLaunchKernelGGL(math_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, fn, x, n, y);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Content watch of a module's weights (round 4).  The reference's modules are plain nn.Modules: an in-place edit of a
 // weight through `p.data` takes effect at the next forward.  Here weights are repacked / folded into kernel-native images,
 // and `.data` edits do not move the version counters the host-side cache keys on.  One 64-lane wave per table row hashes every

@@ -69,18 +69,17 @@ struct EinxWatch {
 #ifdef __HIPCC__
 // one 64-lane wave hashes EVERY word of table row t (round 5; round 4 sampled 65 words per tensor).  Rows are chunks of at most
 // a few thousand words (the host cuts the tensors, einx.h: EINX_WATCH_CHUNK_WORDS), so the loads of a row are all in flight
-// at once.  term(word, position) = mix64((position << 32) | word): a bijective, NON-LINEAR finaliser (multiply, xor-shift,
-// multiply, xor-shift) of the injective (position, word) code, summed with wrap-around (order independent).  Round 5 used
-// ((position << 32) + word) * constant, which is linear: the row hash only depended on the SUM of the words, so a permutation
-// inside a row or a +5 / -5 edit of two words went unseen.  Now any single-word edit changes the hash for certain
-// and multi-word edits collide with probability ~2^-64, wherever the words sit.
+// at once.  term(word, position) = t ^ (t >> 29) with t = (word + 1) * coef(position), coef = (2 position + 1) * odd 64-bit
+// constant: every position has its own odd multiplier, so swapping two different words or a +d / -d edit of two words changes
+// the wrap-around sum for certain ((w_i - w_j) (c_i - c_j) cannot vanish mod 2^64 for 32-bit words and < 2^12 positions), the
+// xor-shift makes the sum non-linear in the words on top, and `word + 1` keeps zero words position-dependent too.  One 32 x 64
+// bit multiply per word.  (Round 5 summed ((position << 32) + word) * constant, which only depended on the SUM of a row's
+// words: a permutation inside a row or a sum-preserving edit went unseen, ADVICE r5.  A full two-multiply finaliser per word
+// doubled the sampling launch the watch rides on: 0.05 -> 0.10 ms per step at B = 32.)
 __device__ __forceinline__ unsigned long long einx_watch_term(unsigned long long pos, uint32_t word) {
-  unsigned long long x = (pos << 32) | word;
-  x *= 0x9E3779B97F4A7C15ull;
-  x ^= x >> 29;
-  x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 32;
-  return x;
+  const unsigned long long coef = (2ull * pos + 1ull) * 0x9E3779B97F4A7C15ull;
+  const unsigned long long t = ((unsigned long long)word + 1ull) * coef;
+  return t ^ (t >> 29);
 }
 __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int lane) {
   const uint32_t* p = reinterpret_cast<const uint32_t*>((uintptr_t)w.table[2 * t]);

@@ -59,6 +59,12 @@ int einx_device_count(void);
 #define EINX_WATCH_CHUNK_WORDS 4096
 int einx_params_hash(const int64_t* table, int n, uint64_t* hash, const uint64_t* ref, int32_t* stale, void* stream);
 
+/* The numeric contract on the device (test aid): y[i] = f(x[i]) for the functions of include/einx_math.h as compiled for gfx950
+ * (fn: 0 exp, 1 log, 2 sin, 3 cos, 4 erf, 5 sigmoid, 6 logsigmoid, 7 gelu, 8 acos -- what torch.exp / log / sin / cos / erf /
+ * sigmoid / F.logsigmoid / F.gelu / acos compute in the reference's modules).  The oracle compiles the same header with gcc;
+ * tests hold the two bit-equal and the header within 2 ulp of float64 libm. */
+int einx_math_eval(int fn, const float* x, long long n, float* y, void* stream);
+
 /* Measurement aid (no reference counterpart; the reference's scripts time with wall clocks around
  * whole forwards, test_events-image_same-time.py:196-208): while enabled, every kernel launch of
  * this library is bracketed by HIP events recorded on the launch stream.  einx_profile_report

@@ -1054,3 +1054,29 @@ EXPORT void orc_pair_metrics(const float* k0, int n, const float* k1, int m, con
   free(keep0);
   free(keep1);
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * The numeric contract itself (include/einx_math.h), exposed so that the CPU suite can cross-check every function against
+ * libm in float64 (tests/test_oracle_golden.py::test_math_contract_vs_libm): kernels and oracle compile the SAME header, so an
+ * error in it is common-mode and invisible to every GPU-vs-oracle array_equal.  fn: 0 exp, 1 log, 2 sin, 3 cos, 4 erf,
+ * 5 sigmoid, 6 logsigmoid, 7 gelu, 8 acos.
+ * ---------------------------------------------------------------------------------------- */
+EXPORT int orc_math_eval(int fn, const float* x, long long n, float* y) {
+  for (long long i = 0; i < n; ++i) {
+    float sn, cs;
+    switch (fn) {
+      case 0: y[i] = einx_expf(x[i]); break;
+      case 1: y[i] = einx_logf(x[i]); break;
+      case 2: einx_sincosf(x[i], &sn, &cs); y[i] = sn; break;
+      case 3: einx_sincosf(x[i], &sn, &cs); y[i] = cs; break;
+      case 4: y[i] = einx_erff(x[i]); break;
+      case 5: y[i] = einx_sigmoidf(x[i]); break;
+      case 6: y[i] = einx_logsigmoidf(x[i]); break;
+      case 7: y[i] = einx_geluf(x[i]); break;
+      case 8: y[i] = einx_acosf(x[i]); break;
+      default: return -1;
+    }
+  }
+  return 0;
+}

@@ -710,3 +710,25 @@ def test_abi_version_and_struct_size_guards():
     d.struct_size = ctypes.sizeof(_lib.ExtractorDesc) - 8  # a host built against a shorter header
     assert not L.einx_extractor_create(ctypes.byref(d))
     assert b"struct_size" in L.einx_last_error()
+
+
+# ------------------------------------------------------------------ the numeric contract on the device
+def test_math_contract_device_bits_equal_the_oracles(oracle):
+    """include/einx_math.h compiled by hipcc for gfx950 gives the SAME bits as compiled by gcc for the oracle, for every function
+    and 200k arguments each (the header against float64 libm: tests/test_oracle_golden.py::test_math_contract_vs_libm, CPU suite)."""
+    import ctypes
+    from test_oracle_golden import _MATH, math_eval_inputs
+    L = pkg.native.lib()
+    O = oracle.lib()
+    O.orc_math_eval.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    for name, fn, _, rng in _MATH:
+        x = math_eval_inputs(name, *rng)
+        exp = np.empty_like(x)
+        assert O.orc_math_eval(fn, x.ctypes.data, x.size, exp.ctypes.data) == 0
+        xt = _t(x)
+        yt = torch.empty_like(xt)
+        assert L.einx_math_eval(fn, ctypes.c_void_p(xt.data_ptr()), x.size, ctypes.c_void_p(yt.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        got = _np(yt)
+        same = got.view(np.uint32) == exp.view(np.uint32)
+        assert same.all(), (name, x[~same][:5], got[~same][:5], exp[~same][:5])

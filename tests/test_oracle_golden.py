@@ -530,3 +530,47 @@ def test_voxel_grid_degenerate_time_stamps_vs_reference(oracle):
             else:
                 assert np.array_equal(got, exp), (name, norm)
             assert (np.count_nonzero(exp) == 0) == (name != "two_stamps")
+
+
+# ------------------------------------------------------------------ the numeric contract itself
+_MATH = [("exp", 0, lambda x: np.exp(x), (-100.0, 88.0)), ("log", 1, lambda x: np.log(x), (1e-38, 3e38)), ("sin", 2, lambda x: np.sin(x), (-60.0, 60.0)),
+         ("cos", 3, lambda x: np.cos(x), (-60.0, 60.0)), ("erf", 4, None, (-6.0, 6.0)), ("sigmoid", 5, lambda x: 1.0 / (1.0 + np.exp(-x)), (-87.0, 87.0)),
+         ("logsigmoid", 6, lambda x: -np.logaddexp(0.0, -x), (-87.0, 87.0)), ("gelu", 7, None, (-8.0, 8.0)), ("acos", 8, lambda x: np.arccos(x), (-1.0, 1.0))]
+
+
+def math_eval_inputs(name, lo, hi, n=200_000, seed=5):
+    """sample points of a math-contract check: uniform over the range (log: log-uniform), plus the range's ends and values around 0 / 1"""
+    u = synth.uniform01(seed + len(name), (n,)).astype(np.float64)
+    x = np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo))) if name == "log" else lo + u * (hi - lo)
+    extra = [lo, hi, 0.5 * (lo + hi)] + ([1.0, 1.0 - 2 ** -24, 1.0 + 2 ** -23] if name in ("log", "acos") and lo <= 1.0 <= hi else []) + \
+            ([0.0, -0.0, 1e-30, -1e-30, 1e-6, -1e-6] if lo < 0 else [])
+    return np.concatenate([x, np.array([v for v in extra if lo <= v <= hi], np.float64)]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,fn,ref,rng", _MATH, ids=[m[0] for m in _MATH])
+def test_math_contract_vs_libm(oracle, name, fn, ref, rng):
+    """include/einx_math.h is compiled by gcc (oracle) AND by hipcc (kernels): an error in it is common-mode, invisible to every
+    GPU-vs-oracle array_equal.  Here each function is held against float64 libm (numpy / math.erf): within 2 ulp (exp, log; 3 for the compositions sigmoid /
+    logsigmoid; sin / cos on |x| <= 60, the positional encoding's range; erf / gelu / acos within a few ulp of their own magnitude)."""
+    import ctypes
+    import math
+    x = math_eval_inputs(name, *rng)
+    y = np.empty_like(x)
+    L = oracle.lib()
+    L.orc_math_eval.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    assert L.orc_math_eval(fn, x.ctypes.data, x.size, y.ctypes.data) == 0
+    x64 = x.astype(np.float64)
+    if name == "erf":
+        exp = np.array([math.erf(v) for v in x64])
+    elif name == "gelu":
+        exp = 0.5 * x64 * (1.0 + np.array([math.erf(v * 0.7071067811865476) for v in x64]))
+    else:
+        exp = ref(x64)
+    ulp = np.spacing(np.abs(exp).astype(np.float32)).astype(np.float64)
+    # absolute floor where the result crosses zero (sin / cos near their roots, gelu's tail): the argument reduction of an
+    # fp32 input cannot do better than one ulp of the ARGUMENT there
+    floor = {"sin": 4e-6, "cos": 4e-6, "gelu": 1e-7, "erf": 0.0, "acos": 4e-7, "logsigmoid": 1.2e-7}.get(name, 0.0)  # logsigmoid: ATen's formula goes through log(1 + e), resolution one ulp of 1
+    err = np.abs(y.astype(np.float64) - exp)
+    bound = {"erf": 4, "gelu": 6, "acos": 4, "sigmoid": 3, "logsigmoid": 3}.get(name, 2) * ulp + floor  # (sigmoid / logsigmoid are compositions: 1 / (1 + exp), as torch computes them)
+    bad = np.nonzero(~(err <= bound) & np.isfinite(exp))[0]
+    assert bad.size == 0, (name, x[bad[:5]], y[bad[:5]], exp[bad[:5]], (err / ulp)[bad[:5]])
