@@ -482,7 +482,28 @@ def layer_table(wl):
                 feats = t_in
     for r in rows:
         print("%-14s cin=%3d cout=%3d ks=%d %3dx%3d pool=%d  %8.1f us  %6.1f TFLOP/s" % r)
-    print("total conv us", round(sum(r[7] for r in rows), 1))
+    total = sum(r[7] for r in rows)
+    print("total conv us (every layer as its own launch)", round(total, 1))
+    # round 6: the image side's first two layers run as one launch in the pipeline (conv1ab_kernel) when the launch is large enough
+    import ctypes
+    ext = model.image_extractor.extractor
+    eng = ext.engine()
+    l0, l1 = eng.backbone[0], eng.backbone[1]
+    pads = pkg.native.padder_pads(260, 346, ext.cell_size)
+    Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
+    L = pkg.native.lib()
+    if L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp):
+        Ho, Wo = (Hp // 2, Wp // 2) if l1.pool else (Hp, Wp)
+        out = torch.empty((B, l1.cout, Ho, Wo), dtype=torch.float32, device=wl.dev)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        st = pkg.native._stream(out)
+        run = lambda: L.einx_conv_first_two_fused(P(wl.img_src), B, 260, 346, pads[2], pads[0], Hp, Wp, ctypes.byref(l0.desc), ctypes.byref(l1.desc), P(out), st)  # noqa: E731
+        dur = hip_time(torch, run, 5, warm=1)
+        fl = (conv_layer_flops(l0.cin, l0.cout, 3, Hp, Wp) + conv_layer_flops(l1.cin, l1.cout, 3, Hp, Wp)) * B
+        two = sum(r[7] for r in rows if r[0] in ("image.bb0", "image.bb1"))
+        print("%-14s cin=%3d cout=%3d ks=%d %3dx%3d pool=%d  %8.1f us  %6.1f TFLOP/s   (one launch instead of image.bb0 + image.bb1 = %.1f us)"
+              % ("image.bb0+1", l0.cin, l1.cout, 3, Hp, Wp, bool(l1.pool), round(dur * 1e6, 1), round(fl / dur / 1e12, 1), two))
+        print("total conv us (as launched in the pipeline)", round(total - two + dur * 1e6, 1))
 
 
 def dominant_kernel_roofline(wl, value_per_gpu, kernel_only=False):
@@ -524,12 +545,63 @@ def dominant_kernel_roofline(wl, value_per_gpu, kernel_only=False):
                        "kernel, tools/collect_profiles.sh; PMC counters cannot be read from inside this process, so this run did not re-measure them)")
     l1(x1)
     kname = pkg.native.lib().einx_conv_last_kernel().decode() + f" ({l1.cin}->{l1.cout} 3x3 @{Hp}x{Wp}, B={B})"  # what the dispatcher launched
-    return {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+    fused = fused_first_two_roofline(wl, l0, l1, pads, Hp, Wp, kernel_only)
+    return {"fused_first_two_layers": fused, "kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": round(dur * 1e3, 4), "launches_timed": reps, "flop_per_launch": flops,
             "timing": "mean of per-launch HIP-event pairs (comparable with a rocprofv3 --kernel-trace average of this kernel)",
             "back_to_back_ms": round(b2b * 1e3, 4), "back_to_back_TFLOPs": round(flops / b2b / 1e12, 2),
             "hbm_frac_at_measured_rate": round(SP_PAIR_BYTES * value_per_gpu / PEAK_HBM_BYTES, 4) if wl.config == "sp_mnn" else None}
+
+
+def fused_first_two_roofline(wl, l0, l1, pads, Hp, Wp, kernel_only=False):
+    """Round 6: the image extractor's first two layers run as ONE launch (conv1ab_kernel: conv1a recomputed per tile on the matrix
+    cores inside conv1b's launch).  Timed like the dominant kernel (per-launch HIP-event pairs on the launch stream); FLOPs = both
+    layers.  None when the dispatcher would not fuse this launch (small batches)."""
+    import ctypes
+    torch, pkg, B = wl.torch, wl.pkg, wl.B
+    L = pkg.native.lib()
+    if not L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp):
+        return None
+    Ho, Wo = (Hp // 2, Wp // 2) if l1.pool else (Hp, Wp)
+    out = torch.empty((B, l1.cout, Ho, Wo), dtype=torch.float32, device=wl.dev)
+    src = wl.img_src
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = pkg.native._stream(src)
+
+    def run():
+        rc = L.einx_conv_first_two_fused(P(src), B, 260, 346, pads[2], pads[0], Hp, Wp, ctypes.byref(l0.desc), ctypes.byref(l1.desc), P(out), st)
+        assert rc == 0, L.einx_last_error()
+
+    reps = 24
+    b2b = hip_time(torch, run, reps, warm=2)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize()
+    for e0, e1 in evs:
+        e0.record()
+        run()
+        e1.record()
+    torch.cuda.synchronize()
+    dur = sum(e0.elapsed_time(e1) for e0, e1 in evs) * 1e-3 / reps
+    flops = (conv_layer_flops(l0.cin, l0.cout, l0.ks, Hp, Wp) + conv_layer_flops(l1.cin, l1.cout, l1.ks, Hp, Wp)) * B
+    # the two launches it replaces, alone on the device
+    x1 = l0(src, fold=(pads[2], pads[0], Hp, Wp))
+    t0 = hip_time(torch, lambda: l0(src, fold=(pads[2], pads[0], Hp, Wp)), 12, warm=2)
+    t1 = hip_time(torch, lambda: l1(x1), 12, warm=2)
+    traffic = None
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv1ab.json")))
+    if wl.config == "sp_mnn" and B == 32 and pmcs:
+        traffic = json.load(open(pmcs[-1])).get("hbm_bytes_per_launch")
+    alg = B * (260 * 346 + l1.cout * Ho * Wo) * 4  # the raw image in, the second layer's output out
+    return {"kernel": L.einx_conv_last_kernel().decode() + f" (1->64->64 3x3 @{Hp}x{Wp}, B={B})", "bound": "mfma", "launch_ms": round(dur * 1e3, 4),
+            "launches_timed": reps, "flop_per_launch": flops, "achieved": round(flops / dur / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / dur / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "back_to_back_ms": round(b2b * 1e3, 4),
+            "replaces_ms": {"first_layer": round(t0 * 1e3, 4), "second_layer": round(t1 * 1e3, 4), "sum": round((t0 + t1) * 1e3, 4)},
+            "algorithmic_bytes_per_launch": alg, "traffic": traffic,
+            "intermediate_bytes_no_longer_moved": 2 * B * l0.cout * Hp * Wp * 4,
+            "note": "image extractor, layers 1-2 as one launch; the event extractor (5 input channels) keeps two launches: its second layer is the "
+                    "`roofline` kernel above"}
 
 
 def stage_rooflines(wl, lg_wl=None):
@@ -553,8 +625,8 @@ def stage_rooflines(wl, lg_wl=None):
     single_stream_forward(wl)
     prof = library_profile(pkg, lambda: single_stream_forward(wl))
     if not wl.config.startswith("silk"):
-        conv_ms = sum(ms for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel"))
-        conv_calls = sum(c for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel"))
+        conv_ms = sum(ms for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel") or k.startswith("conv1ab_kernel"))
+        conv_calls = sum(c for k, (c, ms) in prof.items() if k.startswith("conv_block_kernel") or k.startswith("conv1ab_kernel"))
         fl = sp_pair_flops(wl.ce) * B
         if conv_ms > 0:
             out.append({"stage": "conv encoders + heads (both extractors, %d launches)" % conv_calls, "ms": round(conv_ms, 3),
@@ -570,7 +642,7 @@ def stage_rooflines(wl, lg_wl=None):
         out.append({"stage": "descriptor-correlation GEMM + fused arg-max (mnn_tile_kernel<0>)", "ms": round(ms / c, 4), "bound": "mfma",
                     "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
-    tail = {k: round(ms, 4) for k, (c, ms) in prof.items() if not k.startswith("conv_block_kernel") and not k.startswith("mnn_tile")}
+    tail = {k: round(ms, 4) for k, (c, ms) in prof.items() if not k.startswith("conv_block_kernel") and not k.startswith("conv1ab_kernel") and not k.startswith("mnn_tile")}
     if tail:
         out.append({"stage": "latency-bound tail (ms per forward, both sides)", "kernels_ms": tail})
     if lg_wl is not None:

@@ -96,6 +96,9 @@ SIGNATURES = {
     "einx_conv_repack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "einx_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "einx_conv_block": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
+    "einx_conv_first_two_fused_ok": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), c_int, c_int, c_int]),
+    "einx_conv_first_two_fused": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc),
+                                  c_void_p, c_void_p]),
     "einx_div_inplace": (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
     "einx_image_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
                            c_float, c_void_p, c_void_p]),

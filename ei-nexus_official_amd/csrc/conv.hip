@@ -449,6 +449,300 @@ __global__ __launch_bounds__(WM * WN * 64, WPS) void conv_block_kernel(const Con
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 6: the first two layers of a 1-channel network (SuperPointv1: conv1a 1 -> 64, conv1b 64 -> 64 + pool) as ONE launch, so that
+// the 761 MB conv1a output (B = 32) is never written to or read from HBM.  The second layer is conv_block_kernel<3,8,32,2,4,1,2,8>
+// (same tile, wave layout, K order, epilogue); what changes is where its input planes come from: instead of staging 8 channels
+// of the first layer's output per chunk from global memory, the workgroup recomputes 16 of them (two chunks) at a time on the
+// 10 x 34 halo of its tile, on the matrix cores:
+//   v_mfma_f32_16x16x4_f32: M = 16 first-layer channels, N = 16 consecutive halo positions, K = the 9 taps padded to 12
+//   (three instructions; taps in order = the first layer's k-ordered chain, the padding rows of A are zero: fma(0, x, acc) = acc);
+//   A = first-layer weights (its native image: row 2 tap), B = the raw 12 x 36 input tile in LDS (loaded once, replicate fold and
+//   zero padding applied), C + bias -> ReLU -> (affine) -> the LDS planes the second layer's B operand is read from; positions
+//   outside the image stay zero (the second layer's zero padding).  22 N-tiles per 16 channels, dealt to the 8 waves.
+// Every output is the same chain of operations as the two launches: bit-identical (tests/test_conv_gpu.py).
+// Cost against the two launches: +2.9 % matrix time, ~+12 vector instructions per wave and chunk, 43 KB of LDS (three per CU).
+// ------------------------------------------------------------------------------------------
+struct Conv1abArgs {
+  ConvArgs c;          // the SECOND layer (in = the raw input of the first one; Hs / Ws / h0 / w0: the first layer's replicate fold)
+  const float* w0;     // first layer, native image [rows][cout0pad]: row 2 tap holds tap's weights of the 64 channels
+  const float* bias0;  // [64] or null
+  const float* scale0; // [64] or null (BatchNorm affine after the ReLU)
+  const float* shift0;
+  int relu0, cout0pad;
+};
+
+template <bool POOL, int WPS>
+__global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa) {
+  const ConvArgs& a = fa.c;
+  constexpr int KS = 3, TH = 8, TW = 32, WN = 4, MT = 1, NT = 2, CK = 8;
+  constexpr int kMT = MT, kNT = NT;
+  constexpr int TAPS = 9, PW = TW + 2, PH = TH + 2;
+  constexpr int PITCH = conv_lds_pitch(TH, TW);
+  static_assert(PITCH == PW, "the halo's flat index is its LDS offset");
+  constexpr int PLANE = PH * PITCH;     // 340
+  constexpr int NTHR = 512;
+  constexpr int C0 = 64;                // first-layer channels = second-layer input channels
+  constexpr int PAIR = 16;              // first-layer channels recomputed per round (two chunks of the second layer)
+  constexpr int IN_LDS = PAIR * PLANE;  // 5440 floats
+  constexpr int W_ROWS = CK * TAPS, W_F4 = W_ROWS * kCoutTile / 4, W_PER_THR = (W_F4 + NTHR - 1) / NTHR;
+  constexpr int RH = PH + 2, RP = PW + 2;  // raw tile: halo 2 (12 x 36)
+  constexpr int NT16 = (PLANE + 15) / 16;  // 22 N-tiles of 16 halo positions
+  constexpr int SLOTS = (NT16 + 7) / 8;    // N-tiles per wave (3)
+  __shared__ __attribute__((aligned(16))) float in_tile[IN_LDS];
+  __shared__ __attribute__((aligned(16))) float w_tile[W_ROWS * kCoutTile];
+  __shared__ __attribute__((aligned(16))) float raw[RH * RP];
+  __shared__ __attribute__((aligned(16))) float w0s[12 * 64], c0s[3 * 64];  // first layer: weights [k][channel], bias | scale | shift
+  __shared__ __attribute__((aligned(16))) float s_bias[kCoutTile], s_scale[kCoutTile], s_shift[kCoutTile];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int ncot = (int)gridDim.y;
+  int item = xcd_contiguous((int)(blockIdx.x + blockIdx.y * gridDim.x), (int)gridDim.x * ncot);
+  const int co0 = (item % ncot) * kCoutTile;
+  int bid = item / ncot;
+  const int tx_i = bid % a.tilesX;
+  bid /= a.tilesX;
+  const int ty_i = bid % a.tilesY;
+  const int b = bid / a.tilesY;
+  if (tid < kCoutTile) {
+    const int co = co0 + tid;
+    const bool cv = co < a.Cout;
+    s_bias[tid] = (cv && a.bias) ? a.bias[co] : 0.0f;
+    s_scale[tid] = (cv && a.scale) ? a.scale[co] : 1.0f;
+    s_shift[tid] = (cv && a.scale) ? a.shift[co] : 0.0f;
+  }
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  // ---- raw input tile (one channel): logical (y, x) inside [0,H) x [0,W) = source clamped (replicate fold), outside = 0
+  if (tid < RH * RP) {
+    const int ry = tid / RP, rx = tid % RP;
+    const int y = y0 - 2 + ry, x = x0 - 2 + rx;
+    float v = 0.0f;
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+      int sy = y - a.h0, sx = x - a.w0;
+      sy = sy < 0 ? 0 : (sy > a.Hs - 1 ? a.Hs - 1 : sy);
+      sx = sx < 0 ? 0 : (sx > a.Ws - 1 ? a.Ws - 1 : sx);
+      v = a.in[(size_t)b * a.Hs * a.Ws + (size_t)sy * a.Ws + sx];
+    }
+    raw[tid] = v;
+  }
+  // halo positions outside the image: zero in all 16 planes, once (never written again)
+  if (tid < PLANE) {
+    const int py = tid / PW, px = tid % PW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    if (!(y >= 0 && y < a.H && x >= 0 && x < a.W)) {
+#pragma unroll
+      for (int c = 0; c < PAIR; ++c) in_tile[c * PLANE + tid] = 0.0f;
+    }
+  }
+  // ---- second layer: per-lane pixel bookkeeping (as conv_block_kernel)
+  int bBase[kNT], qidx[kNT];
+#pragma unroll
+  for (int nt = 0; nt < kNT; ++nt) {
+    const int q = (wn * kNT + nt) * 32 + j;
+    qidx[nt] = q;  // NPIX == 256 slots: every slot is a pixel
+    bBase[nt] = half * PLANE + (q / TW) * PITCH + q % TW;
+  }
+  const int aBase = half * kCoutTile + wm * MT * 32 + j;
+  unsigned woff[W_PER_THR];
+#pragma unroll
+  for (int i = 0; i < W_PER_THR; ++i) {
+    const int f = tid + i * NTHR;
+    const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
+    woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4) * 4u;
+  }
+  // ---- first layer on the matrix cores: this wave's N-tiles (16 halo positions each).  Its weights (12 K rows x 64 channels,
+  // rows past the ninth tap zero) and epilogue constants sit in LDS: nothing of it is held in registers across the second
+  // layer's chunks (the kernel has 80 registers for three workgroups per CU).
+  for (int i = tid; i < 12 * C0; i += NTHR) {
+    const int k = i / C0, c = i % C0;
+    w0s[i] = k < TAPS ? fa.w0[(size_t)(2 * k) * fa.cout0pad + c] : 0.0f;
+  }
+  if (tid < C0) {
+    c0s[tid] = fa.bias0 ? fa.bias0[tid] : 0.0f;
+    c0s[C0 + tid] = fa.scale0 ? fa.scale0[tid] : 1.0f;
+    c0s[2 * C0 + tid] = fa.scale0 ? fa.shift0[tid] : 0.0f;
+  }
+  const int q16 = lane >> 4, n16 = lane & 15;
+  int rawBase[SLOTS];                           // raw-tile offset of the 3x3 patch of slot s's position
+  const int wr0 = 4 * q16 * PLANE + 16 * wave + n16;  // LDS offset of slot 0's position in channel 4 q16 of the pair; slot s: + 128 s
+  const int aBase0 = q16 * C0 + n16;            // A: k = 4 g + q16 -> + 256 g; channels of pair cp -> + 16 cp
+  unsigned live = 0;                            // bit s: slot s holds a position inside the image (its outputs are written)
+#pragma unroll
+  for (int s_ = 0; s_ < SLOTS; ++s_) {
+    const int t = wave + 8 * s_;
+    const int p = 16 * t + n16;
+    const bool pv = t < NT16 && p < PLANE;
+    const int pc = pv ? p : 0;
+    const int py = pc / PW, px = pc % PW;
+    rawBase[s_] = py * RP + px;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    if (pv && y >= 0 && y < a.H && x >= 0 && x < a.W) live |= 1u << s_;
+  }
+  int kOff[3];  // raw-tile offset of tap k = 4 g + q16 (taps past the ninth read a valid address; their A rows are zero)
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int k = 4 * g + q16;
+    kOff[g] = k < TAPS ? (k / 3) * RP + k % 3 : 0;
+  }
+  typedef float f32x4v_ __attribute__((ext_vector_type(4)));
+  auto first_layer_pair = [&](int cp) {  // first-layer channels 16 cp .. 16 cp + 15 on the 340 halo positions -> in_tile
+    float fA[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) fA[g] = w0s[aBase0 + 256 * g + PAIR * cp];
+    const float* cst = c0s + PAIR * cp + 4 * q16;  // this lane's four channels: bias at +i, scale at +64 + i, shift at +128 + i
+#pragma unroll
+    for (int s_ = 0; s_ < SLOTS; ++s_) {
+      if (wave + 8 * s_ >= NT16) break;  // wave-uniform
+      f32x4v_ c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int g = 0; g < 3; ++g) c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[g], raw[rawBase[s_] + kOff[g]], c4, 0, 0, 0);
+      if ((live >> s_) & 1u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = c4[i] + cst[i];
+          if (fa.relu0) v = fmaxf(v, 0.0f);
+          if (fa.scale0) v = fmaf(v, cst[C0 + i], cst[2 * C0 + i]);
+          in_tile[wr0 + 128 * s_ + i * PLANE] = v;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[kMT][kNT];
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+  f32x4 sW[W_PER_THR];
+  auto issue_w = [&](int c) {
+    const __amdgpu_buffer_rsrc_t rw = conv_rsrc(a.w + (size_t)c * W_ROWS * a.CoutPad, (unsigned)(W_ROWS * a.CoutPad) * 4u);
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i)
+      if ((i + 1) * NTHR <= W_F4 || tid + i * NTHR < W_F4) sW[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[i], 0, 0));
+  };
+  auto commit_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < W_PER_THR; ++i)
+      if ((i + 1) * NTHR <= W_F4 || tid + i * NTHR < W_F4) *reinterpret_cast<f32x4*>(w_tile + (tid + i * NTHR) * 4) = sW[i];
+  };
+  auto mfma_chunk = [&](int plane0) {  // the second layer's 36 K-steps on planes plane0 .. plane0 + 7
+    constexpr int STEPS = (CK / 2) * TAPS;
+    constexpr int PF = 2;
+    float av[PF + 1][kMT], bv[PF + 1][kNT];
+    const float* it = in_tile + plane0 * PLANE;
+    auto load_frag = [&](int st, int buf) {
+      const int kp = st / TAPS, tap = st % TAPS;
+      const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) av[buf][mt] = w_tile[aBase + (kp * TAPS + tap) * 2 * kCoutTile + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < kNT; ++nt) bv[buf][nt] = it[bBase[nt] + kp * 2 * PLANE + ky * PITCH + kx];
+    };
+#pragma unroll
+    for (int st = 0; st < PF && st < STEPS; ++st) load_frag(st, st % (PF + 1));
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      if (st + PF < STEPS) load_frag(st + PF, (st + PF) % (PF + 1));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % (PF + 1)][mt], bv[st % (PF + 1)][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  issue_w(0);
+  constexpr int NPAIRS = C0 / PAIR;  // 4
+  for (int cp = 0; cp < NPAIRS; ++cp) {
+    __syncthreads();  // raw tile / first-layer constants / zeroed cells visible (first round); the previous round's LDS reads are done
+    first_layer_pair(cp);
+    commit_w();
+    __syncthreads();
+    issue_w(2 * cp + 1);
+    mfma_chunk(0);
+    __syncthreads();
+    commit_w();
+    __syncthreads();
+    if (2 * cp + 2 < 2 * NPAIRS) issue_w(2 * cp + 2);
+    mfma_chunk(CK);
+  }
+
+  // ---- epilogue of the second layer: bias -> ReLU -> BN affine -> (pool) -> NCHW store (as conv_block_kernel)
+  const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
+  const unsigned plane_o = (unsigned)(Ho * Wo);
+  float* out_b = a.out + (size_t)b * a.Cout * plane_o;
+  constexpr int NO = POOL ? kNT / 2 : kNT;
+  unsigned ovoff[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    int pix = -1;
+    const int q = qidx[POOL ? 2 * o : o];
+    const int ty = q / TW, tx = q % TW;
+    if (POOL) {
+      const int yo = (y0 + ty) >> 1, xo = (x0 + tx) >> 1;
+      if (!(ty & 1) && !(tx & 1) && yo < Ho && xo < Wo) pix = yo * Wo + xo;
+    } else {
+      const int y = y0 + ty, x = x0 + tx;
+      if (y < a.H && x < a.W) pix = y * a.W + x;
+    }
+    ovoff[o] = pix >= 0 ? ((unsigned)pix + (unsigned)(4 * half) * plane_o) * 4u : 0xFFFFFFFFu;
+  }
+  auto epilogue = [&](auto relu_c, auto aff_c) {
+    constexpr bool RELU = decltype(relu_c)::value, AFF = decltype(aff_c)::value;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl0 = wm * 32 + 8 * g;
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(&s_bias[cl0 + 4 * half]);
+      f32x4 sc, sh;
+      if (AFF) {
+        sc = *reinterpret_cast<const f32x4*>(&s_scale[cl0 + 4 * half]);
+        sh = *reinterpret_cast<const f32x4*>(&s_shift[cl0 + 4 * half]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const int co_r = co0 + cl0 + i;
+        const int nch = a.Cout - co_r > 0 ? a.Cout - co_r : 0;
+        const __amdgpu_buffer_rsrc_t ro = conv_rsrc(out_b + (size_t)co_r * plane_o, (unsigned)nch * plane_o * 4u);
+        float pv[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+          float v = acc[0][nt][r] + bi[i];
+          if (RELU) v = fmaxf(v, 0.0f);
+          if (AFF) v = fmaf(v, sc[i], sh[i]);
+          pv[nt] = v;
+        }
+        if (!POOL) {
+#pragma unroll
+          for (int nt = 0; nt < kNT; ++nt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[nt]), ro, ovoff[nt], 0, 0);
+        } else {
+#pragma unroll
+          for (int o = 0; o < NO; ++o) {
+            float m = fmaxf(pv[2 * o], pv[2 * o + 1]);
+            m = max_lane_xor<1>(m);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ro, ovoff[o], 0, 0);
+          }
+        }
+      }
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  if (a.relu) {
+    if (a.scale) epilogue(T_{}, T_{});
+    else epilogue(T_{}, F_{});
+  } else {
+    if (a.scale) epilogue(F_{}, T_{});
+    else epilogue(F_{}, F_{});
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small grids (single pairs: the reference's own call pattern): conv3x3 on v_mfma_f32_16x16x4_f32.
 // A launch that cannot fill the chip is bound by the LATENCY of one workgroup = chunks x K-steps x MFMA latency; the
 // k-ordered chain forbids splitting K.  The 16x16x4 instruction consumes four K per 32-cycle issue (40 dependent) instead
@@ -801,6 +1095,61 @@ EINX_EXPORT int einx_bn_fold(const float* gamma, const float* beta, const float*
   EINX_CHECK_ARG(n > 0, "bad channel count");
   hipLaunchKernelGGL(bn_fold_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, n, scale,
                      shift);
+  EINX_CHECK_LAUNCH();
+  return EINX_OK;
+}
+
+// first two layers of a 1-channel network as one launch (conv1ab_kernel); -1 from the dispatcher check = not applicable, the
+// caller runs the two layers one after the other
+EINX_EXPORT int einx_conv_first_two_fused_ok(const einx_conv_desc* d0, const einx_conv_desc* d1, int B, int H, int W) {
+  if (!d0 || !d1) return 0;
+  const bool shapes = d0->cin == 1 && d0->cout == 64 && d0->ks == 3 && !d0->pool && d1->cin == 64 && d1->cout == 64 && d1->ks == 3;
+  if (!shapes || (d1->pool && ((H & 1) || (W & 1)))) return 0;
+  // the large-grid regime of conv_block_kernel's three-per-CU instantiation (what the fused kernel replaces); smaller launches keep
+  // the two latency-tuned launches
+  const long grid = (long)einx_cdiv(W, 32) * einx_cdiv(H, 8) * B;
+  return grid >= 8L * 768 ? 1 : 0;
+}
+
+EINX_EXPORT int einx_conv_first_two_fused(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d0,
+                                          const einx_conv_desc* d1, float* out, void* stream) {
+  EINX_CHECK_ARG(in && out && d0 && d1 && d0->w_native && d1->w_native, "null pointer");
+  EINX_CHECK_ARG(einx_conv_first_two_fused_ok(d0, d1, B, H, W), "layers / launch size outside what the fused first-two-layers kernel covers");
+  EINX_CHECK_ARG((d0->scale == nullptr) == (d0->shift == nullptr) && (d1->scale == nullptr) == (d1->shift == nullptr), "scale and shift go together");
+  EINX_CHECK_ARG((size_t)Hs * Ws < (1u << 30) && (size_t)64 * H * W < (1u << 30), "image too large");
+  Conv1abArgs fa;
+  ConvArgs& a = fa.c;
+  a.in = in;
+  a.w = d1->w_native;
+  a.bias = d1->bias;
+  a.scale = d1->scale;
+  a.shift = d1->shift;
+  a.out = out;
+  a.B = B;
+  a.Cin = 64;
+  a.Cout = 64;
+  a.CoutPad = 64;
+  a.Hs = Hs;
+  a.Ws = Ws;
+  a.h0 = h0;
+  a.w0 = w0;
+  a.H = H;
+  a.W = W;
+  a.relu = d1->relu;
+  a.tilesX = einx_cdiv(W, 32);
+  a.tilesY = einx_cdiv(H, 8);
+  fa.w0 = d0->w_native;
+  fa.bias0 = d0->bias;
+  fa.scale0 = d0->scale;
+  fa.shift0 = d0->shift;
+  fa.relu0 = d0->relu;
+  fa.cout0pad = 64;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(a.tilesX * a.tilesY * B), 1);
+  g_last_conv_kernel = d1->pool ? "conv1ab_kernel<true> (first two layers fused, 3 per CU)" : "conv1ab_kernel<false> (first two layers fused, 3 per CU)";
+  EINX_PROF("conv1ab_kernel (first two layers)", s);
+  if (d1->pool) hipLaunchKernelGGL((conv1ab_kernel<true, 6>), grid, dim3(512), 0, s, fa);
+  else hipLaunchKernelGGL((conv1ab_kernel<false, 6>), grid, dim3(512), 0, s, fa);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

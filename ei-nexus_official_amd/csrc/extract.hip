@@ -369,7 +369,19 @@ EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uin
   const float* cur = in;
   int h = pl.Hp, w = pl.Wp;
   const int nb = (int)e->backbone.size();
-  for (int i = 0; i < nb; ++i) {
+  int first = 0;
+  // the first two layers of a 1-channel network as one launch (large launches only: einx_conv_first_two_fused_ok)
+  if (nb >= 2 && einx_conv_first_two_fused_ok(&e->backbone[0], &e->backbone[1], B, pl.Hp, pl.Wp)) {
+    float* out = (2 < nb) ? buf[1] : o->feats;
+    if ((rc = einx_conv_first_two_fused(in, B, H, W, pl.h0, pl.w0, pl.Hp, pl.Wp, &e->backbone[0], &e->backbone[1], out, stream))) return rc;
+    if (e->backbone[1].pool) {
+      h /= 2;
+      w /= 2;
+    }
+    cur = out;
+    first = 2;
+  }
+  for (int i = first; i < nb; ++i) {
     const einx_conv_desc& c = e->backbone[i];
     float* out = (i + 1 < nb) ? buf[i & 1] : o->feats;
     if (i == 0) rc = einx_conv_block(cur, B, H, W, pl.h0, pl.w0, pl.Hp, pl.Wp, &c, out, stream);

@@ -66,6 +66,55 @@ def test_conv_block_three_per_cu_instantiation_bit_exact(oracle, pool):
     assert np.array_equal(_np(got), exp)
 
 
+@pytest.mark.parametrize("case", [dict(B=18, H=260, W=346, fold=(2, 3, 264, 352), pool=True, bn0=False, relu1=True),   # SuperPointv1 at 346x260 (replicate fold)
+                                  dict(B=640, H=40, W=48, fold=None, pool=True, bn0=True, relu1=True),               # small maps, BatchNorm after the first layer
+                                  dict(B=420, H=37, W=77, fold=(1, 1, 40, 80), pool=False, bn0=True, relu1=False),   # un-pooled second layer, partial tiles
+                                  dict(B=1100, H=24, W=40, fold=None, pool=True, bn0=False, relu1=True)],
+                         ids=["sp_346x260", "small_bn", "unpooled_partial", "tiny"])
+def test_first_two_layers_fused_bit_exact(oracle, case):
+    """Round 6: conv1a (1 -> 64) recomputed inside conv1b's launch on the matrix cores (conv1ab_kernel): the output of the second
+    layer is bit-equal to the two launches it replaces (every image) and to the oracle's two conv blocks (sampled images)."""
+    import ctypes
+    B, H, W, fold = case["B"], case["H"], case["W"], case["fold"]
+    x = synth.normalish(91, (B, 1, H, W))
+    w0 = synth.synth_param("a.weight", (64, 1, 3, 3), 92)
+    b0 = synth.uniform(93, (64,), -0.5, 0.5)
+    w1 = synth.synth_param("b.weight", (64, 64, 3, 3), 94)
+    b1 = synth.uniform(95, (64,), -0.5, 0.5)
+    bn0 = s0 = t0 = None
+    if case["bn0"]:
+        g, be = synth.uniform(96, (64,), 0.5, 1.5), synth.uniform(97, (64,), -0.3, 0.3)
+        mu, var = synth.uniform(98, (64,), -0.3, 0.3), synth.uniform(99, (64,), 0.5, 1.5)
+        g[5] = -g[5]
+        s0, t0 = oracle.bn_fold(g, be, mu, var)
+        bn0 = (_t(g), _t(be), _t(mu), _t(var), 1e-5)
+    l0 = pkg.native.ConvLayer(_t(w0), _t(b0), bn0, relu=True, pool=False)
+    l1 = pkg.native.ConvLayer(_t(w1), _t(b1), None, relu=case["relu1"], pool=case["pool"])
+    xt = _t(x)
+    Hp, Wp = (fold[2], fold[3]) if fold else (H, W)
+    h0, w0_ = (fold[0], fold[1]) if fold else (0, 0)
+    L = pkg.native.lib()
+    assert L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp) == 1
+    assert L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), 1, Hp, Wp) == 0  # small launches keep the two layers
+    seq = l1(l0(xt, fold=(h0, w0_, Hp, Wp) if fold else None))
+    Ho, Wo = (Hp // 2, Wp // 2) if case["pool"] else (Hp, Wp)
+    got = torch.full((B, 64, Ho, Wo), float("nan"), dtype=torch.float32, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rc = L.einx_conv_first_two_fused(P(xt), B, H, W, h0, w0_, Hp, Wp, ctypes.byref(l0.desc), ctypes.byref(l1.desc), P(got), None)
+    assert rc == 0, L.einx_last_error()
+    assert L.einx_conv_last_kernel().decode().startswith("conv1ab_kernel")
+    torch.cuda.synchronize()
+    assert torch.equal(got, seq)
+    for b in (0, B // 2, B - 1):  # the oracle on sampled images
+        xb = x[b:b + 1]
+        if fold:
+            pads = (w0_, Wp - W - w0_, h0, Hp - H - h0)
+            xb = oracle.pad_replicate(xb, pads)
+        mid = oracle.conv_block(xb, w0, b0, s0, t0, relu=True, pool=False)
+        exp = oracle.conv_block(mid, w1, b1, None, None, relu=case["relu1"], pool=case["pool"])
+        assert np.array_equal(_np(got[b:b + 1]), exp), b
+
+
 @pytest.mark.parametrize("shape", CONV16_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
 def test_conv16_small_grid_kernel_bit_exact(oracle, shape):
     """conv16_kernel (v_mfma_f32_16x16x4_f32, one accumulator chain per output in the same K order as conv_block_kernel):
