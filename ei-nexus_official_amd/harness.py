@@ -22,8 +22,9 @@ class SameTimeEvaluator:
         self.resolution = tuple(int(v) for v in resolution)
         self.mma_thr, self.vdd_thr = tuple(mma_thr), tuple(vdd_thr)
         self.names = metric_names(self.mma_thr, self.vdd_thr)
-        self.sums = None
-        self.counts = None
+        self._sums = None
+        self._counts = None
+        self._rows = []
         self.pairs = 0
 
     @torch.no_grad()
@@ -48,12 +49,33 @@ class SameTimeEvaluator:
 
     def _account(self, ef, imf, matches, homography):
         rows = batch_metrics(ef._batched, imf._batched, self.model._last_match, homography, self.mma_thr, self.vdd_thr)
-        ok = ~torch.isnan(rows)
-        z = torch.nan_to_num(rows)
-        self.sums = z.sum(0) if self.sums is None else self.sums + z.sum(0)
-        self.counts = ok.sum(0).double() if self.counts is None else self.counts + ok.sum(0).double()
+        # the running sums are folded lazily (`_fold`): eight small reductions per batch on the forward's stream were a third of
+        # what the evaluation loop cost on top of the forward (profiles/r06_notes.md 3)
+        self._rows.append(rows)
+        if len(self._rows) >= 64:
+            self._fold()
         self.pairs += rows.shape[0]
         return rows, (ef, imf, matches)
+
+    def _fold(self):
+        if not self._rows:
+            return
+        rows = torch.cat(self._rows, 0) if len(self._rows) > 1 else self._rows[0]
+        self._rows = []
+        ok = ~torch.isnan(rows)
+        z = torch.nan_to_num(rows)
+        self._sums = z.sum(0) if self._sums is None else self._sums + z.sum(0)
+        self._counts = ok.sum(0).double() if self._counts is None else self._counts + ok.sum(0).double()
+
+    @property
+    def sums(self):
+        self._fold()
+        return self._sums
+
+    @property
+    def counts(self):
+        self._fold()
+        return self._counts
 
     @torch.no_grad()
     def run(self, batches, depth=2):

@@ -30,13 +30,34 @@ for _ in range(20):
     w.img.copy_(w.img_src); w.model(w.ev, w.img, w.mask)
 torch.cuda.synchronize()
 print("forward only: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
-for depth in (2, 3):
+for depth in (2, 3, 2, 3):
+    ts = []
+    for rep_i in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in ev.run(feed(40), depth=depth):
+            pass
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 40 * 1e3)
+    print("run depth %d: %s ms per batch" % (depth, " ".join("%.3f" % t for t in ts)))
+ts = []
+for rep_i in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in ev.run(feed(20), depth=depth):
-        pass
+    for _ in range(30):
+        ev.step(events, w.img_src.clone())
     torch.cuda.synchronize()
-    print("run depth %d: %.3f ms per batch" % (depth, (time.perf_counter() - t0) / 20 * 1e3))
+    ts.append((time.perf_counter() - t0) / 30 * 1e3)
+print("step: %s ms per batch" % " ".join("%.3f" % t for t in ts))
+ts = []
+for rep_i in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        w.img.copy_(w.img_src); w.model(w.ev, w.img, w.mask)
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) / 30 * 1e3)
+print("forward only again: %s ms" % " ".join("%.3f" % t for t in ts))
 # phases of the loop body, by hand (depth 2)
 from collections import deque
 stage = [rep.EventStage(dev), rep.EventStage(dev)]
