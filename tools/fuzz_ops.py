@@ -184,7 +184,7 @@ def lg_case(seed):
     r = np.random.default_rng(seed)
     din = int(r.choice([256, 256, 128]))
     # one case in three: widths other than 256 = 4 x 64 (head_dim = descriptor_dim // num_heads in {32, 64, 128}, lightglue.py:456-461)
-    heads, dh, layers = (4, 64, 9) if r.integers(3) else (int(r.choice([1, 2, 3, 4, 6, 8])), int(r.choice([32, 64, 128])), int(r.integers(1, 5)))
+    heads, dh, layers = (4, 64, 9) if r.integers(3) else (int(r.choice([1, 2, 3, 4, 6, 8])), int(r.choice([32, 64, 128, 16, 48, 80, 100, 20, 124])), int(r.integers(1, 5)))  # (round 6: any multiple of 4 up to 128)
     key = (din, heads, dh, layers)
     if key not in _LG:
         lg = pkg.LightGlue({"input_dim": din, "descriptor_dim": heads * dh, "num_heads": heads, "n_layers": layers}).to(DEV).eval()

@@ -79,7 +79,25 @@ def one_case(seed, families):
         wide = torch.zeros((B, ce, H, W + 3), device=DEV)
         wide[..., :W] = evt
         evt = wide[..., :W]
-    ef, imf, mt = m(evt, t(img.copy()), mt_)
+    img_t = t(img.copy())
+    img_o = img.copy()
+    lay = int(r.integers(6)) if family == "sp" else 0  # round 6: what SuperPointv1 takes beside contiguous gray (superpoint_extractor.py:372-376)
+    if lay in (1, 2, 3):
+        if lay in (1, 2):  # RGB, plain or channels-last memory
+            chans = [img[:, 0], synth.synth_image(seed + 2, B, H, W)[:, 0], synth.synth_image(seed + 3, B, H, W)[:, 0]]
+            img_o = np.ascontiguousarray(np.stack(chans, 1))
+            img_t = t(img_o) if lay == 1 else t(np.ascontiguousarray(np.stack(chans, -1))).permute(0, 3, 1, 2)
+        else:  # a strided view of a wider gray tensor
+            wide_i = torch.zeros((B, 1, H + 2, W + 5), device=DEV)
+            wide_i[:, :, 1:H + 1, 2:W + 2] = img_t
+            img_t = wide_i[:, :, 1:H + 1, 2:W + 2]
+        desc += f" image layout {lay}"
+    ef, imf, mt = m(evt, img_t, mt_)
+    if lay:
+        scaled = img_o / np.float32(255.0)
+        if not np.array_equal(n(img_t), scaled):
+            raise AssertionError(f"{desc}: the caller's image is not left scaled in place like the reference leaves it")
+    img = img_o
     ek, ik = ("vgg", "superpointv1") if family == "sp" else ("vgg_np", "silk")
     kw = dict(top_k=top_k, radius=radius, border=border, det_thr=det_thr, ordering=ordering)
     es, is_ = (float(e.descriptor_scale_factor.detach()) for e in (m.event_extractor.extractor, m.image_extractor.extractor))
@@ -104,6 +122,35 @@ def one_case(seed, families):
         g = n(mt["matches0"][b]).reshape(-1)
         if not np.array_equal(g, np.asarray(e["matches0"]).reshape(-1)):
             raise AssertionError(f"{desc}: matches0[{b}] differs")
+    return desc
+
+
+def fused_case(seed):
+    """Round 6: launches large enough for the image extractor's fused first two layers (conv1ab_kernel: >= 6144 tiles of 8x32): many
+    tiny images per forward, sampled images against per-image oracle runs, bit for bit."""
+    r = np.random.default_rng(seed)
+    H, W = int(r.integers(16, 41)), int(r.integers(16, 65))
+    tiles = -(-(H + 7) // 8) * -(-(W + 7) // 32)
+    B = int(6144 // max(-(-((H + 7) // 8 * 8) // 8) * -(-((W + 7) // 8 * 8) // 32), 1)) + int(r.integers(1, 40))
+    top_k = int(r.choice([5, 40]))
+    desc = f"seed {seed}: fused regime sp B={B} {H}x{W} top_k={top_k}"
+    m, sd = model_for("sp", 5, top_k, 4, 4, 1.0, "yx", seed)
+    ev, mask = synth.synth_events(seed, B, 5, H, W)
+    img = synth.synth_image(seed + 1, B, H, W)
+    ef, imf, mt = m(t(ev), t(img.copy()), t(mask))
+    import ctypes
+    eng = m.image_extractor.extractor.engine()
+    pads = pkg.native.padder_pads(H, W, 8)
+    if not pkg.native.lib().einx_conv_first_two_fused_ok(ctypes.byref(eng.backbone[0].desc), ctypes.byref(eng.backbone[1].desc), B, H + pads[2] + pads[3], W + pads[0] + pads[1]):
+        raise AssertionError(f"{desc}: the launch is not in the fused regime (tiles {tiles})")
+    for b in sorted({0, B - 1, int(r.integers(B)), int(r.integers(B))}):
+        oi = orc.extractor_forward("superpointv1", sub(sd, "image_extractor.extractor."), img[b:b + 1].copy(), None, top_k=top_k)
+        for key in ("score", "logits", "raw_descriptors", "backbone_feats"):
+            if not np.array_equal(n(imf[key][b:b + 1]), oi[key]):
+                raise AssertionError(f"{desc}: image {key}[{b}] differs")
+        for key in ("sparse_positions", "sparse_descriptors"):
+            if not np.array_equal(n(imf[key][b]), oi[key][0]):
+                raise AssertionError(f"{desc}: image {key}[{b}] differs")
     return desc
 
 
@@ -294,7 +341,10 @@ def main():
             if a.harness:
                 harness_case(seed)
             else:
-                (voxel_case if seed % 4 == 0 else (lambda s: modes_case(s, fams)) if seed % 4 == 2 and not a.no_modes else lambda s: one_case(s, fams))(seed)
+                if seed % 16 == 5 and not LARGE and "sp" in fams:
+                    fused_case(seed)
+                else:
+                    (voxel_case if seed % 4 == 0 else (lambda s: modes_case(s, fams)) if seed % 4 == 2 and not a.no_modes else lambda s: one_case(s, fams))(seed)
             ok += 1
         except AssertionError as e:
             bad.append(str(e))
