@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 PR = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def last_json_line(path):
@@ -114,6 +114,22 @@ def main():
             busy[k.split("(")[0].replace("void ", "")] = {"launches": len(v["GRBM_GUI_ACTIVE"]), "mfma_busy_frac": round(b, 4)}
     out["mfma_busy_fraction_per_kernel (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))"] = busy
     json.dump(out, open(os.path.join(PR, f"{R}_pmc_conv1b.json"), "w"), indent=1)
+    # round 6: the image extractor's fused first two layers (conv1ab_kernel) from the same passes
+    kf = [k for k in fetch if "conv1ab_kernel<true" in k]
+    if kf:
+        ff, wf = fetch[kf[0]]["FETCH_SIZE"], write[kf[0]]["WRITE_SIZE"]
+        fo = {"kernel": "conv1ab_kernel<true, 6> (image extractor, layers 1-2 as one launch: 1->64->64 3x3 @264x352 + ReLU + pool, B=32)",
+              "FETCH_SIZE_KB": sum(ff) / len(ff), "WRITE_SIZE_KB": sum(wf) / len(wf), "launches_averaged": len(ff), "fetch_correction": corr}
+        fo["hbm_bytes_per_launch"] = (corr * fo["FETCH_SIZE_KB"] + fo["WRITE_SIZE_KB"]) * 1024
+        fo["algorithmic_bytes_per_launch"] = 32 * (260 * 346 + 64 * 132 * 176) * 4
+        fo["two_launches_it_replaces_bytes"] = out["conv1a_calibration"]["input_bytes"] + 2 * out["conv1a_calibration"]["output_bytes"] + 32 * 64 * 132 * 176 * 4
+        fo["note"] = ("same separate --pmc passes and FETCH_SIZE correction as the conv1b file; the raw image is read through the workgroups' 12x36 "
+                      "halo tiles (re-read by neighbouring tiles out of L2), the first layer's 761 MB output is neither written nor read")
+        for k, v in busy.items():
+            if k.startswith("conv1ab_kernel"):
+                fo["mfma_busy"] = v
+        json.dump(fo, open(os.path.join(PR, f"{R}_pmc_conv1ab.json"), "w"), indent=1)
+        print("pmc fused: hbm bytes/launch", fo["hbm_bytes_per_launch"] / 1e6, "MB")
     write_readme(out, busy)
     print("pmc: hbm bytes/launch", out["hbm_bytes_per_launch"] / 1e6, "MB; busy", {k[:40]: v["mfma_busy_frac"] for k, v in busy.items()})
 
@@ -243,6 +259,25 @@ def write_readme(pmc, busy):
     A("|---|---|---|")
     for k, v in sorted(busy.items(), key=lambda kv: -kv[1]["mfma_busy_frac"]):
         A(f"| `{k}` | {v['launches']} | {v['mfma_busy_frac'] * 100:.1f} % |")
+    fz = rf.get("fused_first_two_layers")
+    if fz:
+        A("")
+        A("## Fused first two layers of the image extractor: `conv1ab_kernel<true, 6>` (round 6)")
+        A("")
+        A(f"* one launch instead of two: {fz['launch_ms']:.3f} ms per launch (mean of {fz['launches_timed']} per-launch HIP-event pairs) against "
+          f"{fz['replaces_ms']['first_layer']:.3f} + {fz['replaces_ms']['second_layer']:.3f} = {fz['replaces_ms']['sum']:.3f} ms for the two launches alone; "
+          f"{fz['flop_per_launch'] / 1e9:.1f} GFLOP (both layers) -> {fz['achieved']:.1f} TFLOP/s = {fz['frac'] * 100:.1f} % of the fp32-MFMA peak.")
+        fk = os.path.join(EV, "prof_kernel_only")
+        for f_ in glob.glob(os.path.join(fk, "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f_)):
+                if "conv1ab_kernel<true" in r["Name"]:
+                    A(f"* `{R}_conv1b_kernel_only_stats.csv` lists the same launches: {r['Calls']} launches, average {float(r['AverageNs']) / 1e6:.3f} ms.")
+        pj = os.path.join(PR, f"{R}_pmc_conv1ab.json")
+        if os.path.exists(pj):
+            pf = json.load(open(pj))
+            A(f"* `{R}_pmc_conv1ab.json`: {pf['fetch_correction']:g} x FETCH_SIZE {pf['FETCH_SIZE_KB'] / 1024:.0f} MiB + WRITE_SIZE {pf['WRITE_SIZE_KB'] / 1024:.0f} MiB = "
+              f"{pf['hbm_bytes_per_launch'] / 1e6:.0f} MB per launch against {pf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (raw image in, pooled "
+              f"second-layer output out); the two launches it replaces moved {pf['two_launches_it_replaces_bytes'] / 1e6:.0f} MB.")
     A("")
     A("## Per-kernel time (single stream, exclusive timings), SP+MNN B=32, 6 steps")
     A("")
