@@ -575,6 +575,7 @@ def fused_first_two_roofline(wl, l0, l1, pads, Hp, Wp, kernel_only=False):
 
     reps = 24
     b2b = hip_time(torch, run, reps, warm=2)
+    kname = L.einx_conv_last_kernel().decode()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     torch.cuda.synchronize()
     for e0, e1 in evs:
@@ -594,7 +595,7 @@ def fused_first_two_roofline(wl, l0, l1, pads, Hp, Wp, kernel_only=False):
     if wl.config == "sp_mnn" and B == 32 and pmcs:
         traffic = json.load(open(pmcs[-1])).get("hbm_bytes_per_launch")
     alg = B * (260 * 346 + l1.cout * Ho * Wo) * 4  # the raw image in, the second layer's output out
-    return {"kernel": L.einx_conv_last_kernel().decode() + f" (1->64->64 3x3 @{Hp}x{Wp}, B={B})", "bound": "mfma", "launch_ms": round(dur * 1e3, 4),
+    return {"kernel": kname + f" (1->64->64 3x3 @{Hp}x{Wp}, B={B})", "bound": "mfma", "launch_ms": round(dur * 1e3, 4),
             "launches_timed": reps, "flop_per_launch": flops, "achieved": round(flops / dur / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flops / dur / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "back_to_back_ms": round(b2b * 1e3, 4),
             "replaces_ms": {"first_layer": round(t0 * 1e3, 4), "second_layer": round(t1 * 1e3, 4), "sum": round((t0 + t1) * 1e3, 4)},
@@ -815,11 +816,12 @@ def harness_leg(pkg, wl, torch, steps=10, events_per_sample=60000):
     for _ in ev.run(feed(3)):
         pass
     torch.cuda.synchronize()
+    run_steps = max(steps, 30)  # a loop: its first batch has nothing to hide its packing and upload under (2 ms over 10 batches = 2 %)
     t0 = time.perf_counter()
-    for _ in ev.run(feed(steps)):
+    for _ in ev.run(feed(run_steps)):
         pass
     torch.cuda.synchronize()
-    sec_run = (time.perf_counter() - t0) / steps
+    sec_run = (time.perf_counter() - t0) / run_steps
     # the representation alone, inputs already on the device (what the two kernels cost inside that step)
     x, y, t, p, offs = rep._pack(events, wl.dev)
     import ctypes
@@ -838,11 +840,12 @@ def harness_leg(pkg, wl, torch, steps=10, events_per_sample=60000):
     res = ev.result()
     streamed = {"config": wl.config, "workload": f"B{B} raw events ({events_per_sample} per sample, host numpy) -> voxel grid + events mask -> "
                 + WORKLOADS[wl.config][2] + " -> MR/MMA/VDD on the device, as a LOOP with 2 batches in flight", "pairs_per_step": B,
-                "value": round(B / sec_run, 2), "unit": "pairs/s", "ms_per_step": round(sec_run * 1e3, 3), "steps": steps,
+                "value": round(B / sec_run, 2), "unit": "pairs/s", "ms_per_step": round(sec_run * 1e3, 3), "steps": run_steps,
                 "h2d_bytes_per_step": int(sum(v.nbytes for e in events for v in e.values())),
                 "note": "SameTimeEvaluator.run: the evaluation loop of test_events-image_same-time.py:130-194 with the next batch's host-side "
-                        "packing (into page-locked memory), its PCIe transfer (side stream) and its kernel launches issued before the host "
-                        "waits for the previous batch's counts; same kernels and results as the step-by-step leg"}
+                        "packing (einx_events_pack into page-locked memory), its PCIe transfer and its two representation kernels (stage stream) and the "
+                        "launches of its forward issued before the host waits for the previous batch's counts; same kernels and results as the "
+                        "step-by-step leg"}
     return streamed, {"config": wl.config, "workload": f"B{B} raw events ({events_per_sample} per sample, host numpy) -> voxel grid + events mask -> "
             + WORKLOADS[wl.config][2] + " -> MR/MMA/VDD on the device", "pairs_per_step": B, "value": round(B / sec, 2), "unit": "pairs/s",
             "ms_per_step": round(sec * 1e3, 3), "steps": steps,
