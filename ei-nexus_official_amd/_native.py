@@ -387,7 +387,7 @@ def lightglue(weights, pb0, pb1, want_la=True, want_ref=False, all_layers=False)
     d = int(weights.d)
     nbytes = L.einx_lg_ws_bytes_heads(B, cap0, cap1, d, int(weights.heads), int(weights.input_dim))
     if not nbytes:
-        raise NotImplementedError("einx LightGlue: descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 128")
+        raise NotImplementedError("einx LightGlue: descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 256")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     r = MatchResult()
     r.matches0 = torch.empty((B, cap0), dtype=torch.int64, device=dev)

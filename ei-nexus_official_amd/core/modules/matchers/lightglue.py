@@ -100,11 +100,11 @@ class LightGlue(nn.Module):
         # widths as the reference derives them (lightglue.py:246-248, 456-461): any num_heads dividing descriptor_dim.  The
         # attention kernel is instantiated for 32-, 64- and 128-wide heads (256 = 4 x 64, every EI-Nexus YAML, runs its own
         # instantiation); other widths run the next larger one on zero-padded heads.  What is left out: head widths that are
-        # not a multiple of 4 (a head's rows are read 16 bytes at a time) or wider than 128.
+        # not a multiple of 4 (a head's rows are read 16 bytes at a time) or wider than 256.
         assert conf.descriptor_dim % conf.num_heads == 0
         hd = conf.descriptor_dim // conf.num_heads
-        if hd % 4 or hd > 128:
-            raise NotImplementedError("einx LightGlue: descriptor_dim // num_heads must be a multiple of 4, at most 128 "
+        if hd % 4 or hd > 256:
+            raise NotImplementedError("einx LightGlue: descriptor_dim // num_heads must be a multiple of 4, at most 256 "
                                       f"(got {conf.descriptor_dim} // {conf.num_heads})")
         if conf.input_dim != conf.descriptor_dim:
             self.input_proj = nn.Linear(conf.input_dim, conf.descriptor_dim, bias=True)

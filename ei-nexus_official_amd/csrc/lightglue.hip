@@ -1104,6 +1104,7 @@ int attn(hipStream_t st, int B, const Dims& dm, const float* Q, const int32_t* n
   else if (dm.dh <= 32) hipLaunchKernelGGL((lg_attn_kernel<32, 0>), grid, dim3(256), 0, st, a);  // (narrower heads: zero padded)
   else if (dm.dh <= 64) hipLaunchKernelGGL((lg_attn_kernel<64, 0>), grid, dim3(256), 0, st, a);
   else if (dm.dh <= 128) hipLaunchKernelGGL((lg_attn_kernel<128, 0>), grid, dim3(256), 0, st, a);
+  else if (dm.dh <= 256) hipLaunchKernelGGL((lg_attn_kernel<256, 0>), grid, dim3(256), 0, st, a);
   else return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1165,13 +1166,13 @@ EINX_EXPORT int einx_normalize_keypoints(const float* kpts, int rows, int cols, 
 namespace {
 // lightglue.py:456-461: head_dim = descriptor_dim // num_heads.  The attention kernel is instantiated for 32-, 64- and 128-wide
 // heads; other widths run the next larger one on zero-padded heads (round 6).  Multiples of 4 (16-byte rows of a head; the
-// rotary encoding needs an even width anyway) up to 128.
+// rotary encoding needs an even width anyway) up to 256 (<256, 0>: 256 + 100 registers, one workgroup per SIMD -- rare widths, not tuned).
 bool dims_of(int d, int heads, Dims& dm) {
   if (d <= 0 || heads <= 0 || d % heads != 0) return false;
   dm.d = d;
   dm.heads = heads;
   dm.dh = d / heads;
-  return dm.dh % 4 == 0 && dm.dh <= 128;
+  return dm.dh % 4 == 0 && dm.dh <= 256;
 }
 }  // namespace
 
@@ -1192,7 +1193,7 @@ EINX_EXPORT int einx_lightglue(const einx_lg_weights* w, const float* kpts0, con
                                float* ref0, float* ref1, int ref_layers, void* stream) {
   EINX_CHECK_ARG(w && kpts0 && desc0 && n && kpts1 && desc1 && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
   Dims dm;
-  EINX_CHECK_ARG(dims_of(w->d, w->heads, dm), "descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 128");
+  EINX_CHECK_ARG(dims_of(w->d, w->heads, dm), "descriptor_dim must be num_heads x head_dim with head_dim a multiple of 4, at most 256");
   const int D = dm.d;  // (shadows the file-level constant: every width below is the model's)
   EINX_CHECK_ARG(w->struct_size == sizeof(einx_lg_weights) && w->layer_size == sizeof(einx_lg_layer),
                  "einx_lg_weights::struct_size / layer_size do not match this library (header / library ABI mismatch)");

@@ -297,8 +297,8 @@ typedef struct einx_lg_weights {
  * LightGlue call returns matched keypoints in these coordinates (lightglue.py:677-687). */
 int einx_normalize_keypoints(const float* kpts, int rows, int cols, float h, float w, float* out, int out_cols, void* stream);
 
-/* Model widths (lightglue.py:456-461): d = descriptor_dim = heads x head_dim, head_dim any multiple of 4 up to 128 (the attention
- * kernel is instantiated for 32 / 64 / 128; other widths run the next larger one on zero-padded heads; anything else is refused);
+/* Model widths (lightglue.py:456-461): d = descriptor_dim = heads x head_dim, head_dim any multiple of 4 up to 256 (the attention
+ * kernel is instantiated for 32 / 64 / 128 / 256; other widths run the next larger one on zero-padded heads; anything else is refused);
  * Wr is [head_dim/2, 2].  d = 256 with 4 heads of 64 -- every EI-Nexus configuration -- runs kernels instantiated for those widths.
  * einx_lg_ws_bytes assumes 64-wide heads (heads = d / 64); 0 = unsupported widths. */
 size_t einx_lg_ws_bytes(int B, int cap0, int cap1, int d, int input_dim);

@@ -1351,6 +1351,8 @@ LGCFG_CASES = [
     dict(name="h4_d64", seed=168, n=130, m=170, input_dim=128, descriptor_dim=64, num_heads=4, n_layers=3, wseed=22, shared=60),     # 4 x 16
     dict(name="h3_d240", seed=169, n=150, m=200, input_dim=240, descriptor_dim=240, num_heads=3, n_layers=2, wseed=23, shared=70),   # 3 x 80, d % 32 != 0
     dict(name="h2_d200", seed=170, n=140, m=120, input_dim=200, descriptor_dim=200, num_heads=2, n_layers=2, wseed=24, shared=50),   # 2 x 100
+    dict(name="h1_d256", seed=171, n=120, m=150, input_dim=256, descriptor_dim=256, num_heads=1, n_layers=2, wseed=25, shared=60),   # 1 x 256 (the widest head the kernels take)
+    dict(name="h2_d384", seed=172, n=100, m=90, input_dim=128, descriptor_dim=384, num_heads=2, n_layers=2, wseed=26, shared=40),    # 2 x 192 through input_proj
 ]
 
 

@@ -272,7 +272,7 @@ def test_pooled_padding0_constructs_and_raises_what_the_reference_raises():
 def test_lightglue_other_widths_have_the_references_parameter_tree():
     """descriptor_dim / num_heads / n_layers / input_dim from the conf (lightglue.py:446-466): names and shapes of every
     parameter equal the reference's (tests/golden/lgcfg.npz); add_scale_ori widens posenc.Wr to 4 inputs; head widths that are
-    not a multiple of 4 or exceed 128 are refused at construction."""
+    not a multiple of 4 or exceed 256 are refused at construction."""
     from helpers import Golden
     g = Golden("lgcfg")
     for name, c in g.cases.items():
@@ -282,8 +282,8 @@ def test_lightglue_other_widths_have_the_references_parameter_tree():
     aso = pkg.LightGlue({"input_dim": 256, "add_scale_ori": True})
     assert {k: list(v.shape) for k, v in aso.state_dict().items() if k.startswith("posenc")} == g.meta["add_scale_ori"]["state_keys"]
     pkg.LightGlue({"descriptor_dim": 256, "num_heads": 16})  # 16-wide heads: accepted since round 6 (zero-padded to 32 in the attention)
-    for conf in ({"descriptor_dim": 60, "num_heads": 2, "input_dim": 60}, {"descriptor_dim": 512, "num_heads": 2, "input_dim": 512}):
-        with pytest.raises(NotImplementedError):  # head widths that are not a multiple of 4, or wider than 128
+    for conf in ({"descriptor_dim": 60, "num_heads": 2, "input_dim": 60}, {"descriptor_dim": 1024, "num_heads": 2, "input_dim": 1024}):
+        with pytest.raises(NotImplementedError):  # head widths that are not a multiple of 4, or wider than 256
             pkg.LightGlue(conf)
     with pytest.raises(AssertionError):
         pkg.LightGlue({"descriptor_dim": 256, "num_heads": 3})

@@ -374,13 +374,13 @@ def test_add_scale_ori_fails_like_the_reference():
 
 
 def test_unsupported_head_width_is_refused_loudly():
-    for conf in ({"input_dim": 60, "descriptor_dim": 60, "num_heads": 2}, {"input_dim": 512, "descriptor_dim": 512, "num_heads": 2}):
-        with pytest.raises(NotImplementedError):  # head widths that are not a multiple of 4 / wider than 128 (16-wide heads run since round 6)
+    for conf in ({"input_dim": 60, "descriptor_dim": 60, "num_heads": 2}, {"input_dim": 1024, "descriptor_dim": 1024, "num_heads": 2}):
+        with pytest.raises(NotImplementedError):  # head widths that are not a multiple of 4 / wider than 256 (16-wide heads run since round 6)
             pkg.LightGlue(conf)
     with pytest.raises(AssertionError):
         pkg.LightGlue({"input_dim": 256, "descriptor_dim": 256, "num_heads": 3})  # the reference's own assert (:247)
     L = import_module(pkg.__name__ + "._native").lib()
-    assert L.einx_lg_ws_bytes_heads(1, 64, 64, 60, 2, 60) == 0 and L.einx_lg_ws_bytes_heads(1, 64, 64, 512, 2, 512) == 0
+    assert L.einx_lg_ws_bytes_heads(1, 64, 64, 60, 2, 60) == 0 and L.einx_lg_ws_bytes_heads(1, 64, 64, 1024, 2, 1024) == 0
     assert L.einx_lg_ws_bytes_heads(1, 64, 64, 256, 16, 256) > 0
     assert L.einx_lg_ws_bytes_heads(1, 64, 64, 256, 4, 256) == L.einx_lg_ws_bytes(1, 64, 64, 256, 256) > 0
     assert L.einx_lg_ws_bytes_heads(1, 64, 64, 256, 8, 256) < L.einx_lg_ws_bytes(1, 64, 64, 256, 256)  # narrower rotary table
