@@ -492,7 +492,7 @@ def layer_table(wl):
     pads = pkg.native.padder_pads(260, 346, ext.cell_size)
     Hp, Wp = 260 + pads[2] + pads[3], 346 + pads[0] + pads[1]
     L = pkg.native.lib()
-    if L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp):
+    if L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp) == 1:
         Ho, Wo = (Hp // 2, Wp // 2) if l1.pool else (Hp, Wp)
         out = torch.empty((B, l1.cout, Ho, Wo), dtype=torch.float32, device=wl.dev)
         P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
@@ -561,7 +561,7 @@ def fused_first_two_roofline(wl, l0, l1, pads, Hp, Wp, kernel_only=False):
     import ctypes
     torch, pkg, B = wl.torch, wl.pkg, wl.B
     L = pkg.native.lib()
-    if not L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp):
+    if L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp) != 1:
         return None
     Ho, Wo = (Hp // 2, Wp // 2) if l1.pool else (Hp, Wp)
     out = torch.empty((B, l1.cout, Ho, Wo), dtype=torch.float32, device=wl.dev)

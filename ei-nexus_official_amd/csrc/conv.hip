@@ -471,7 +471,10 @@ struct Conv1abArgs {
   int relu0, cout0pad;
 };
 
-template <bool POOL, int WPS>
+// CIN0: input channels of the first layer (1: SuperPointv1's gray image; 5: the event voxel grid of BASELINE.json's bench shape).
+// K of the first layer = its 9 CIN0 real products in the oracle's order (channel pair, tap, parity; the zero slots of an odd
+// channel count are no-ops of the chain and are left out), padded to a multiple of four.
+template <int CIN0, bool POOL, int WPS>
 __global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa) {
   const ConvArgs& a = fa.c;
   constexpr int KS = 3, TH = 8, TW = 32, WN = 4, MT = 1, NT = 2, CK = 8;
@@ -488,10 +491,15 @@ __global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa)
   constexpr int RH = PH + 2, RP = PW + 2;  // raw tile: halo 2 (12 x 36)
   constexpr int NT16 = (PLANE + 15) / 16;  // 22 N-tiles of 16 halo positions
   constexpr int SLOTS = (NT16 + 7) / 8;    // N-tiles per wave (3)
+  constexpr int RAWP = RH * RP;            // raw-tile floats per input channel (432)
+  constexpr int NK = TAPS * CIN0;          // real products of a first-layer output
+  constexpr int NI = (NK + 3) / 4;         // 16x16x4 instructions per N-tile (1 channel: 3; 5 channels: 12)
+  static_assert(NI <= 4 || NI % 4 == 0, "operands are requested four instructions at a time");
   __shared__ __attribute__((aligned(16))) float in_tile[IN_LDS];
   __shared__ __attribute__((aligned(16))) float w_tile[W_ROWS * kCoutTile];
-  __shared__ __attribute__((aligned(16))) float raw[RH * RP];
-  __shared__ __attribute__((aligned(16))) float w0s[12 * 64], c0s[3 * 64];  // first layer: weights [k][channel], bias | scale | shift
+  __shared__ __attribute__((aligned(16))) float raw[CIN0 * RAWP];
+  __shared__ __attribute__((aligned(16))) float w0s[NI * 4 * PAIR], c0s[3 * 64];  // first layer: weights [k][16 channels of the current pair], bias | scale | shift
+  __shared__ int kofs[NI * 4];             // raw-tile offset of product k (its channel plane + tap shift); padding ks: 0
   __shared__ __attribute__((aligned(16))) float s_bias[kCoutTile], s_scale[kCoutTile], s_shift[kCoutTile];
 
   const int tid = threadIdx.x;
@@ -514,18 +522,35 @@ __global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa)
     s_shift[tid] = (cv && a.scale) ? a.shift[co] : 0.0f;
   }
   const int y0 = ty_i * TH, x0 = tx_i * TW;
-  // ---- raw input tile (one channel): logical (y, x) inside [0,H) x [0,W) = source clamped (replicate fold), outside = 0
-  if (tid < RH * RP) {
-    const int ry = tid / RP, rx = tid % RP;
+  // ---- raw input tile (CIN0 channels): logical (y, x) inside [0,H) x [0,W) = source clamped (replicate fold), outside = 0
+  for (int i = tid; i < CIN0 * RAWP; i += NTHR) {
+    const int ci = i / RAWP, r_ = i % RAWP;
+    const int ry = r_ / RP, rx = r_ % RP;
     const int y = y0 - 2 + ry, x = x0 - 2 + rx;
     float v = 0.0f;
     if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
       int sy = y - a.h0, sx = x - a.w0;
       sy = sy < 0 ? 0 : (sy > a.Hs - 1 ? a.Hs - 1 : sy);
       sx = sx < 0 ? 0 : (sx > a.Ws - 1 ? a.Ws - 1 : sx);
-      v = a.in[(size_t)b * a.Hs * a.Ws + (size_t)sy * a.Ws + sx];
+      v = a.in[((size_t)b * CIN0 + ci) * a.Hs * a.Ws + (size_t)sy * a.Ws + sx];
     }
-    raw[tid] = v;
+    raw[i] = v;
+  }
+  // product k of a first-layer output, in the oracle's order (channel pair, tap, parity) without the zero slots -> (channel, tap)
+  auto k_to_ci_tap = [](int k, int* ci, int* tap) {
+    constexpr int FULL = (CIN0 / 2) * 2 * TAPS;  // products of the complete channel pairs
+    if (k < FULL) {
+      *ci = 2 * (k / (2 * TAPS)) + (k & 1);
+      *tap = (k % (2 * TAPS)) >> 1;
+    } else {  // the last, single channel of an odd count
+      *ci = CIN0 - 1;
+      *tap = k - FULL;
+    }
+  };
+  if (tid < NI * 4) {
+    int ci, tap;
+    k_to_ci_tap(tid < NK ? tid : 0, &ci, &tap);
+    kofs[tid] = tid < NK ? ci * RAWP + (tap / 3) * RP + tap % 3 : 0;
   }
   // halo positions outside the image: zero in all 16 planes, once (never written again)
   if (tid < PLANE) {
@@ -552,23 +577,29 @@ __global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa)
     const int r = f / (kCoutTile / 4), c4 = f % (kCoutTile / 4);
     woff[i] = (unsigned)((f < W_F4 ? r : 0) * a.CoutPad + co0 + c4 * 4) * 4u;
   }
-  // ---- first layer on the matrix cores: this wave's N-tiles (16 halo positions each).  Its weights (12 K rows x 64 channels,
-  // rows past the ninth tap zero) and epilogue constants sit in LDS: nothing of it is held in registers across the second
-  // layer's chunks (the kernel has 80 registers for three workgroups per CU).
-  for (int i = tid; i < 12 * C0; i += NTHR) {
-    const int k = i / C0, c = i % C0;
-    w0s[i] = k < TAPS ? fa.w0[(size_t)(2 * k) * fa.cout0pad + c] : 0.0f;
-  }
+  // ---- first layer on the matrix cores: this wave's N-tiles (16 halo positions each).  Its weights (the current pair's 16
+  // channels, NI x 4 K rows, rows past the last product zero) and epilogue constants sit in LDS: nothing of it is held in
+  // registers across the second layer's chunks (the kernel has 80 registers for three workgroups per CU).
+  auto load_w0s = [&](int cp) {  // K rows of first-layer channels 16 cp .. 16 cp + 15 (read by the NEXT first_layer_pair, two barriers later)
+    for (int i = tid; i < NI * 4 * PAIR; i += NTHR) {
+      const int k = i / PAIR, c = i % PAIR;
+      int ci, tap;
+      k_to_ci_tap(k < NK ? k : 0, &ci, &tap);
+      const int row = (ci >> 1) * 2 * TAPS + tap * 2 + (ci & 1);  // the native weight image's K order
+      w0s[i] = k < NK ? fa.w0[(size_t)row * fa.cout0pad + PAIR * cp + c] : 0.0f;
+    }
+  };
+  load_w0s(0);
   if (tid < C0) {
     c0s[tid] = fa.bias0 ? fa.bias0[tid] : 0.0f;
     c0s[C0 + tid] = fa.scale0 ? fa.scale0[tid] : 1.0f;
     c0s[2 * C0 + tid] = fa.scale0 ? fa.shift0[tid] : 0.0f;
   }
   const int q16 = lane >> 4, n16 = lane & 15;
-  int rawBase[SLOTS];                           // raw-tile offset of the 3x3 patch of slot s's position
+  int rawBase[SLOTS];                                 // raw-tile offset of the 3x3 patch of slot s's position (channel 0)
   const int wr0 = 4 * q16 * PLANE + 16 * wave + n16;  // LDS offset of slot 0's position in channel 4 q16 of the pair; slot s: + 128 s
-  const int aBase0 = q16 * C0 + n16;            // A: k = 4 g + q16 -> + 256 g; channels of pair cp -> + 16 cp
-  unsigned live = 0;                            // bit s: slot s holds a position inside the image (its outputs are written)
+  const int aBase0 = q16 * PAIR + n16;                // A: k = 4 g + q16 -> + 64 g
+  unsigned live = 0;                                  // bit s: slot s holds a position inside the image (its outputs are written)
 #pragma unroll
   for (int s_ = 0; s_ < SLOTS; ++s_) {
     const int t = wave + 8 * s_;
@@ -580,24 +611,28 @@ __global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa)
     const int y = y0 - 1 + py, x = x0 - 1 + px;
     if (pv && y >= 0 && y < a.H && x >= 0 && x < a.W) live |= 1u << s_;
   }
-  int kOff[3];  // raw-tile offset of tap k = 4 g + q16 (taps past the ninth read a valid address; their A rows are zero)
-#pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const int k = 4 * g + q16;
-    kOff[g] = k < TAPS ? (k / 3) * RP + k % 3 : 0;
-  }
   typedef float f32x4v_ __attribute__((ext_vector_type(4)));
   auto first_layer_pair = [&](int cp) {  // first-layer channels 16 cp .. 16 cp + 15 on the 340 halo positions -> in_tile
-    float fA[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) fA[g] = w0s[aBase0 + 256 * g + PAIR * cp];
     const float* cst = c0s + PAIR * cp + 4 * q16;  // this lane's four channels: bias at +i, scale at +64 + i, shift at +128 + i
 #pragma unroll
     for (int s_ = 0; s_ < SLOTS; ++s_) {
       if (wave + 8 * s_ >= NT16) break;  // wave-uniform
       f32x4v_ c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      constexpr int GRP = NI < 4 ? NI : 4;  // instructions whose operands are requested together (register budget)
 #pragma unroll
-      for (int g = 0; g < 3; ++g) c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[g], raw[rawBase[s_] + kOff[g]], c4, 0, 0, 0);
+      for (int g0 = 0; g0 < NI; g0 += GRP) {
+        float fA[GRP], fB[GRP];
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+          fA[g] = w0s[aBase0 + 64 * (g0 + g)];
+          fB[g] = raw[rawBase[s_] + kofs[4 * (g0 + g) + q16]];
+        }
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[g], fB[g], c4, 0, 0, 0);
+        if (NI > 4) __builtin_amdgcn_sched_barrier(0);
+      }
+      // (interleaving the wave's three N-tiles as independent chains measured the same on the image side and does not rescue the
+      // 5-channel form: profiles/r06_notes.md 2)
       if ((live >> s_) & 1u) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -664,6 +699,7 @@ __global__ __launch_bounds__(512, WPS) void conv1ab_kernel(const Conv1abArgs fa)
     commit_w();
     __syncthreads();
     issue_w(2 * cp + 1);
+    if (cp + 1 < NPAIRS) load_w0s(cp + 1);  // read after the next round's first barrier
     mfma_chunk(0);
     __syncthreads();
     commit_w();
@@ -1103,12 +1139,15 @@ EINX_EXPORT int einx_bn_fold(const float* gamma, const float* beta, const float*
 // caller runs the two layers one after the other
 EINX_EXPORT int einx_conv_first_two_fused_ok(const einx_conv_desc* d0, const einx_conv_desc* d1, int B, int H, int W) {
   if (!d0 || !d1) return 0;
-  const bool shapes = d0->cin == 1 && d0->cout == 64 && d0->ks == 3 && !d0->pool && d1->cin == 64 && d1->cout == 64 && d1->ks == 3;
+  // 1: the dispatcher's choice (1-channel first layers: +1 % on the step).  2: covered by the kernel, but slower than the two launches
+  // (5 input channels: 12 instead of 3 first-layer instructions per N-tile, 8.34 -> 8.62 ms per step; kept callable and tested).
+  const bool shapes = (d0->cin == 1 || d0->cin == 5) && d0->cout == 64 && d0->ks == 3 && !d0->pool && d1->cin == 64 && d1->cout == 64 && d1->ks == 3;
   if (!shapes || (d1->pool && ((H & 1) || (W & 1)))) return 0;
   // the large-grid regime of conv_block_kernel's three-per-CU instantiation (what the fused kernel replaces); smaller launches keep
   // the two latency-tuned launches
   const long grid = (long)einx_cdiv(W, 32) * einx_cdiv(H, 8) * B;
-  return grid >= 8L * 768 ? 1 : 0;
+  if (grid < 8L * 768) return 0;
+  return d0->cin == 1 ? 1 : 2;
 }
 
 EINX_EXPORT int einx_conv_first_two_fused(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d0,
@@ -1116,7 +1155,7 @@ EINX_EXPORT int einx_conv_first_two_fused(const float* in, int B, int Hs, int Ws
   EINX_CHECK_ARG(in && out && d0 && d1 && d0->w_native && d1->w_native, "null pointer");
   EINX_CHECK_ARG(einx_conv_first_two_fused_ok(d0, d1, B, H, W), "layers / launch size outside what the fused first-two-layers kernel covers");
   EINX_CHECK_ARG((d0->scale == nullptr) == (d0->shift == nullptr) && (d1->scale == nullptr) == (d1->shift == nullptr), "scale and shift go together");
-  EINX_CHECK_ARG((size_t)Hs * Ws < (1u << 30) && (size_t)64 * H * W < (1u << 30), "image too large");
+  EINX_CHECK_ARG((size_t)d0->cin * Hs * Ws < (1u << 30) && (size_t)64 * H * W < (1u << 30), "image too large");
   Conv1abArgs fa;
   ConvArgs& a = fa.c;
   a.in = in;
@@ -1146,10 +1185,17 @@ EINX_EXPORT int einx_conv_first_two_fused(const float* in, int B, int Hs, int Ws
   fa.cout0pad = 64;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(a.tilesX * a.tilesY * B), 1);
-  g_last_conv_kernel = d1->pool ? "conv1ab_kernel<true> (first two layers fused, 3 per CU)" : "conv1ab_kernel<false> (first two layers fused, 3 per CU)";
+  static thread_local char nm[96];
+  snprintf(nm, sizeof nm, "conv1ab_kernel<%d,%s> (first two layers fused, 3 per CU)", d0->cin, d1->pool ? "true" : "false");
+  g_last_conv_kernel = nm;
   EINX_PROF("conv1ab_kernel (first two layers)", s);
-  if (d1->pool) hipLaunchKernelGGL((conv1ab_kernel<true, 6>), grid, dim3(512), 0, s, fa);
-  else hipLaunchKernelGGL((conv1ab_kernel<false, 6>), grid, dim3(512), 0, s, fa);
+  if (d0->cin == 1) {
+    if (d1->pool) hipLaunchKernelGGL((conv1ab_kernel<1, true, 6>), grid, dim3(512), 0, s, fa);
+    else hipLaunchKernelGGL((conv1ab_kernel<1, false, 6>), grid, dim3(512), 0, s, fa);
+  } else {
+    if (d1->pool) hipLaunchKernelGGL((conv1ab_kernel<5, true, 6>), grid, dim3(512), 0, s, fa);
+    else hipLaunchKernelGGL((conv1ab_kernel<5, false, 6>), grid, dim3(512), 0, s, fa);
+  }
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

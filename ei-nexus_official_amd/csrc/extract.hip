@@ -14,6 +14,7 @@
 // The op-level entry points (einx_conv_block, einx_score_map, ...) stay exported for the unit tests; this file
 // only sequences them, so a handle-level forward is bit-identical to the op-by-op forward.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <map>
@@ -371,7 +372,7 @@ EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uin
   const int nb = (int)e->backbone.size();
   int first = 0;
   // the first two layers of a 1-channel network as one launch (large launches only: einx_conv_first_two_fused_ok)
-  if (nb >= 2 && einx_conv_first_two_fused_ok(&e->backbone[0], &e->backbone[1], B, pl.Hp, pl.Wp)) {
+  if (nb >= 2 && 1 == einx_conv_first_two_fused_ok(&e->backbone[0], &e->backbone[1], B, pl.Hp, pl.Wp)) {
     float* out = (2 < nb) ? buf[1] : o->feats;
     if ((rc = einx_conv_first_two_fused(in, B, H, W, pl.h0, pl.w0, pl.Hp, pl.Wp, &e->backbone[0], &e->backbone[1], out, stream))) return rc;
     if (e->backbone[1].pool) {

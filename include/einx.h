@@ -112,12 +112,14 @@ typedef struct einx_conv_desc {
 int einx_conv_block(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d, float* out,
                     void* stream);
 
-/* The first two layers of a 1-channel network as ONE launch (round 6): SuperPointv1's conv1a (1 -> 64, 3x3, ReLU) and conv1b
+/* The first two layers of a network with a thin first layer as ONE launch (round 6): SuperPointv1's conv1a (1 -> 64, 3x3, ReLU) and conv1b
  * (64 -> 64, 3x3, ReLU, MaxPool 2x2), superpoint_extractor.py:388-390 -- the first layer's output (761 MB at B = 32) is
  * recomputed per tile on the matrix cores and never touches HBM.  Bit-identical to einx_conv_block(d0) followed by
  * einx_conv_block(d1).  in / Hs / Ws / h0 / w0 / H / W: as einx_conv_block for the FIRST layer; out: the second layer's output.
- * einx_conv_first_two_fused_ok: 1 when the pair of layers and the launch size are what the kernel covers (64-channel 3x3
- * layers on one input channel, a launch of at least eight rounds of workgroups); otherwise run the two layers one by one. */
+ * einx_conv_first_two_fused_ok: 1 when the pair of layers and the launch size are what the kernel covers AND the one launch is the
+ * faster form (64-channel 3x3 layers on ONE input channel, a launch of at least eight rounds of workgroups) -- what einx_extract
+ * uses; 2 when the kernel covers the pair but the two launches are faster (5 input channels: the event voxel grid of the bench shape;
+ * einx_conv_first_two_fused still takes it); 0 otherwise: run the two layers one by one. */
 int einx_conv_first_two_fused_ok(const einx_conv_desc* d0, const einx_conv_desc* d1, int B, int H, int W);
 int einx_conv_first_two_fused(const float* in, int B, int Hs, int Ws, int h0, int w0, int H, int W, const einx_conv_desc* d0,
                               const einx_conv_desc* d1, float* out, void* stream);

@@ -69,15 +69,20 @@ def test_conv_block_three_per_cu_instantiation_bit_exact(oracle, pool):
 @pytest.mark.parametrize("case", [dict(B=18, H=260, W=346, fold=(2, 3, 264, 352), pool=True, bn0=False, relu1=True),   # SuperPointv1 at 346x260 (replicate fold)
                                   dict(B=640, H=40, W=48, fold=None, pool=True, bn0=True, relu1=True),               # small maps, BatchNorm after the first layer
                                   dict(B=420, H=37, W=77, fold=(1, 1, 40, 80), pool=False, bn0=True, relu1=False),   # un-pooled second layer, partial tiles
-                                  dict(B=1100, H=24, W=40, fold=None, pool=True, bn0=False, relu1=True)],
-                         ids=["sp_346x260", "small_bn", "unpooled_partial", "tiny"])
+                                  dict(B=1100, H=24, W=40, fold=None, pool=True, bn0=False, relu1=True),
+                                  dict(B=18, H=260, W=346, fold=(2, 3, 264, 352), pool=True, bn0=True, relu1=True, cin=5, bn1=True),  # VGGExtractor, 5 event bins
+                                  dict(B=420, H=37, W=77, fold=(1, 1, 40, 80), pool=False, bn0=True, relu1=True, cin=5, bn1=True),
+                                  dict(B=1100, H=24, W=40, fold=None, pool=True, bn0=False, relu1=False, cin=5, bn1=False)],
+                         ids=["sp_346x260", "small_bn", "unpooled_partial", "tiny", "vgg5_346x260", "vgg5_unpooled_partial", "vgg5_tiny"])
 def test_first_two_layers_fused_bit_exact(oracle, case):
-    """Round 6: conv1a (1 -> 64) recomputed inside conv1b's launch on the matrix cores (conv1ab_kernel): the output of the second
-    layer is bit-equal to the two launches it replaces (every image) and to the oracle's two conv blocks (sampled images)."""
+    """Round 6: the thin first layer (1 -> 64: SuperPointv1; 5 -> 64: the event extractor at BASELINE's 5 bins) recomputed inside the
+    second layer's launch on the matrix cores (conv1ab_kernel<CIN0>): the output of the second layer is bit-equal to the two launches
+    it replaces (every image) and to the oracle's two conv blocks (sampled images)."""
     import ctypes
     B, H, W, fold = case["B"], case["H"], case["W"], case["fold"]
-    x = synth.normalish(91, (B, 1, H, W))
-    w0 = synth.synth_param("a.weight", (64, 1, 3, 3), 92)
+    cin = case.get("cin", 1)
+    x = synth.normalish(91, (B, cin, H, W))
+    w0 = synth.synth_param("a.weight", (64, cin, 3, 3), 92)
     b0 = synth.uniform(93, (64,), -0.5, 0.5)
     w1 = synth.synth_param("b.weight", (64, 64, 3, 3), 94)
     b1 = synth.uniform(95, (64,), -0.5, 0.5)
@@ -89,12 +94,20 @@ def test_first_two_layers_fused_bit_exact(oracle, case):
         s0, t0 = oracle.bn_fold(g, be, mu, var)
         bn0 = (_t(g), _t(be), _t(mu), _t(var), 1e-5)
     l0 = pkg.native.ConvLayer(_t(w0), _t(b0), bn0, relu=True, pool=False)
-    l1 = pkg.native.ConvLayer(_t(w1), _t(b1), None, relu=case["relu1"], pool=case["pool"])
+    bn1 = s1 = t1 = None
+    if case.get("bn1"):
+        g1, be1 = synth.uniform(196, (64,), 0.5, 1.5), synth.uniform(197, (64,), -0.3, 0.3)
+        mu1, var1 = synth.uniform(198, (64,), -0.3, 0.3), synth.uniform(199, (64,), 0.5, 1.5)
+        g1[9] = -g1[9]
+        s1, t1 = oracle.bn_fold(g1, be1, mu1, var1)
+        bn1 = (_t(g1), _t(be1), _t(mu1), _t(var1), 1e-5)
+    l1 = pkg.native.ConvLayer(_t(w1), _t(b1), bn1, relu=case["relu1"], pool=case["pool"])
     xt = _t(x)
     Hp, Wp = (fold[2], fold[3]) if fold else (H, W)
     h0, w0_ = (fold[0], fold[1]) if fold else (0, 0)
     L = pkg.native.lib()
-    assert L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp) == 1
+    # 1: the dispatcher fuses (one input channel); 2: covered and bit-exact but slower than two launches (five channels), never dispatched
+    assert L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), B, Hp, Wp) == (1 if cin == 1 else 2)
     assert L.einx_conv_first_two_fused_ok(ctypes.byref(l0.desc), ctypes.byref(l1.desc), 1, Hp, Wp) == 0  # small launches keep the two layers
     seq = l1(l0(xt, fold=(h0, w0_, Hp, Wp) if fold else None))
     Ho, Wo = (Hp // 2, Wp // 2) if case["pool"] else (Hp, Wp)
@@ -111,7 +124,7 @@ def test_first_two_layers_fused_bit_exact(oracle, case):
             pads = (w0_, Wp - W - w0_, h0, Hp - H - h0)
             xb = oracle.pad_replicate(xb, pads)
         mid = oracle.conv_block(xb, w0, b0, s0, t0, relu=True, pool=False)
-        exp = oracle.conv_block(mid, w1, b1, None, None, relu=case["relu1"], pool=case["pool"])
+        exp = oracle.conv_block(mid, w1, b1, s1, t1, relu=case["relu1"], pool=case["pool"])
         assert np.array_equal(_np(got[b:b + 1]), exp), b
 
 

@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: conv1a recomputed inside conv1b's launch (conv1ab_kernel) against the two launches; same box, alternating
+# round 6: first layer recomputed inside the second layer's launch (conv1ab_kernel) against the two launches; same box, alternating
+# EINX_FUSE01_CIN: comma list of first-layer channel counts the dispatcher may fuse ("" = none), experiment switch of this script's build
 O=gpurun_out/r6_fuse01; mkdir -p $O
 python -m pytest tests/test_conv_gpu.py -q -x -k "fused" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
 grep -q "passed" $O/pytest.txt || exit 1
@@ -8,10 +9,11 @@ run() { n=$1; shift
   python - "$O/$n.json" "$n" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[2], d["value"], d["ms_per_step"], d["roofline"]["kernel"][:40], d["roofline"]["launch_ms"])
+print(sys.argv[2], d["value"], d["ms_per_step"])
 PY
 }
-run two EINX_FUSE01=0
-run fused EINX_FUSE01=1
-run two2 EINX_FUSE01=0
-run fused2 EINX_FUSE01=1
+run image_only EINX_FUSE01_CIN=1
+run both EINX_FUSE01_CIN=1,5
+run image_only2 EINX_FUSE01_CIN=1
+run both2 EINX_FUSE01_CIN=1,5
+run none EINX_FUSE01_CIN=0

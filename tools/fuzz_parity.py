@@ -141,7 +141,7 @@ def fused_case(seed):
     import ctypes
     eng = m.image_extractor.extractor.engine()
     pads = pkg.native.padder_pads(H, W, 8)
-    if not pkg.native.lib().einx_conv_first_two_fused_ok(ctypes.byref(eng.backbone[0].desc), ctypes.byref(eng.backbone[1].desc), B, H + pads[2] + pads[3], W + pads[0] + pads[1]):
+    if pkg.native.lib().einx_conv_first_two_fused_ok(ctypes.byref(eng.backbone[0].desc), ctypes.byref(eng.backbone[1].desc), B, H + pads[2] + pads[3], W + pads[0] + pads[1]) != 1:
         raise AssertionError(f"{desc}: the launch is not in the fused regime (tiles {tiles})")
     for b in sorted({0, B - 1, int(r.integers(B)), int(r.integers(B))}):
         oi = orc.extractor_forward("superpointv1", sub(sd, "image_extractor.extractor."), img[b:b + 1].copy(), None, top_k=top_k)
