@@ -115,10 +115,10 @@ def main():
     out["mfma_busy_fraction_per_kernel (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))"] = busy
     json.dump(out, open(os.path.join(PR, f"{R}_pmc_conv1b.json"), "w"), indent=1)
     # round 6: the image extractor's fused first two layers (conv1ab_kernel) from the same passes
-    kf = [k for k in fetch if "conv1ab_kernel<true" in k]
+    kf = [k for k in fetch if "conv1ab_kernel<1, true" in k]
     if kf:
         ff, wf = fetch[kf[0]]["FETCH_SIZE"], write[kf[0]]["WRITE_SIZE"]
-        fo = {"kernel": "conv1ab_kernel<true, 6> (image extractor, layers 1-2 as one launch: 1->64->64 3x3 @264x352 + ReLU + pool, B=32)",
+        fo = {"kernel": "conv1ab_kernel<1, true, 6> (image extractor, layers 1-2 as one launch: 1->64->64 3x3 @264x352 + ReLU + pool, B=32)",
               "FETCH_SIZE_KB": sum(ff) / len(ff), "WRITE_SIZE_KB": sum(wf) / len(wf), "launches_averaged": len(ff), "fetch_correction": corr}
         fo["hbm_bytes_per_launch"] = (corr * fo["FETCH_SIZE_KB"] + fo["WRITE_SIZE_KB"]) * 1024
         fo["algorithmic_bytes_per_launch"] = 32 * (260 * 346 + 64 * 132 * 176) * 4
@@ -262,7 +262,7 @@ def write_readme(pmc, busy):
     fz = rf.get("fused_first_two_layers")
     if fz:
         A("")
-        A("## Fused first two layers of the image extractor: `conv1ab_kernel<true, 6>` (round 6)")
+        A("## Fused first two layers of the image extractor: `conv1ab_kernel<1, true, 6>` (round 6)")
         A("")
         A(f"* one launch instead of two: {fz['launch_ms']:.3f} ms per launch (mean of {fz['launches_timed']} per-launch HIP-event pairs) against "
           f"{fz['replaces_ms']['first_layer']:.3f} + {fz['replaces_ms']['second_layer']:.3f} = {fz['replaces_ms']['sum']:.3f} ms for the two launches alone; "
@@ -270,7 +270,7 @@ def write_readme(pmc, busy):
         fk = os.path.join(EV, "prof_kernel_only")
         for f_ in glob.glob(os.path.join(fk, "**", "*kernel_stats.csv"), recursive=True):
             for r in csv.DictReader(open(f_)):
-                if "conv1ab_kernel<true" in r["Name"]:
+                if "conv1ab_kernel<1, true" in r["Name"]:
                     A(f"* `{R}_conv1b_kernel_only_stats.csv` lists the same launches: {r['Calls']} launches, average {float(r['AverageNs']) / 1e6:.3f} ms.")
         pj = os.path.join(PR, f"{R}_pmc_conv1ab.json")
         if os.path.exists(pj):
