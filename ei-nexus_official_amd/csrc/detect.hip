@@ -42,7 +42,10 @@ __device__ __forceinline__ bool mask_on(const uint8_t* mask, int b, int H, int W
 // is bit-identical to the one-thread-per-cell form.  A lane writes its 8 score pixels as two 16-byte
 // stores; 8 neighbouring cells give 256 contiguous bytes per row.
 __global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B, int hc, int wc, const uint8_t* mask, int H, int W,
-                                                      int h0, int w0, int dilate, int border, float* prob, float* score) {
+                                                      int h0, int w0, int dilate, int border, float* prob, float* score, int32_t* zero_ptr,
+                                                      int zero_n) {
+  // (einx_extract: the NMS pass flags of the detection that follows are zeroed here instead of by a memset launch of their own)
+  if ((int)(blockIdx.x * 256 + threadIdx.x) < zero_n) zero_ptr[blockIdx.x * 256 + threadIdx.x] = 0;
   const int cells = hc * wc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 7, i = lane >> 3;
@@ -115,9 +118,10 @@ __global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B
 }
 
 __global__ void score1_kernel(const float* logits, int B, int Hp, int Wp, const uint8_t* mask, int H, int W, int h0, int w0,
-                              int dilate, int border, float* prob, float* score) {
+                              int dilate, int border, float* prob, float* score, int32_t* zero_ptr, int zero_n) {
   const int n = Hp * Wp;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < zero_n) zero_ptr[gid] = 0;
   if (gid >= B * n) return;
   const int b = gid / n, p = gid % n;
   const int y = p / Wp, x = p % Wp;
@@ -963,7 +967,16 @@ void topk_ranks(int N, int k, int* lo, int* hi) {
 
 EINX_EXPORT int einx_score_map(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0,
                                int dilate, int border, float* prob, float* score, void* stream) {
+  return einx_score_map_zero(logits, B, C, hc, wc, mask, H, W, h0, w0, dilate, border, prob, score, nullptr, 0, stream);
+}
+
+// the same launch, which also zeroes zero_n int32 words at zero_ptr (einx_extract: the NMS pass flags of the detection that follows;
+// returns EINX_ERR_ARG when the launch has fewer threads than words -- the caller then keeps the memset)
+int einx_score_map_zero(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0, int dilate,
+                        int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, void* stream) {
   EINX_CHECK_ARG(logits && prob && score, "null pointer");
+  EINX_CHECK_ARG(zero_n == 0 || (zero_ptr && (long)zero_n <= (long)(C == 65 ? einx_cdiv(B * hc * wc, 32) : einx_cdiv(B * hc * wc, 256)) * 256),
+                 "more words to zero than threads in the launch");
   EINX_CHECK_ARG(C == 65 || C == 1, "detector head must have 65 or 1 channels");
   EINX_CHECK_ARG(B > 0 && hc > 0 && wc > 0, "bad shape");
   hipStream_t s = (hipStream_t)stream;
@@ -971,11 +984,11 @@ EINX_EXPORT int einx_score_map(const float* logits, int B, int C, int hc, int wc
   if (C == 65) {
     const int n = B * hc * wc;
     hipLaunchKernelGGL(score65_kernel, dim3(einx_cdiv(n, 32)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
-                       prob, score);
+                       prob, score, zero_ptr, zero_n);
   } else {
     const int n = B * hc * wc;
     hipLaunchKernelGGL(score1_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
-                       prob, score);
+                       prob, score, zero_ptr, zero_n);
   }
   EINX_CHECK_LAUNCH();
   return EINX_OK;
@@ -1008,6 +1021,18 @@ EINX_EXPORT size_t einx_detect_ws_bytes(const einx_detect_params* p) {
 
 EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions,
                             int32_t* indices, int32_t* counts, float* thr, int32_t* not_converged, void* stream) {
+  return einx_detect_prezeroed(score, p, ws, nms_out, positions, indices, counts, thr, not_converged, 0, stream);
+}
+
+// where einx_detect keeps its B x nms_iters pass flags inside `ws` (einx_extract has the score kernel zero them)
+int32_t* einx_detect_flags(const einx_detect_params* p, void* ws, int* n) {
+  const size_t map_bytes = (size_t)p->B * p->Hp * p->Wp * sizeof(float);
+  *n = p->radius > 0 ? p->B * p->nms_iters : 0;
+  return (int32_t*)((char*)ws + 2 * map_bytes);
+}
+
+int einx_detect_prezeroed(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
+                          int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, void* stream) {
   EINX_CHECK_ARG(score && p && ws && positions && indices && counts && thr && not_converged, "null pointer");
   EINX_CHECK_ARG(p->B > 0 && p->Hp > 0 && p->Wp > 0 && p->cap > 0, "bad shape");
   EINX_CHECK_ARG(p->radius >= 0 && p->radius <= NMS_MAXR, "nms radius must be in 0..4");
@@ -1022,7 +1047,7 @@ EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, voi
   const float* cur = score;
   const int nIt = p->radius > 0 ? p->nms_iters : 0;
   if (nIt > 0) {
-    if (hipMemsetAsync(flags, 0, (size_t)p->B * nIt * sizeof(int32_t), s) != hipSuccess) {
+    if (!flags_zeroed && hipMemsetAsync(flags, 0, (size_t)p->B * nIt * sizeof(int32_t), s) != hipSuccess) {
       einx_set_error("einx_detect: memset failed");
       return EINX_ERR_LAUNCH;
     }

@@ -120,6 +120,13 @@ __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int
   }
 }
 #endif
+// einx_score_map that also zeroes the NMS pass flags of the detection that follows, and einx_detect told so (einx_extract: one launch
+// less per network on the latency-bound chain of a single-pair forward)
+int einx_score_map_zero(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0, int dilate,
+                        int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, void* stream);
+int32_t* einx_detect_flags(const einx_detect_params* p, void* ws, int* n);
+int einx_detect_prezeroed(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
+                          int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, void* stream);
 // einx_desc_sample with the extractor's weight watch riding on spare workgroups (einx_extract)
 int einx_desc_sample_watch(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last, const int32_t* indices,
                            const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, void* stream);

@@ -449,15 +449,21 @@ EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uin
     if ((rc = det_branch(stream))) return rc;
     if ((rc = desc_branch(stream))) return rc;
   }
-  rc = einx_score_map(o->logits, B, e->det.back().cout, h, w, mask, H, W, pl.h0, pl.w0, e->d.dilate_mask, e->d.border, o->prob, o->score,
-                      stream);
+  einx_detect_params dp;
+  detect_params(e, pl, B, H, W, o->cap, nms_budget(nms_iters), &dp);
+  // the score kernel also zeroes the detection's NMS pass flags (no memset launch) when it has a thread per flag word
+  int nflags = 0;
+  int32_t* flags = einx_detect_flags(&dp, det_ws, &nflags);
+  const int C_det = e->det.back().cout;
+  const long score_threads = (long)(C_det == 65 ? einx_cdiv(B * h * w, 32) : einx_cdiv(B * h * w, 256)) * 256;
+  const bool zero_in_score = nflags > 0 && nflags <= score_threads;
+  rc = einx_score_map_zero(o->logits, B, C_det, h, w, mask, H, W, pl.h0, pl.w0, e->d.dilate_mask, e->d.border, o->prob, o->score,
+                           zero_in_score ? flags : nullptr, zero_in_score ? nflags : 0, stream);
   if (rc) {
     if (sd) (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
     return rc;
   }
-  einx_detect_params dp;
-  detect_params(e, pl, B, H, W, o->cap, nms_budget(nms_iters), &dp);
-  rc = einx_detect(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, stream);
+  rc = einx_detect_prezeroed(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, zero_in_score ? 1 : 0, stream);
   if (sd && hipStreamWaitEvent((hipStream_t)stream, sd->join, 0) != hipSuccess && !rc) {  // join before the sampler reads `raw`
     einx_set_error("einx_extract: join failed");
     return EINX_ERR_LAUNCH;
