@@ -139,6 +139,7 @@ class BatchedFeats:
         self.pads = None  # (w0, w1, h0, h1)
         self.padded = None  # (Hp, Wp)
         self.feats = self.logits = self.raw = self.prob = self.score = None
+        self.score_crop = None  # [B,1,H,W] written by einx_extract's score kernel (handle-level path); None: cropped from `score`
         self.det = None
         self.sparse_desc = None
         self.raw_cl = None
@@ -192,7 +193,7 @@ class BatchedFeats:
         out["logits"] = self.logits
         out["raw_descriptors"] = self.raw
         out["probability"] = self.prob
-        out["score"] = self.score[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
+        out["score"] = self.score_crop if self.score_crop is not None else self.score[:, :, h0:Hp - h1, w0:Wp - w1].clone().contiguous()
         out["nms"] = None  # filled by materialize (a re-detection replaces it)
         if self.cell == 8:
             out["coarse_descriptors"] = self.coarse
@@ -363,8 +364,10 @@ class ExtractorEngine:
         ws = e(nws, dt=torch.uint8)
         m8 = _mask_u8(mask, H, W)
         P = N._ptr
+        bf.score_crop = e(B, 1, H, W)  # the dict's un-padded `score`, written by the score kernel (no crop + clone launch afterwards)
         out = _lib.ExtractOut(P(bf.feats), P(bf.logits), P(bf.raw), P(bf.prob), P(bf.score), P(bf.coarse), P(bf.raw_cl), P(det.nms),
-                              P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap)
+                              P(det.positions), P(det.indices), P(det.counts), P(det.thr), P(det.not_converged), P(bf.sparse_desc), cap,
+                              P(bf.score_crop))
         wt = getattr(self, "watch", None)
         if wt is not None and wt.n:  # `.data` edits of the weights: compared inside the call, reported through the watch's own `stale` word
             ww = _lib.WeightWatch(ctypes.sizeof(_lib.WeightWatch), wt.n, P(wt.table), P(wt.ref), P(wt.scratch), P(wt.stale))

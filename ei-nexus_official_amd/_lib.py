@@ -40,7 +40,7 @@ class ExtractShapes(ctypes.Structure):
 class ExtractOut(ctypes.Structure):
     _names = ("feats", "logits", "raw", "prob", "score", "coarse", "raw_cl", "nms", "positions", "indices", "counts", "thr", "not_converged",
               "sparse_desc")
-    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32)]
+    _fields_ = [(n, c_void_p) for n in _names] + [("cap", ctypes.c_int32), ("score_crop", c_void_p)]
 
 
 class WeightWatch(ctypes.Structure):

@@ -90,7 +90,7 @@ class EIM(nn.Module):
             # (under graph capture the allocations come from the graph's private pool and are never recycled, and
             # record_stream on them makes hipStreamEndCapture crash)
             for t in (() if torch.cuda.is_current_stream_capturing() else
-                      (ev.feats, ev.logits, ev.raw, ev.raw_cl, ev.prob, ev.score, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
+                      (ev.feats, ev.logits, ev.raw, ev.raw_cl, ev.prob, ev.score, ev.score_crop, ev.sparse_desc, ev.coarse, ev.normalized, ev.det.positions,
                        ev.det.indices, ev.det.counts, ev.det.thr, ev.det.not_converged, ev.det.nms)):
                 if t is not None:
                     t.record_stream(cur)  # allocated on the side stream, consumed on the caller's stream

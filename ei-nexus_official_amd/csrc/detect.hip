@@ -43,7 +43,7 @@ __device__ __forceinline__ bool mask_on(const uint8_t* mask, int b, int H, int W
 // stores; 8 neighbouring cells give 256 contiguous bytes per row.
 __global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B, int hc, int wc, const uint8_t* mask, int H, int W,
                                                       int h0, int w0, int dilate, int border, float* prob, float* score, int32_t* zero_ptr,
-                                                      int zero_n) {
+                                                      int zero_n, float* crop) {
   // (einx_extract: the NMS pass flags of the detection that follows are zeroed here instead of by a memset launch of their own)
   if ((int)(blockIdx.x * 256 + threadIdx.x) < zero_n) zero_ptr[blockIdx.x * 256 + threadIdx.x] = 0;
   const int cells = hc * wc;
@@ -115,10 +115,21 @@ __global__ __launch_bounds__(256) void score65_kernel(const float* logits, int B
   f32x4* dst = reinterpret_cast<f32x4*>(score + ((size_t)b * Hp + y) * Wp + w * 8);  // 32-byte aligned: Wp % 8 == 0
   dst[0] = f32x4{out[0], out[1], out[2], out[3]};
   dst[1] = f32x4{out[4], out[5], out[6], out[7]};
+  if (crop) {  // the un-padded map of the output dict (the reference's `unpad`), written here instead of by a crop + clone afterwards
+    const int uy = y - h0;
+    if (uy >= 0 && uy < H) {
+      float* cr = crop + ((size_t)b * H + uy) * W - w0 + w * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int ux = w * 8 + k - w0;
+        if (ux >= 0 && ux < W) cr[k] = out[k];
+      }
+    }
+  }
 }
 
 __global__ void score1_kernel(const float* logits, int B, int Hp, int Wp, const uint8_t* mask, int H, int W, int h0, int w0,
-                              int dilate, int border, float* prob, float* score, int32_t* zero_ptr, int zero_n) {
+                              int dilate, int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, float* crop) {
   const int n = Hp * Wp;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < zero_n) zero_ptr[gid] = 0;
@@ -130,6 +141,10 @@ __global__ void score1_kernel(const float* logits, int B, int Hp, int Wp, const 
   if (border > 0 && (y < border || y >= Hp - border || x < border || x >= Wp - border)) v = 0.0f;
   prob[gid] = v;  // the reference's score aliases probability for cell-1 networks
   score[gid] = v;
+  if (crop) {
+    const int uy = y - h0, ux = x - w0;
+    if (uy >= 0 && uy < H && ux >= 0 && ux < W) crop[((size_t)b * H + uy) * W + ux] = v;
+  }
 }
 
 // get_dense_positions (detector_util.py:504-519) on an unpadded map: row p of image b = (y+0.5, x+0.5, score)
@@ -967,13 +982,14 @@ void topk_ranks(int N, int k, int* lo, int* hi) {
 
 EINX_EXPORT int einx_score_map(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0,
                                int dilate, int border, float* prob, float* score, void* stream) {
-  return einx_score_map_zero(logits, B, C, hc, wc, mask, H, W, h0, w0, dilate, border, prob, score, nullptr, 0, stream);
+  return einx_score_map_zero(logits, B, C, hc, wc, mask, H, W, h0, w0, dilate, border, prob, score, nullptr, 0, nullptr, stream);
 }
 
 // the same launch, which also zeroes zero_n int32 words at zero_ptr (einx_extract: the NMS pass flags of the detection that follows;
 // returns EINX_ERR_ARG when the launch has fewer threads than words -- the caller then keeps the memset)
 int einx_score_map_zero(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0, int dilate,
-                        int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, void* stream) {
+                        int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, float* crop, void* stream) {
+  EINX_CHECK_ARG(!crop || (H > 0 && W > 0), "the cropped map needs the un-padded size");
   EINX_CHECK_ARG(logits && prob && score, "null pointer");
   EINX_CHECK_ARG(zero_n == 0 || (zero_ptr && (long)zero_n <= (long)(C == 65 ? einx_cdiv(B * hc * wc, 32) : einx_cdiv(B * hc * wc, 256)) * 256),
                  "more words to zero than threads in the launch");
@@ -984,11 +1000,11 @@ int einx_score_map_zero(const float* logits, int B, int C, int hc, int wc, const
   if (C == 65) {
     const int n = B * hc * wc;
     hipLaunchKernelGGL(score65_kernel, dim3(einx_cdiv(n, 32)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
-                       prob, score, zero_ptr, zero_n);
+                       prob, score, zero_ptr, zero_n, crop);
   } else {
     const int n = B * hc * wc;
     hipLaunchKernelGGL(score1_kernel, dim3(einx_cdiv(n, 256)), dim3(256), 0, s, logits, B, hc, wc, mask, H, W, h0, w0, dilate, border,
-                       prob, score, zero_ptr, zero_n);
+                       prob, score, zero_ptr, zero_n, crop);
   }
   EINX_CHECK_LAUNCH();
   return EINX_OK;

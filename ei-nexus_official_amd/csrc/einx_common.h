@@ -120,10 +120,11 @@ __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int
   }
 }
 #endif
-// einx_score_map that also zeroes the NMS pass flags of the detection that follows, and einx_detect told so (einx_extract: one launch
+// einx_score_map that also zeroes the NMS pass flags of the detection that follows and writes the un-padded score map (crop: [B,1,H,W] or
+// null), and einx_detect told so (einx_extract: one launch
 // less per network on the latency-bound chain of a single-pair forward)
 int einx_score_map_zero(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0, int dilate,
-                        int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, void* stream);
+                        int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, float* crop, void* stream);
 int32_t* einx_detect_flags(const einx_detect_params* p, void* ws, int* n);
 int einx_detect_prezeroed(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
                           int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, void* stream);

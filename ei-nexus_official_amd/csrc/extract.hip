@@ -458,7 +458,7 @@ EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uin
   const long score_threads = (long)(C_det == 65 ? einx_cdiv(B * h * w, 32) : einx_cdiv(B * h * w, 256)) * 256;
   const bool zero_in_score = nflags > 0 && nflags <= score_threads;
   rc = einx_score_map_zero(o->logits, B, C_det, h, w, mask, H, W, pl.h0, pl.w0, e->d.dilate_mask, e->d.border, o->prob, o->score,
-                           zero_in_score ? flags : nullptr, zero_in_score ? nflags : 0, stream);
+                           zero_in_score ? flags : nullptr, zero_in_score ? nflags : 0, o->score_crop, stream);
   if (rc) {
     if (sd) (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
     return rc;

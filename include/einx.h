@@ -409,6 +409,8 @@ typedef struct einx_extract_out {
   int32_t* not_converged; /* [B] 1: the NMS fix-point of this image needs more passes than were enqueued (see einx_detect) */
   float* sparse_desc;     /* [B,cap,desc_dim] */
   int32_t cap;
+  float* score_crop;      /* optional (NULL: off): [B,1,H,W] the un-padded score map of the output dict (Padder.unpad, utils/util.py:42-50),
+                             written by the score kernel instead of by a crop + clone afterwards */
 } einx_extract_out;
 
 /* Optional content watch of a network's weights riding on an einx_extract_watch call (what einx_params_hash does as a launch
