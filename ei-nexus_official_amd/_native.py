@@ -369,6 +369,9 @@ def gather_matches(r, kpts0, kpts1, n, cols):
 def compact_matches(r):
     """r.mk0/r.mk1 [B,cap0,cols] + r.nmatch -> r.mk0_flat/r.mk1_flat [B*cap0,cols] packed pair after pair."""
     B, cap0, cols = r.mk0.shape
+    if B == 1:  # one pair: its matched rows already sit at the front of mk0[0] / mk1[0] (no launch on the single-pair chain)
+        r.mk0_flat, r.mk1_flat = r.mk0[0], r.mk1[0]
+        return r
     r.mk0_flat = torch.empty((B * cap0, cols), dtype=F32, device=r.mk0.device)
     r.mk1_flat = torch.empty((B * cap0, cols), dtype=F32, device=r.mk0.device)
     check(lib().einx_compact_rows(_ptr(r.mk0), _ptr(r.mk1), _ptr(r.nmatch), B, cap0, cols, _ptr(r.mk0_flat), _ptr(r.mk1_flat),

@@ -23,11 +23,17 @@ __device__ __forceinline__ float wave_butterfly_sum(float v) {
 template <bool BILINEAR, bool CL = false>
 __global__ __launch_bounds__(256) void desc_sample_kernel(const float* raw, int D, int hc, int wc, int Hp, int Wp,
                                                           const int32_t* indices, const int32_t* counts, int cap, float scale,
-                                                          float* out, const EinxWatch watch, int main_blocks) {
+                                                          float* out, const EinxWatch watch, int main_blocks, const EinxCrop crop,
+                                                          int watch_blocks) {
   const int b = blockIdx.y;
   const int kp = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if ((int)blockIdx.x >= main_blocks) {  // spare workgroups of image 0: the extractor's weight watch, four tensors each
+  if ((int)blockIdx.x >= main_blocks) {
+    if ((int)blockIdx.x >= main_blocks + watch_blocks) {  // extra workgroups: the cropped NMS map of image b (einx_extract)
+      einx_crop_block(crop, b, (int)blockIdx.x - main_blocks - watch_blocks, (int)threadIdx.x);
+      return;
+    }
+    // spare workgroups of image 0: the extractor's weight watch, four tensors each
     const int t = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
     if (b == 0 && t < watch.n) einx_watch_tensor(watch, t, lane);
     return;
@@ -659,21 +665,25 @@ EINX_EXPORT int einx_desc_sample(const float* raw, int B, int D, int hc, int wc,
   none.flag = nullptr;
   none.n = 0;
   none.bit = 0;
-  return einx_desc_sample_watch(raw, B, D, hc, wc, Hp, Wp, bilinear, channels_last, indices, counts, cap, scale, out, none, stream);
+  EinxCrop nocrop{};
+  nocrop.map = nullptr;
+  return einx_desc_sample_watch(raw, B, D, hc, wc, Hp, Wp, bilinear, channels_last, indices, counts, cap, scale, out, none, nocrop, stream);
 }
 
 int einx_desc_sample_watch(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last, const int32_t* indices,
-                           const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, void* stream) {
+                           const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, const EinxCrop& crop, void* stream) {
   const int main_blocks = einx_cdiv(cap, 4);
-  dim3 grid((unsigned)(main_blocks + (watch.n > 0 ? einx_cdiv(watch.n, 4) : 0)), (unsigned)B);
+  const int watch_blocks = watch.n > 0 ? einx_cdiv(watch.n, 4) : 0;
+  const int crop_blocks = crop.map ? einx_cdiv(crop.H * crop.W, 256) : 0;
+  dim3 grid((unsigned)(main_blocks + watch_blocks + crop_blocks), (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
   EINX_PROF("desc_sample_kernel", s);
   if (bilinear && channels_last)
-    hipLaunchKernelGGL((desc_sample_kernel<true, true>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks);
+    hipLaunchKernelGGL((desc_sample_kernel<true, true>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks, crop, watch_blocks);
   else if (bilinear)
-    hipLaunchKernelGGL((desc_sample_kernel<true, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks);
+    hipLaunchKernelGGL((desc_sample_kernel<true, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks, crop, watch_blocks);
   else
-    hipLaunchKernelGGL((desc_sample_kernel<false, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks);
+    hipLaunchKernelGGL((desc_sample_kernel<false, false>), grid, dim3(256), 0, s, raw, D, hc, wc, Hp, Wp, indices, counts, cap, scale, out, watch, main_blocks, crop, watch_blocks);
   EINX_CHECK_LAUNCH();
   return EINX_OK;
 }

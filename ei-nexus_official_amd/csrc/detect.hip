@@ -1037,7 +1037,7 @@ EINX_EXPORT size_t einx_detect_ws_bytes(const einx_detect_params* p) {
 
 EINX_EXPORT int einx_detect(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions,
                             int32_t* indices, int32_t* counts, float* thr, int32_t* not_converged, void* stream) {
-  return einx_detect_prezeroed(score, p, ws, nms_out, positions, indices, counts, thr, not_converged, 0, stream);
+  return einx_detect_prezeroed(score, p, ws, nms_out, positions, indices, counts, thr, not_converged, 0, nullptr, stream);
 }
 
 // where einx_detect keeps its B x nms_iters pass flags inside `ws` (einx_extract has the score kernel zero them)
@@ -1048,7 +1048,7 @@ int32_t* einx_detect_flags(const einx_detect_params* p, void* ws, int* n) {
 }
 
 int einx_detect_prezeroed(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
-                          int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, void* stream) {
+                          int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, const float** final_map, void* stream) {
   EINX_CHECK_ARG(score && p && ws && positions && indices && counts && thr && not_converged, "null pointer");
   EINX_CHECK_ARG(p->B > 0 && p->Hp > 0 && p->Wp > 0 && p->cap > 0, "bad shape");
   EINX_CHECK_ARG(p->radius >= 0 && p->radius <= NMS_MAXR, "nms radius must be in 0..4");
@@ -1121,7 +1121,8 @@ int einx_detect_prezeroed(const float* score, const einx_detect_params* p, void*
     EINX_PROF("select_compact_kernel", s);
     hipLaunchKernelGGL(select_compact_kernel, dim3(p->B), dim3(SEL_THREADS), 0, s, a);
   }
-  if (nms_out) {
+  if (final_map) *final_map = a.map;
+  if (nms_out && !final_map) {
     EINX_PROF("nms_crop_kernel", s);
     EINX_CHECK_LAUNCH();
     const size_t n = (size_t)p->B * p->H * p->W;

@@ -126,11 +126,29 @@ __device__ __forceinline__ void einx_watch_tensor(const EinxWatch& w, int t, int
 int einx_score_map_zero(const float* logits, int B, int C, int hc, int wc, const uint8_t* mask, int H, int W, int h0, int w0, int dilate,
                         int border, float* prob, float* score, int32_t* zero_ptr, int zero_n, float* crop, void* stream);
 int32_t* einx_detect_flags(const einx_detect_params* p, void* ws, int* n);
+// final_map != null: the cropped `nms` output is NOT written here; *final_map receives the buffer that holds the NMS fix-point (the caller
+// crops it: einx_extract, on the sampling launch)
 int einx_detect_prezeroed(const float* score, const einx_detect_params* p, void* ws, float* nms_out, float* positions, int32_t* indices,
-                          int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, void* stream);
-// einx_desc_sample with the extractor's weight watch riding on spare workgroups (einx_extract)
+                          int32_t* counts, float* thr, int32_t* not_converged, int flags_zeroed, const float** final_map, void* stream);
+// The thresholded NMS map cropped to the un-padded window (the dict's `nms`): out[b,y,x] = v > thr[b] ? v : 0.  Riding on extra workgroups
+// of the sampling launch inside einx_extract (both only need the selection's outputs): one launch less on a single pair's chain.
+struct EinxCrop {
+  const float* map;  // [B,Hp,Wp] the NMS fix-point; null: off
+  const float* thr;  // [B]
+  float* out;        // [B,H,W]
+  int Hp, Wp, h0, w0, H, W;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void einx_crop_block(const EinxCrop& c, int b, int blk, int tid) {
+  const int r = blk * 256 + tid;
+  if (r >= c.H * c.W) return;
+  const float v = c.map[((size_t)b * c.Hp + (r / c.W + c.h0)) * c.Wp + r % c.W + c.w0];
+  c.out[(size_t)b * c.H * c.W + r] = v > c.thr[b] ? v : 0.0f;
+}
+#endif
+// einx_desc_sample with the extractor's weight watch and the NMS-map crop riding on spare workgroups (einx_extract)
 int einx_desc_sample_watch(const float* raw, int B, int D, int hc, int wc, int Hp, int Wp, int bilinear, int channels_last, const int32_t* indices,
-                           const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, void* stream);
+                           const int32_t* counts, int cap, float scale, float* out, const EinxWatch& watch, const EinxCrop& crop, void* stream);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -463,7 +463,11 @@ EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uin
     if (sd) (void)hipStreamWaitEvent((hipStream_t)stream, sd->join, 0);
     return rc;
   }
-  rc = einx_detect_prezeroed(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, zero_in_score ? 1 : 0, stream);
+  // the cropped `nms` output is written by extra workgroups of the sampling launch below (one launch less): the detection only
+  // reports which buffer holds the NMS fix-point
+  const float* nms_map = nullptr;
+  rc = einx_detect_prezeroed(o->score, &dp, det_ws, o->nms, o->positions, o->indices, o->counts, o->thr, o->not_converged, zero_in_score ? 1 : 0,
+                             o->nms ? &nms_map : nullptr, stream);
   if (sd && hipStreamWaitEvent((hipStream_t)stream, sd->join, 0) != hipSuccess && !rc) {  // join before the sampler reads `raw`
     einx_set_error("einx_extract: join failed");
     return EINX_ERR_LAUNCH;
@@ -479,6 +483,16 @@ EINX_EXPORT int einx_extract_watch(const einx_extractor* e, float* in, const uin
   watch.flag = on ? ww->stale : nullptr;
   watch.n = on ? ww->n : 0;
   watch.bit = 1;
+  EinxCrop crop{};
+  crop.map = o->nms ? nms_map : nullptr;
+  crop.thr = o->thr;
+  crop.out = o->nms;
+  crop.Hp = pl.Hp;
+  crop.Wp = pl.Wp;
+  crop.h0 = pl.h0;
+  crop.w0 = pl.w0;
+  crop.H = H;
+  crop.W = W;
   return einx_desc_sample_watch(use_cl ? o->raw_cl : o->raw, B, D, h, w, pl.Hp, pl.Wp, bilinear ? 1 : 0, use_cl ? 1 : 0, o->indices, o->counts,
-                                o->cap, e->d.desc_scale, o->sparse_desc, watch, stream);
+                                o->cap, e->d.desc_scale, o->sparse_desc, watch, crop, stream);
 }
