@@ -322,8 +322,10 @@ class MatchResult:
         self.stale = None  # device int32 [1]: the matcher's weight watch (LightGlue), read back with the match counts
 
 
-def mnn(desc0, n, desc1, m, want_la=True, ratio_thresh=None, distance_thresh=None):
-    """ratio_thresh / distance_thresh: find_nn's optional thresholds (MNN.py:12-22), falsy = off."""
+def mnn(desc0, n, desc1, m, want_la=True, ratio_thresh=None, distance_thresh=None, gather=None):
+    """ratio_thresh / distance_thresh: find_nn's optional thresholds (MNN.py:12-22), falsy = off.
+    gather = (kpts0, kpts1, cols): also the matched keypoints of every pair (gather_matches' r.mk0 / r.mk1 / r.nmatch), in the
+    same call -- without thresholds the mutual check and the compaction are one launch."""
     _dev_check(desc0, desc1)
     _dev_check(n, m, dt=I32)
     B, cap0, D = desc0.shape
@@ -345,6 +347,16 @@ def mnn(desc0, n, desc1, m, want_la=True, ratio_thresh=None, distance_thresh=Non
         check(L.einx_mnn_thresh(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, int(bool(ratio_thresh)), r2,
                                 int(bool(distance_thresh)), t2, _ptr(ws), _ptr(r.matches0), _ptr(r.matches1), _ptr(r.scores0), _ptr(r.scores1),
                                 _ptr(r.la), _stream(desc0)), "einx_mnn_thresh")
+        return r if gather is None else gather_matches(r, gather[0], gather[1], n, gather[2])
+    if gather is not None:
+        k0, k1, cols = gather
+        _dev_check(k0, k1)
+        r.mk0 = torch.empty((B, cap0, cols), dtype=F32, device=dev)
+        r.mk1 = torch.empty((B, cap0, cols), dtype=F32, device=dev)
+        r.nmatch = torch.empty((B,), dtype=torch.int32, device=dev)
+        check(L.einx_mnn_gather(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, _ptr(ws), _ptr(r.matches0), _ptr(r.matches1),
+                                _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _ptr(k0), _ptr(k1), int(cols), _ptr(r.mk0), _ptr(r.mk1),
+                                _ptr(r.nmatch), _stream(desc0)), "einx_mnn_gather")
         return r
     check(L.einx_mnn(_ptr(desc0), _ptr(n), cap0, _ptr(desc1), _ptr(m), cap1, B, D, _ptr(ws), _ptr(r.matches0), _ptr(r.matches1),
                      _ptr(r.scores0), _ptr(r.scores1), _ptr(r.la), _stream(desc0)), "einx_mnn")

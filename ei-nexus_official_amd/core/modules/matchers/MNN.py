@@ -28,9 +28,8 @@ class NearestNeighborMatcher(nn.Module):
     @on_input_device
     def match_batched(self, pb0, pb1):
         """device-side: no host sync"""
-        r = N.mnn(pb0.desc, pb0.counts, pb1.desc, pb1.counts, want_la=self.want_log_assignment, ratio_thresh=self.ratio_thresh,
-                  distance_thresh=self.distance_thresh)
-        return N.gather_matches(r, pb0.kpts, pb1.kpts, pb0.counts, 3)
+        return N.mnn(pb0.desc, pb0.counts, pb1.desc, pb1.counts, want_la=self.want_log_assignment, ratio_thresh=self.ratio_thresh,
+                     distance_thresh=self.distance_thresh, gather=(pb0.kpts, pb1.kpts, 3))
 
     @torch.no_grad()
     @on_input_device

@@ -546,6 +546,75 @@ __global__ __launch_bounds__(1024) void gather_matches_kernel(const float* k0, c
   if (tid == 0) nmatch[b] = base;
 }
 
+// mnn_finalize_kernel + gather_matches_kernel as ONE launch (one workgroup per pair; round 6: a launch less on the matcher's
+// latency-bound tail): the mutual check of rows / columns t, then -- from the same registers -- the order-preserving compaction of
+// the matched keypoints.  Same values as the two launches.
+__global__ __launch_bounds__(1024) void mnn_finalize_gather_kernel(const unsigned long long* rowkey, const unsigned long long* colkey, const int32_t* nn,
+                                                                   const int32_t* mm, int cap0, int cap1, int64_t* m0, int64_t* m1, float* s0, float* s1,
+                                                                   const float* k0, const float* k1, int cols, float* o0, float* o1, int32_t* nmatch) {
+  __shared__ int scratch[17];
+  const int b = blockIdx.x;
+  const int n = min(nn[b], cap0), m = min(mm[b], cap1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long* rk = rowkey + (size_t)b * cap0;
+  const unsigned long long* ck = colkey + (size_t)b * cap1;
+  const int mx = cap0 > cap1 ? cap0 : cap1;
+  int base = 0;
+  for (int i0 = 0; i0 < mx; i0 += 1024) {
+    const int t = i0 + tid;
+    int64_t r0 = -1;
+    if (t < cap0) {
+      if (t < n && m > 0) {
+        const int j = (int)(0xFFFFFFFFu - (unsigned)(rk[t] & 0xFFFFFFFFull));
+        const int back = (int)(0xFFFFFFFFu - (unsigned)(ck[j] & 0xFFFFFFFFull));
+        if (back == t) r0 = j;
+      }
+      m0[(size_t)b * cap0 + t] = r0;
+      s0[(size_t)b * cap0 + t] = r0 > -1 ? 1.0f : 0.0f;
+    }
+    if (t < cap1) {
+      int64_t r1 = -1;
+      if (t < m && n > 0) {
+        const int i = (int)(0xFFFFFFFFu - (unsigned)(ck[t] & 0xFFFFFFFFull));
+        const int back = (int)(0xFFFFFFFFu - (unsigned)(rk[i] & 0xFFFFFFFFull));
+        if (back == t) r1 = i;
+      }
+      m1[(size_t)b * cap1 + t] = r1;
+      s1[(size_t)b * cap1 + t] = r1 > -1 ? 1.0f : 0.0f;
+    }
+    const int v = (t < n && r0 > -1) ? 1 : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int w = 0; w < 16; ++w) {
+        const int u = scratch[w];
+        scratch[w] = run;
+        run += u;
+      }
+      scratch[16] = run;
+    }
+    __syncthreads();
+    const int pos = base + scratch[wave] + incl - v;
+    const int total = scratch[16];
+    __syncthreads();
+    if (v) {
+      for (int c = 0; c < cols; ++c) {
+        o0[((size_t)b * cap0 + pos) * cols + c] = k0[((size_t)b * cap0 + t) * 3 + c];
+        o1[((size_t)b * cap0 + pos) * cols + c] = k1[((size_t)b * cap1 + (int)r0) * 3 + c];
+      }
+    }
+    base += total;
+  }
+  if (tid == 0) nmatch[b] = base;
+}
+
 // rows [b, 0:counts[b]] of two padded [B,cap,width] arrays -> consecutive rows of two flat arrays
 // (pair b starts at sum(counts[:b])): lets the host cut per-pair views with one split call
 __global__ __launch_bounds__(256) void compact_rows_kernel(const float* s0, const float* s1, const int32_t* counts, int B, int cap, int width,

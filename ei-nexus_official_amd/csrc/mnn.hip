@@ -30,9 +30,43 @@ EINX_EXPORT int einx_mnn(const float* desc0, const int32_t* n, int cap0, const f
   return einx_mnn_thresh(desc0, n, cap0, desc1, m, cap1, B, D, 0, 0.0f, 0, 0.0f, ws, matches0, matches1, scores0, scores1, la, stream);
 }
 
+namespace {
+struct GatherOut {  // optional: the matched keypoints of every pair, compacted in row order (einx_gather_matches' outputs)
+  const float *k0 = nullptr, *k1 = nullptr;
+  int cols = 0;
+  float *o0 = nullptr, *o1 = nullptr;
+  int32_t* nmatch = nullptr;
+};
+int mnn_impl(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D, int use_ratio,
+             float ratio_sq, int use_dist, float dist_sq, void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la,
+             const GatherOut& go, void* stream);
+}  // namespace
+
 EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
                                 int use_ratio, float ratio_sq, int use_dist, float dist_sq, void* ws, int64_t* matches0, int64_t* matches1,
                                 float* scores0, float* scores1, float* la, void* stream) {
+  return mnn_impl(desc0, n, cap0, desc1, m, cap1, B, D, use_ratio, ratio_sq, use_dist, dist_sq, ws, matches0, matches1, scores0, scores1, la,
+                  GatherOut{}, stream);
+}
+
+EINX_EXPORT int einx_mnn_gather(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
+                                void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, const float* kpts0,
+                                const float* kpts1, int cols, float* mk0, float* mk1, int32_t* nmatch, void* stream) {
+  EINX_CHECK_ARG(kpts0 && kpts1 && mk0 && mk1 && nmatch && cols >= 1 && cols <= 3, "null pointer / bad cols");
+  GatherOut go;
+  go.k0 = kpts0;
+  go.k1 = kpts1;
+  go.cols = cols;
+  go.o0 = mk0;
+  go.o1 = mk1;
+  go.nmatch = nmatch;
+  return mnn_impl(desc0, n, cap0, desc1, m, cap1, B, D, 0, 0.0f, 0, 0.0f, ws, matches0, matches1, scores0, scores1, la, go, stream);
+}
+
+namespace {
+int mnn_impl(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D, int use_ratio,
+             float ratio_sq, int use_dist, float dist_sq, void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la,
+             const GatherOut& go, void* stream) {
   EINX_CHECK_ARG(desc0 && desc1 && n && m && ws && matches0 && matches1 && scores0 && scores1, "null pointer");
   EINX_CHECK_ARG(B > 0 && cap0 > 0 && cap1 > 0 && D > 0 && D % 4 == 0, "bad shape (D must be a multiple of 4)");
   hipStream_t s = (hipStream_t)stream;
@@ -91,6 +125,9 @@ EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, 
     }
     hipLaunchKernelGGL(mnn_finalize_thresh_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, s, a.rowkey, a.colkey, a.row2,
                        a.col2, n, m, cap0, cap1, use_ratio, ratio_sq, use_dist, dist_sq, matches0, matches1, scores0, scores1);
+  } else if (go.nmatch) {  // mutual check + matched-keypoint compaction in one launch
+    hipLaunchKernelGGL(mnn_finalize_gather_kernel, dim3((unsigned)B), dim3(1024), 0, s, a.rowkey, a.colkey, n, m, cap0, cap1, matches0, matches1,
+                       scores0, scores1, go.k0, go.k1, go.cols, go.o0, go.o1, go.nmatch);
   } else {
     hipLaunchKernelGGL(mnn_finalize_kernel, dim3((unsigned)einx_cdiv(mx, 256), (unsigned)B), dim3(256), 0, s, a.rowkey, a.colkey, n, m,
                        cap0, cap1, matches0, matches1, scores0, scores1);
@@ -104,6 +141,7 @@ EINX_EXPORT int einx_mnn_thresh(const float* desc0, const int32_t* n, int cap0, 
   }
   return EINX_OK;
 }
+}  // namespace
 
 EINX_EXPORT int einx_similarity(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B,
                                 int D, float* sim, void* stream) {

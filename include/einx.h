@@ -232,6 +232,11 @@ int einx_upsample_normalize(const float* raw, int B, int D, int hc, int wc, int 
 size_t einx_mnn_ws_bytes(int B, int cap0, int cap1);
 int einx_mnn(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
              void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, void* stream);
+/* einx_mnn followed by einx_gather_matches (below) with the mutual check and the matched-keypoint compaction as ONE launch
+ * (MNN.py:98-129: the matches and the per-pair matched_kpts lists); same outputs as the two calls. */
+int einx_mnn_gather(const float* desc0, const int32_t* n, int cap0, const float* desc1, const int32_t* m, int cap1, int B, int D,
+                    void* ws, int64_t* matches0, int64_t* matches1, float* scores0, float* scores1, float* la, const float* kpts0,
+                    const float* kpts1, int cols, float* mk0, float* mk1, int32_t* nmatch, void* stream);
 /* the same with find_nn's optional thresholds (MNN.py:12-22): dist = 2*(1-sim) of the best / second-best
  * neighbour per row (per column for matches1); a match is kept when dist0 <= ratio_sq*dist1 (use_ratio) and
  * dist0 <= dist_sq (use_dist); the mutual check (:25-32) runs on the masked matches.  ratio_sq / dist_sq are the
