@@ -126,6 +126,33 @@ def launch_ranks(args, argv):
     return rc
 
 
+def stream_overlap_report(pkg, dev):
+    """The four streams of a forward (caller, the event extractor's side stream, the library's fork stream of each) probed pair by
+    pair with einx_stream_overlap_us AFTER the timed region: elapsed / spin, 1 = side by side, 2 = serialised on one hardware queue.
+    (What the step rate depends on besides the kernels: under a process group RCCL's streams take hardware queues as well.)"""
+    import ctypes
+    import torch
+    N = importlib.import_module(pkg.__name__ + "._native")
+    EIM = importlib.import_module(pkg.__name__ + ".core.modules.EIM").EIM
+    lib = N.lib()
+    key = (dev.type, dev.index)
+    side = EIM._side_streams.get(key)
+    if side is None:
+        return None
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    hs = {"main": cur, "side": side.cuda_stream, "fork(main)": lib.einx_fork_stream_of(ctypes.c_void_p(cur)),
+          "fork(side)": lib.einx_fork_stream_of(ctypes.c_void_p(side.cuda_stream))}
+    names = [k for k, v in hs.items() if k == "main" or v]
+    out = {}
+    spin = 200
+    for i, a in enumerate(names):
+        for b in names[i + 1:]:
+            r = ctypes.c_float()
+            if lib.einx_stream_overlap_us(ctypes.c_void_p(hs[a]), ctypes.c_void_p(hs[b]), spin, ctypes.byref(r)) == 0:
+                out[f"{a}|{b}"] = round(r.value / spin, 2)
+    return out
+
+
 # ------------------------------------------------------------------------------------ all-rank legs
 SCALE_LEG_STEPS = 10
 
@@ -1009,6 +1036,8 @@ def run_rank(args):
     pairs_total = max(stats["pairs"], 1.0)
     value = stats["pairs"] / elapsed if elapsed > 0 else 0.0
 
+    streams = stream_overlap_report(pkg, dev) if rank == 0 else None
+
     # ---- all-rank legs (every N): BASELINE configs[4], SP + LightGlue at 64 pairs per GPU, sharded like the headline ----
     scale_legs, leg_wls = [], {}
     for cfg_, b_, steps_ in scale_leg_plan(args):
@@ -1155,6 +1184,8 @@ def run_rank(args):
             out["extra_configs"] = extras
         if rccl is not None:
             out["rccl"] = rccl
+        if streams is not None:
+            out["streams"] = streams
         if placements is not None:
             out["placement"] = placements  # per rank: GPU, its NUMA node, the cores the rank is pinned to, thread-pool size
         if cpu_torch is not None:

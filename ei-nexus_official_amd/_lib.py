@@ -78,6 +78,9 @@ SIGNATURES = {
     "einx_params_hash": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "einx_last_error": (c_char_p, []),
     "einx_math_eval": (c_int, [c_int, c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    "einx_fork_stream_of": (c_void_p, [c_void_p]),
+    "einx_fork_stream_prepare_beside": (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int]),
+    "einx_stream_overlap_us": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]),
     "einx_device_count": (c_int, []),
     "einx_profile_enable": (c_int, [c_int]),
     "einx_profile_report": (c_int, [c_char_p, c_size_t]),

@@ -51,20 +51,39 @@ class EIM(nn.Module):
     _side_streams = {}  # one side stream per device for the whole process
 
     def _side_stream(self, device):
-        """HIP maps streams onto a small pool of hardware queues in creation order: a side stream per model instance means that
-        the third or fourth model of a process gets one that shares a queue with the main stream, and its two extractors
-        serialise (measured in bench.py's extra legs: B=1 1.23 ms instead of 0.92).  So all instances share one."""
+        """HIP maps streams onto a small pool of hardware queues: a side stream per model instance means that the third or
+        fourth model of a process gets one that shares a queue with the main stream, and its two extractors serialise (measured
+        in bench.py's extra legs: B=1 1.23 ms instead of 0.92).  So all instances share one, chosen by probing (round 6)."""
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         st = EIM._side_streams.get(key)
         if st is None:
-            cur = torch.cuda.current_stream(device)
-            st = EIM._side_streams[key] = torch.cuda.Stream(device=device)
-            # the native fork streams of both callers right behind them in HIP's creation order (einx.h::einx_fork_stream_prepare:
-            # created later -- after a loader's copy streams, say -- they can land on their caller's compute pipe)
             from ..._lib import check
             from ... import _native as N
-            for s_ in (cur, st):
-                check(N.lib().einx_fork_stream_prepare(ctypes.c_void_p(s_.cuda_stream)), "einx_fork_stream_prepare")
+            cur = torch.cuda.current_stream(device)
+            lib = N.lib()
+            # a stream that runs BESIDE the caller's: which hardware queue a stream lands on depends on what the process created
+            # before it (a process group, a loader), so candidates from torch's pool are probed (einx_stream_overlap_us:
+            # elapsed / spin is ~1.1 side by side, ~1.3 on one compute pipe, ~2.1 on one queue) and the first clean one is kept
+            best, best_ratio = None, None
+            with torch.cuda.device(device):
+                for _ in range(8):
+                    cand = torch.cuda.Stream(device=device)
+                    us = ctypes.c_float()
+                    if lib.einx_stream_overlap_us(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(cand.cuda_stream), 100, ctypes.byref(us)) != 0:
+                        best = best or cand  # (no verdict from the probe: first candidate)
+                        break
+                    ratio = us.value / 100.0
+                    if best is None or ratio < best_ratio - 0.1:
+                        best, best_ratio = cand, ratio
+                    if ratio < 1.25:
+                        break
+                st = EIM._side_streams[key] = best
+                # the native fork streams of both callers, each beside its caller and clear of the other three streams of a forward
+                # (einx.h::einx_fork_stream_prepare_beside)
+                arr = (ctypes.c_void_p * 2)(st.cuda_stream, None)
+                check(lib.einx_fork_stream_prepare_beside(ctypes.c_void_p(cur.cuda_stream), arr, 1), "einx_fork_stream_prepare_beside")
+                arr = (ctypes.c_void_p * 2)(cur.cuda_stream, lib.einx_fork_stream_of(ctypes.c_void_p(cur.cuda_stream)))
+                check(lib.einx_fork_stream_prepare_beside(ctypes.c_void_p(st.cuda_stream), arr, 2), "einx_fork_stream_prepare_beside")
         return st
 
     @on_input_device

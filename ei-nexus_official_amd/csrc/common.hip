@@ -229,6 +229,61 @@ EINX_EXPORT int einx_math_eval(int fn, const float* x, long long n, float* y, vo
 
 
 // ------------------------------------------------------------------------------------------
+// Do two streams run side by side?  HIP deals streams onto a few hardware queues / compute pipes; two streams that share one
+// serialise, and which ones share depends on what else the process created before (a process group's own streams, a loader's
+// copy streams).  The probe holds one 64-lane wave spinning for `spin_us` on each stream between a common start and a common
+// end event and returns the elapsed time: about spin_us when the streams overlap, about twice that when they do not.  The
+// wave leaves its loop on the constant-rate clock or after a bounded number of polls, whichever comes first.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks, int max_polls) {
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < max_polls; ++i) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+}  // namespace
+
+EINX_EXPORT int einx_stream_overlap_us(void* stream_a, void* stream_b, int spin_us, float* elapsed_us) {
+  EINX_CHECK_ARG(elapsed_us && spin_us > 0 && spin_us <= 5000, "bad arguments (spin_us in 1..5000)");
+  hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+  int rate_khz = 0;
+  int dev = 0;
+  EINX_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess &&
+                     rate_khz > 0,
+                 "no wall clock rate");
+  const long long ticks = (long long)spin_us * rate_khz / 1000;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  int rc = EINX_OK;
+  float ms = 0.f;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e2) != hipSuccess ||
+      hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+    einx_set_error("%s: hipEventCreate failed", __func__);
+    rc = EINX_ERR_LAUNCH;
+  } else {
+    // a waits for nothing; b starts after e0 (recorded on a); a ends after b's wave
+    const bool ok = hipEventRecord(e0, a) == hipSuccess && hipStreamWaitEvent(b, e0, 0) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks, 1 << 20);
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks, 1 << 20);
+    }
+    if (!ok || hipGetLastError() != hipSuccess || hipEventRecord(e1, b) != hipSuccess || hipStreamWaitEvent(a, e1, 0) != hipSuccess ||
+        hipEventRecord(e2, a) != hipSuccess || hipEventSynchronize(e2) != hipSuccess || hipEventElapsedTime(&ms, e0, e2) != hipSuccess)
+    {
+      einx_set_error("%s: probe failed: %s", __func__, hipGetErrorString(hipGetLastError()));
+      rc = EINX_ERR_LAUNCH;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e2) (void)hipEventDestroy(e2);
+  if (rc == EINX_OK) *elapsed_us = ms * 1000.f;
+  return rc;
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Content watch of a module's weights (round 4).  The reference's modules are plain nn.Modules: an in-place edit of a
 // weight through `p.data` takes effect at the next forward.  Here weights are repacked / folded into kernel-native images,
 // and `.data` edits do not move the version counters the host-side cache keys on.  One 64-lane wave per table row hashes every

@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -94,8 +96,76 @@ SideMap& side_map() {
   return *m;
 }
 
+// A new side stream for `caller` that runs BESIDE it.  HIP deals streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+// default) on a handful of compute pipes; which queue a new stream gets depends on everything the process created before (torch's
+// stream pool, a process group's streams, a loader's copy streams), and a side stream on its caller's queue serialises the fork
+// (bench.py under torchrun with 4 queues: einx_stream_overlap_us(caller, fork stream) = 2.1).  So creation is probed (round 6):
+// candidates are created -- and kept alive, or the runtime hands the same queue out again -- until one overlaps with the caller
+// and, if possible, with the streams the host names (einx_fork_stream_prepare_beside) and the side streams of the two most
+// recently used other sides of the device; the best one stays, the rest are destroyed.  Skipped (first candidate taken)
+// while the caller is capturing.  Costs a few hundred microseconds per candidate, once per (device, caller stream).
+constexpr int kSideCandidates = 8;
+constexpr int kProbeSpinUs = 100;
+hipStream_t pick_side_stream(const SideMap& sides, int dev, hipStream_t caller, void* const* beside, int n_beside) {
+  static const bool debug = getenv("EINX_DEBUG_STREAMS") != nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool probe = hipStreamIsCapturing(caller, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+  if (!probe) (void)hipGetLastError();
+  // peers: (stream, weight) -- the caller first
+  std::vector<std::pair<hipStream_t, int>> peers;
+  peers.push_back({caller, 8});
+  for (int i = 0; probe && i < n_beside; ++i)
+    if ((hipStream_t)beside[i] != caller) peers.push_back({(hipStream_t)beside[i], 2});
+  if (probe) {
+    std::vector<const EinxSide*> recent;
+    std::vector<hipStream_t> recent_callers;
+    for (int k = 0; k < 2; ++k) {
+      SideMap::const_iterator best = sides.end();
+      for (SideMap::const_iterator it = sides.begin(); it != sides.end(); ++it) {
+        if (!it->second || it->first.first != dev || it->first.second == caller || !it->second->stream) continue;
+        bool taken = false;
+        for (const EinxSide* r : recent) taken = taken || r == it->second.get();
+        if (!taken && (best == sides.end() || it->second->last_use > best->second->last_use)) best = it;
+      }
+      if (best == sides.end()) break;
+      recent.push_back(best->second.get());
+      // (only the side's OWN stream: its caller's handle may belong to a stream the host has destroyed since)
+      bool have = false;
+      for (const std::pair<hipStream_t, int>& pr : peers) have = have || pr.first == best->second->stream;
+      if (!have) peers.push_back({best->second->stream, 2});
+    }
+  }
+  std::vector<hipStream_t> made;
+  int best_i = -1, best_cost = 1 << 30;
+  for (int c = 0; c < kSideCandidates; ++c) {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    made.push_back(st);
+    int cost = 0;
+    if (probe) {
+      for (const std::pair<hipStream_t, int>& pr : peers) {
+        float us = 0.f;
+        if (einx_stream_overlap_us((void*)pr.first, (void*)st, kProbeSpinUs, &us) != EINX_OK) continue;  // (no verdict: no cost)
+        const float ratio = us / kProbeSpinUs;
+        cost += ratio > 1.6f ? 4 * pr.second : ratio > 1.25f ? pr.second : 0;  // one queue / (probably) one pipe
+        if (debug) fprintf(stderr, "[einx streams] caller %p candidate %d (%p) vs %p: %.2f\n", (void*)caller, c, (void*)st, (void*)pr.first, ratio);
+      }
+    }
+    if (debug) fprintf(stderr, "[einx streams] caller %p candidate %d cost %d\n", (void*)caller, c, cost);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_i = c;
+    }
+    if (cost == 0) break;
+  }
+  hipStream_t chosen = best_i >= 0 ? made[best_i] : nullptr;
+  for (hipStream_t st : made)
+    if (st != chosen) (void)hipStreamDestroy(st);
+  return chosen;
+}
+
 // the side of `caller` (keyed on the stream's OWN device, not on the current one); the returned reference keeps it alive
-std::shared_ptr<EinxSide> side_for(hipStream_t caller) {
+std::shared_ptr<EinxSide> side_for(hipStream_t caller, void* const* beside = nullptr, int n_beside = 0) {
   int dev = 0;
   if (caller) {
     if (hipStreamGetDevice(caller, &dev) != hipSuccess) return nullptr;
@@ -111,8 +181,8 @@ std::shared_ptr<EinxSide> side_for(hipStream_t caller) {
     int cur = 0;
     const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
     if (sw) (void)hipSetDevice(dev);
-    const bool ok = hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess &&
-                    hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) == hipSuccess &&
+    sd->stream = pick_side_stream(sides, dev, caller, beside, n_beside);
+    const bool ok = sd->stream != nullptr && hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) == hipSuccess;
     if (sw) (void)hipSetDevice(cur);
     if (!ok) {
@@ -268,6 +338,15 @@ EINX_EXPORT int einx_fork_stream_prepare(void* stream) {
   return EINX_OK;
 }
 
+EINX_EXPORT int einx_fork_stream_prepare_beside(void* stream, void* const* beside, int n_beside) {
+  EINX_CHECK_ARG(n_beside >= 0 && n_beside <= 8 && (beside || n_beside == 0), "0..8 streams to stay clear of");
+  if (!side_for((hipStream_t)stream, beside, n_beside)) {
+    einx_set_error("einx_fork_stream_prepare_beside: could not create the side stream / events");
+    return EINX_ERR_LAUNCH;
+  }
+  return EINX_OK;
+}
+
 EINX_EXPORT int einx_fork_stream_release(void* stream) {
   std::vector<std::shared_ptr<EinxSide>> dropped;  // destroyed after the map lock is released
   {
@@ -283,6 +362,15 @@ EINX_EXPORT int einx_fork_stream_release(void* stream) {
     }
   }
   return EINX_OK;
+}
+
+EINX_EXPORT void* einx_fork_stream_of(void* stream) {
+  int dev = 0;
+  if (stream ? hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess : hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_sides_mu);
+  SideMap& sides = side_map();
+  SideMap::iterator it = sides.find({dev, (hipStream_t)stream});
+  return it == sides.end() ? nullptr : (void*)it->second->stream;
 }
 
 EINX_EXPORT int einx_fork_stream_count(void) {

@@ -65,6 +65,14 @@ int einx_params_hash(const int64_t* table, int n, uint64_t* hash, const uint64_t
  * tests hold the two bit-equal and the header within 2 ulp of float64 libm. */
 int einx_math_eval(int fn, const float* x, long long n, float* y, void* stream);
 
+/* Do two streams of the current device run side by side (no reference counterpart: the reference has one stream)?  HIP deals
+ * streams onto a few hardware queues; two that share one serialise, and which share depends on everything the process created
+ * before (a process group's streams, a loader's copy streams).  Holds one wave spinning for spin_us (1..5000) on each stream
+ * between a common start and end and returns the elapsed time in *elapsed_us: about spin_us when they overlap, about twice that
+ * when they do not (or when a == b).  Synchronises with both streams; not capturable.  The Python package uses it to choose the
+ * event extractor's side stream, einx_fork_stream_prepare to choose the fork streams. */
+int einx_stream_overlap_us(void* stream_a, void* stream_b, int spin_us, float* elapsed_us);
+
 /* Measurement aid (no reference counterpart; the reference's scripts time with wall clocks around
  * whole forwards, test_events-image_same-time.py:196-208): while enabled, every kernel launch of
  * this library is bracketed by HIP events recorded on the launch stream.  einx_profile_report
@@ -435,12 +443,17 @@ typedef struct einx_weight_watch {
 einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
 void einx_extractor_destroy(einx_extractor* e);
 /* Optional: create the library's side stream + fork / join events of `stream` NOW instead of at the first small-batch
- * einx_extract on it.  HIP deals streams onto the GPU's compute pipes in creation order (four pipes: the fifth stream of a
- * process shares a pipe with the first), so a fork stream created right after its caller's stream runs beside it, one created
- * after several unrelated streams may land on the caller's own pipe and the fork serialises (single pair: 0.77 -> 1.06 ms).  A
- * host that creates further streams of its own calls this once per caller stream first; the Python package does so when a model
- * is first used on a device. */
+ * einx_extract on it.  HIP deals streams onto a few hardware queues on the GPU's compute pipes (GPU_MAX_HW_QUEUES, 4 by
+ * default), and which one a new stream gets depends on everything the process created before: a side stream on its caller's
+ * queue serialises the fork (single pair: 0.77 -> 1.06 ms).  Since round 6 creation is PROBED (einx_stream_overlap_us): up to
+ * eight candidates are created until one runs beside `stream` and beside the side streams of the two most recently used
+ * other sides of the device; the best stays, the others are destroyed.  The probe synchronises with `stream` (a few hundred
+ * microseconds per candidate, once per (device, stream)); it is skipped while `stream` is capturing.  A host that wants that
+ * cost at start-up calls this once per caller stream; the Python package does so when a model is first used on a device. */
 int einx_fork_stream_prepare(void* stream);
+/* The same with up to 8 further streams the new side stream should stay clear of (a host that runs two extractors on two streams
+ * names the other extractor's stream and its side stream, einx_fork_stream_of).  No effect when `stream` has a side already. */
+int einx_fork_stream_prepare_beside(void* stream, void* const* beside, int n_beside);
 /* The library keeps at most EINX_FORK_STREAMS_MAX (device, caller stream) sides; a call on a further stream evicts the least
  * recently used one that no call is using at that moment (its side stream and events are destroyed once their enqueued work has
  * drained), so a server that creates a stream per request does not grow HIP streams / events without bound.
@@ -449,6 +462,8 @@ int einx_fork_stream_prepare(void* stream);
 #define EINX_FORK_STREAMS_MAX 16
 int einx_fork_stream_release(void* stream);
 int einx_fork_stream_count(void);
+/* the side stream (a hipStream_t) the library forks `stream` onto, NULL when none exists yet (diagnostics: einx_stream_overlap_us) */
+void* einx_fork_stream_of(void* stream);
 int einx_extract_shapes(const einx_extractor* e, int H, int W, einx_extract_shapes_t* shapes);
 /* nms_iters: NMS pass budget per call (see einx_detect); <= 0 selects the default (8) in BOTH functions below.  The
  * workspace size depends on it (B x nms_iters convergence flags), so query and call must pass the same value. */

@@ -698,6 +698,38 @@ def test_fork_streams_stay_bounded_over_many_caller_streams():
     assert torch.equal(got[0]["sparse_descriptors"][0], ref[0]["sparse_descriptors"][0])
 
 
+def test_side_streams_are_chosen_to_run_beside_their_callers():
+    """HIP deals streams onto a few hardware queues; a side stream on its caller's queue serialises the fork.  Round 6 probes at
+    creation (einx_stream_overlap_us: one wave spinning on each stream between a common start and end; elapsed / spin ~1.1 side
+    by side, ~2.1 on one queue).  The probe itself: a stream against itself reads ~2, bad arguments are refused.  After a forward:
+    the event extractor's side stream and both fork streams overlap with their callers."""
+    import ctypes
+    L = pkg.native.lib()
+    EIM = import_module(pkg.__name__ + ".core.modules.EIM").EIM
+    cfg, model, _ = _eim_model("SP_MNN", 52)
+    ev, mask = synth.synth_events(65, 1, 5)
+    model(_t(ev), _t(synth.synth_image(65, 1)), _t(mask))
+    torch.cuda.synchronize()
+
+    def ratio(a, b, spin=200):
+        us = ctypes.c_float()
+        assert L.einx_stream_overlap_us(ctypes.c_void_p(a), ctypes.c_void_p(b), spin, ctypes.byref(us)) == 0
+        return us.value / spin
+
+    cur = torch.cuda.current_stream().cuda_stream
+    same = ratio(cur, cur)
+    assert 1.7 < same < 2.6, same
+    us = ctypes.c_float()
+    assert L.einx_stream_overlap_us(ctypes.c_void_p(cur), ctypes.c_void_p(cur), 0, ctypes.byref(us)) != 0
+    assert L.einx_stream_overlap_us(ctypes.c_void_p(cur), ctypes.c_void_p(cur), 100, None) != 0
+    side = EIM._side_streams[("cuda", torch.cuda.current_device())].cuda_stream
+    f_main, f_side = L.einx_fork_stream_of(ctypes.c_void_p(cur)), L.einx_fork_stream_of(ctypes.c_void_p(side))
+    assert f_main and f_side and f_main != f_side
+    assert L.einx_fork_stream_of(ctypes.c_void_p(f_main)) is None  # a side stream has no side of its own
+    got = {"main|side": ratio(cur, side), "main|fork(main)": ratio(cur, f_main), "side|fork(side)": ratio(side, f_side)}
+    assert all(r < 1.6 for r in got.values()), got
+
+
 def test_abi_version_and_struct_size_guards():
     """the public structs changed layout with no guard.  Now einx_abi_version() == EINX_ABI_VERSION, and a struct whose
     struct_size does not match the library's is refused with an error instead of being read as garbage."""
