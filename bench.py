@@ -135,11 +135,10 @@ def stream_overlap_report(pkg, dev):
     N = importlib.import_module(pkg.__name__ + "._native")
     EIM = importlib.import_module(pkg.__name__ + ".core.modules.EIM").EIM
     lib = N.lib()
-    key = (dev.type, dev.index)
-    side = EIM._side_streams.get(key)
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    side = EIM._side_streams.get((dev.type, dev.index, cur))
     if side is None:
         return None
-    cur = torch.cuda.current_stream(dev).cuda_stream
     hs = {"main": cur, "side": side.cuda_stream, "fork(main)": lib.einx_fork_stream_of(ctypes.c_void_p(cur)),
           "fork(side)": lib.einx_fork_stream_of(ctypes.c_void_p(side.cuda_stream))}
     names = [k for k, v in hs.items() if k == "main" or v]

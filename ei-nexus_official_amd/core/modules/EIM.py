@@ -48,19 +48,23 @@ class EIM(nn.Module):
     # (Measured in round 3 and removed in round 5, tools/experiments/r3_exp15.sh: running the event side's dense kernels beside the
     # image extractor's convolutions and the image side's beside the matcher is slower, 11.69 vs 11.10 ms per step at B=32.)
 
-    _side_streams = {}  # one side stream per device for the whole process
+    _side_streams = {}  # (device type, index, caller stream handle) -> side stream, shared by every model of the process; bounded
+    _SIDE_STREAMS_MAX = 16
 
     def _side_stream(self, device):
-        """HIP maps streams onto a small pool of hardware queues: a side stream per model instance means that the third or
-        fourth model of a process gets one that shares a queue with the main stream, and its two extractors serialise (measured
-        in bench.py's extra legs: B=1 1.23 ms instead of 0.92).  So all instances share one, chosen by probing (round 6)."""
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        """The stream the event extractor runs on beside the caller's.  HIP maps streams onto a small pool of hardware queues: a
+        side stream per model instance means that the third or fourth model of a process gets one that shares a queue with the
+        main stream, and its two extractors serialise (measured in bench.py's extra legs: B=1 1.23 ms instead of 0.92).  So all
+        instances share one per (device, caller stream), chosen by probing (round 6)."""
+        cur = torch.cuda.current_stream(device)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
         st = EIM._side_streams.get(key)
         if st is None:
             from ..._lib import check
             from ... import _native as N
-            cur = torch.cuda.current_stream(device)
             lib = N.lib()
+            if torch.cuda.is_current_stream_capturing():  # no probe (it synchronises) and no stream creation inside a capture
+                raise RuntimeError("einx: run one forward on this stream before capturing it (the side streams are chosen then)")
             # a stream that runs BESIDE the caller's: which hardware queue a stream lands on depends on what the process created
             # before it (a process group, a loader), so candidates from torch's pool are probed (einx_stream_overlap_us:
             # elapsed / spin is ~1.1 side by side, ~1.3 on one compute pipe, ~2.1 on one queue) and the first clean one is kept
@@ -68,6 +72,8 @@ class EIM(nn.Module):
             with torch.cuda.device(device):
                 for _ in range(8):
                     cand = torch.cuda.Stream(device=device)
+                    if cand.cuda_stream == cur.cuda_stream:
+                        continue
                     us = ctypes.c_float()
                     if lib.einx_stream_overlap_us(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(cand.cuda_stream), 100, ctypes.byref(us)) != 0:
                         best = best or cand  # (no verdict from the probe: first candidate)
@@ -77,6 +83,10 @@ class EIM(nn.Module):
                         best, best_ratio = cand, ratio
                     if ratio < 1.25:
                         break
+                if best is None:
+                    best = torch.cuda.Stream(device=device)
+                while len(EIM._side_streams) >= EIM._SIDE_STREAMS_MAX:  # (oldest first; torch's pool owns the streams)
+                    EIM._side_streams.pop(next(iter(EIM._side_streams)))
                 st = EIM._side_streams[key] = best
                 # the native fork streams of both callers, each beside its caller and clear of the other three streams of a forward
                 # (einx.h::einx_fork_stream_prepare_beside)

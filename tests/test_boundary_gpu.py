@@ -722,12 +722,21 @@ def test_side_streams_are_chosen_to_run_beside_their_callers():
     us = ctypes.c_float()
     assert L.einx_stream_overlap_us(ctypes.c_void_p(cur), ctypes.c_void_p(cur), 0, ctypes.byref(us)) != 0
     assert L.einx_stream_overlap_us(ctypes.c_void_p(cur), ctypes.c_void_p(cur), 100, None) != 0
-    side = EIM._side_streams[("cuda", torch.cuda.current_device())].cuda_stream
+    side = EIM._side_streams[("cuda", torch.cuda.current_device(), cur)].cuda_stream
     f_main, f_side = L.einx_fork_stream_of(ctypes.c_void_p(cur)), L.einx_fork_stream_of(ctypes.c_void_p(side))
     assert f_main and f_side and f_main != f_side
     assert L.einx_fork_stream_of(ctypes.c_void_p(f_main)) is None  # a side stream has no side of its own
     got = {"main|side": ratio(cur, side), "main|fork(main)": ratio(cur, f_main), "side|fork(side)": ratio(side, f_side)}
     assert all(r < 1.6 for r in got.values()), got
+    # a forward on another caller stream gets a side stream of its own, beside THAT stream
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        model(_t(ev), _t(synth.synth_image(65, 1)), _t(mask))
+    s2.synchronize()
+    side2 = EIM._side_streams[("cuda", torch.cuda.current_device(), s2.cuda_stream)].cuda_stream
+    assert side2 != s2.cuda_stream and ratio(s2.cuda_stream, side2) < 1.6
+    assert len(EIM._side_streams) <= EIM._SIDE_STREAMS_MAX
 
 
 def test_abi_version_and_struct_size_guards():
