@@ -27,18 +27,24 @@
 
 #include "einx_common.h"
 
-// One library-owned side stream + fork / join events per (device, caller stream), shared by EVERY extractor handle of the
-// process (round 5; rounds 3-4 kept one per handle): HIP maps streams onto its few hardware queues in creation order, so the
-// streams of the fifth or sixth handle of a process landed on the queue of a caller's stream and the fork serialised -- bench.py's
-// single-pair leg ran 1.06 instead of 0.77 ms per forward once two more streams had been created before its model
-// (tools/experiments/r5_eager_after_run2.py).  Created on first use.  Round 6: BOUNDED -- at most EINX_FORK_STREAMS_MAX sides
-// exist; a call on a further stream evicts the least recently used side that no call holds (shared_ptr: a side in use outlives
-// its map entry and is destroyed by its last user), and einx_fork_stream_release drops one explicitly.  hipStreamDestroy /
-// hipEventDestroy on objects with enqueued work are deferred by the runtime until that work has drained.
+// One side (a library-owned stream + fork / join events) per (device, caller stream), shared by EVERY extractor handle of the
+// process (round 5; rounds 3-4 kept one per handle): HIP maps streams onto its few hardware queues, so the streams of the fifth or
+// sixth handle of a process landed on the queue of a caller's stream and the fork serialised -- bench.py's single-pair leg ran
+// 1.06 instead of 0.77 ms per forward once two more streams had been created before its model
+// (tools/experiments/r5_eager_after_run2.py).  Round 6: BOUNDED, and no stream is ever destroyed.  The streams come from a POOL of
+// EINX_FORK_STREAM_POOL streams per device, created together at the first use on that device and kept for the life of the process;
+// a side BORROWS the pool stream that a probe finds running beside its caller (pick_side_stream), and owns only its two events.
+// At most EINX_FORK_STREAMS_MAX sides exist; a call on a further stream evicts the least recently used side that no call holds
+// (shared_ptr: a side in use outlives its map entry), einx_fork_stream_release drops one explicitly.  (An earlier form of this
+// round created up to eight candidate streams per side and destroyed the rejected ones, and destroyed a side's stream at
+// eviction: with hipGraphs in the same process, hipGraphLaunch of ROCm 7.2 then crashed in hip::Graph::UpdateStreams after
+// some tens of captures -- tools/experiments/r6_modes_crash.py, profiles/r06_notes.md 7.)  hipEventDestroy on events with
+// enqueued work is deferred by the runtime until that work has drained.
 // `mu` is held while a call enqueues its fork .. join section, so two host threads that enqueue on one stream cannot interleave
-// on the events; re-recording an event does not disturb waits that were enqueued on its earlier record.
+// on the events; re-recording an event does not disturb waits that were enqueued on its earlier record.  Two sides may borrow
+// the same pool stream (more callers than pool streams): their sections then run one after the other, each between its own events.
 struct EinxSide {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // borrowed from the device's pool: never destroyed
   hipEvent_t fork = nullptr, join = nullptr;
   int dev = 0;
   unsigned long long last_use = 0;
@@ -48,11 +54,10 @@ struct EinxSide {
   EinxSide& operator=(const EinxSide&) = delete;
   ~EinxSide() {
     int cur = 0;
-    const bool sw = (stream || fork || join) && hipGetDevice(&cur) == hipSuccess && cur != dev;
+    const bool sw = (fork || join) && hipGetDevice(&cur) == hipSuccess && cur != dev;
     if (sw) (void)hipSetDevice(dev);
     if (fork) (void)hipEventDestroy(fork);
     if (join) (void)hipEventDestroy(join);
-    if (stream) (void)hipStreamDestroy(stream);
     if (sw) (void)hipSetDevice(cur);
   }
 };
@@ -96,20 +101,39 @@ SideMap& side_map() {
   return *m;
 }
 
-// A new side stream for `caller` that runs BESIDE it.  HIP deals streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
-// default) on a handful of compute pipes; which queue a new stream gets depends on everything the process created before (torch's
+// The pool stream for `caller`'s side: one that runs BESIDE it.  HIP deals streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4
+// by default) on a handful of compute pipes; which queue a stream got depends on everything the process created before it (torch's
 // stream pool, a process group's streams, a loader's copy streams), and a side stream on its caller's queue serialises the fork
-// (bench.py under torchrun with 4 queues: einx_stream_overlap_us(caller, fork stream) = 2.1).  So creation is probed (round 6):
-// candidates are created -- and kept alive, or the runtime hands the same queue out again -- until one overlaps with the caller
-// and, if possible, with the streams the host names (einx_fork_stream_prepare_beside) and the side streams of the two most
-// recently used other sides of the device; the best one stays, the rest are destroyed.  Skipped (first candidate taken)
-// while the caller is capturing.  Costs a few hundred microseconds per candidate, once per (device, caller stream).
-constexpr int kSideCandidates = 8;
+// (bench.py under torchrun with 4 queues: einx_stream_overlap_us(caller, fork stream) = 2.1).  So the choice is probed (round 6):
+// the pool's streams are tried, least borrowed first, until one overlaps with the caller and, if possible, with the streams the
+// host names (einx_fork_stream_prepare_beside) and the side streams of the two most recently used other sides of the device; the
+// best one is borrowed.  Skipped (least borrowed stream taken) while the caller is capturing.  A few hundred microseconds per
+// stream tried, once per (device, caller stream).  Called with g_sides_mu held and `dev` current.
 constexpr int kProbeSpinUs = 100;
+struct StreamPool {
+  std::vector<hipStream_t> streams;
+};
+StreamPool* pool_for(int dev) {
+  static std::map<int, StreamPool>* pools = new std::map<int, StreamPool>();  // (never destructed: no HIP calls at process exit)
+  StreamPool& p = (*pools)[dev];
+  if (p.streams.empty()) {
+    for (int i = 0; i < EINX_FORK_STREAM_POOL; ++i) {
+      hipStream_t st = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+      p.streams.push_back(st);
+    }
+    if (p.streams.empty()) (void)hipGetLastError();
+  }
+  return p.streams.empty() ? nullptr : &p;
+}
+
 hipStream_t pick_side_stream(const SideMap& sides, int dev, hipStream_t caller, void* const* beside, int n_beside) {
   static const bool debug = getenv("EINX_DEBUG_STREAMS") != nullptr;
+  static const bool no_probe = getenv("EINX_NO_STREAM_PROBE") != nullptr;  // (diagnostics: no probe, least borrowed stream)
+  StreamPool* pool = pool_for(dev);
+  if (!pool) return nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool probe = hipStreamIsCapturing(caller, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+  const bool probe = !no_probe && hipStreamIsCapturing(caller, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
   if (!probe) (void)hipGetLastError();
   // peers: (stream, weight) -- the caller first
   std::vector<std::pair<hipStream_t, int>> peers;
@@ -118,7 +142,6 @@ hipStream_t pick_side_stream(const SideMap& sides, int dev, hipStream_t caller, 
     if ((hipStream_t)beside[i] != caller) peers.push_back({(hipStream_t)beside[i], 2});
   if (probe) {
     std::vector<const EinxSide*> recent;
-    std::vector<hipStream_t> recent_callers;
     for (int k = 0; k < 2; ++k) {
       SideMap::const_iterator best = sides.end();
       for (SideMap::const_iterator it = sides.begin(); it != sides.end(); ++it) {
@@ -135,33 +158,45 @@ hipStream_t pick_side_stream(const SideMap& sides, int dev, hipStream_t caller, 
       if (!have) peers.push_back({best->second->stream, 2});
     }
   }
-  std::vector<hipStream_t> made;
+  // pool streams, least borrowed first (ties: pool order)
+  const int np = (int)pool->streams.size();
+  std::vector<int> borrowed(np, 0), order(np);
+  for (SideMap::const_iterator it = sides.begin(); it != sides.end(); ++it)
+    for (int i = 0; i < np; ++i)
+      if (it->second && it->first.first == dev && it->second->stream == pool->streams[i]) ++borrowed[i];
+  for (int i = 0; i < np; ++i) order[i] = i;
+  for (int i = 1; i < np; ++i)
+    for (int j = i; j > 0 && borrowed[order[j]] < borrowed[order[j - 1]]; --j) {
+      const int t = order[j];
+      order[j] = order[j - 1];
+      order[j - 1] = t;
+    }
   int best_i = -1, best_cost = 1 << 30;
-  for (int c = 0; c < kSideCandidates; ++c) {
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-    made.push_back(st);
+  for (int c = 0; c < np; ++c) {
+    hipStream_t st = pool->streams[order[c]];
+    if (st == caller) continue;
     int cost = 0;
     if (probe) {
       for (const std::pair<hipStream_t, int>& pr : peers) {
+        if (pr.first == st) {  // a stream the side has to stay clear of IS this pool stream
+          cost += 4 * pr.second;
+          continue;
+        }
         float us = 0.f;
         if (einx_stream_overlap_us((void*)pr.first, (void*)st, kProbeSpinUs, &us) != EINX_OK) continue;  // (no verdict: no cost)
         const float ratio = us / kProbeSpinUs;
         cost += ratio > 1.6f ? 4 * pr.second : ratio > 1.25f ? pr.second : 0;  // one queue / (probably) one pipe
-        if (debug) fprintf(stderr, "[einx streams] caller %p candidate %d (%p) vs %p: %.2f\n", (void*)caller, c, (void*)st, (void*)pr.first, ratio);
+        if (debug) fprintf(stderr, "[einx streams] caller %p pool stream %d (%p) vs %p: %.2f\n", (void*)caller, order[c], (void*)st, (void*)pr.first, ratio);
       }
     }
-    if (debug) fprintf(stderr, "[einx streams] caller %p candidate %d cost %d\n", (void*)caller, c, cost);
+    if (debug) fprintf(stderr, "[einx streams] caller %p pool stream %d cost %d (borrowed by %d)\n", (void*)caller, order[c], cost, borrowed[order[c]]);
     if (cost < best_cost) {
       best_cost = cost;
-      best_i = c;
+      best_i = order[c];
     }
     if (cost == 0) break;
   }
-  hipStream_t chosen = best_i >= 0 ? made[best_i] : nullptr;
-  for (hipStream_t st : made)
-    if (st != chosen) (void)hipStreamDestroy(st);
-  return chosen;
+  return best_i >= 0 ? pool->streams[best_i] : nullptr;
 }
 
 // the side of `caller` (keyed on the stream's OWN device, not on the current one); the returned reference keeps it alive

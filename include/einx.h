@@ -11,9 +11,10 @@
  *   - the caller makes the device of `stream` and of the buffers the current HIP device (hipSetDevice) before a call;
  *   - return 0 on success, negative on error (einx_last_error() gives the text);
  *   - no device-memory allocation inside: callers pass workspaces sized by the *_ws_bytes helpers.  Two documented pieces of
- *     library-owned state: (a) einx_extract lazily creates ONE side stream + two events per (device, caller stream) that
- *     forks (see einx_extract), shared by every handle of the process; at most EINX_FORK_STREAMS_MAX of them exist at a time
- *     (least recently used first out; einx_fork_stream_release drops one explicitly); (b) einx_voxel_grid /
+ *     library-owned state: (a) a pool of EINX_FORK_STREAM_POOL streams per device, created at the first einx_extract that
+ *     forks on that device and never destroyed, and two events per (device, caller stream) that forks (see einx_extract),
+ *     shared by every handle of the process; at most EINX_FORK_STREAMS_MAX such pairs exist at a time (least recently used
+ *     first out; einx_fork_stream_release drops one explicitly); (b) einx_voxel_grid /
  *     einx_events_mask keep a few hundred bytes of pinned staging per host thread for the host offsets array;
  *   - einx_build_flags() tells a shipped library from a timing-only experiment build (see below).
  * No torch types cross this boundary.  INTEGRATION.md shows the ctypes binding.
@@ -442,24 +443,27 @@ typedef struct einx_weight_watch {
 
 einx_extractor* einx_extractor_create(const einx_extractor_desc* d); /* NULL on error (einx_last_error) */
 void einx_extractor_destroy(einx_extractor* e);
-/* Optional: create the library's side stream + fork / join events of `stream` NOW instead of at the first small-batch
- * einx_extract on it.  HIP deals streams onto a few hardware queues on the GPU's compute pipes (GPU_MAX_HW_QUEUES, 4 by
- * default), and which one a new stream gets depends on everything the process created before: a side stream on its caller's
- * queue serialises the fork (single pair: 0.77 -> 1.06 ms).  Since round 6 creation is PROBED (einx_stream_overlap_us): up to
- * eight candidates are created until one runs beside `stream` and beside the side streams of the two most recently used
- * other sides of the device; the best stays, the others are destroyed.  The probe synchronises with `stream` (a few hundred
- * microseconds per candidate, once per (device, stream)); it is skipped while `stream` is capturing.  A host that wants that
- * cost at start-up calls this once per caller stream; the Python package does so when a model is first used on a device. */
+/* Optional: choose the library's side stream and create the fork / join events of `stream` NOW instead of at the first
+ * einx_extract that forks on it.  HIP deals streams onto a few hardware queues on the GPU's compute pipes (GPU_MAX_HW_QUEUES, 4
+ * by default), and which one a stream got depends on everything the process created before it: a side stream on its caller's
+ * queue serialises the fork (single pair: 0.77 -> 1.06 ms).  Since round 6 the choice is PROBED (einx_stream_overlap_us): the
+ * library keeps EINX_FORK_STREAM_POOL streams per device (created together at the first use, never destroyed) and lends
+ * `stream` the one that runs beside it and beside the side streams of the two most recently used other sides of the device.
+ * The probe synchronises with `stream` (a few hundred microseconds per pool stream tried, once per (device, stream)); it is
+ * skipped while `stream` is capturing.  A host that wants that cost at start-up calls this once per caller stream; the Python
+ * package does so when a model is first used on a device. */
 int einx_fork_stream_prepare(void* stream);
 /* The same with up to 8 further streams the new side stream should stay clear of (a host that runs two extractors on two streams
  * names the other extractor's stream and its side stream, einx_fork_stream_of).  No effect when `stream` has a side already. */
 int einx_fork_stream_prepare_beside(void* stream, void* const* beside, int n_beside);
 /* The library keeps at most EINX_FORK_STREAMS_MAX (device, caller stream) sides; a call on a further stream evicts the least
- * recently used one that no call is using at that moment (its side stream and events are destroyed once their enqueued work has
- * drained), so a server that creates a stream per request does not grow HIP streams / events without bound.
+ * recently used one that no call is using at that moment (its events are destroyed once their enqueued work has drained; its
+ * stream goes back to the pool), so a server that creates a stream per request does not grow HIP streams / events without
+ * bound: EINX_FORK_STREAM_POOL streams per device for the life of the process, whatever the host does.
  * einx_fork_stream_release drops the side of `stream` now (a host that destroys a stream it has made calls on; optional).
  * einx_fork_stream_count: sides alive at the moment (tests, diagnostics). */
 #define EINX_FORK_STREAMS_MAX 16
+#define EINX_FORK_STREAM_POOL 8
 int einx_fork_stream_release(void* stream);
 int einx_fork_stream_count(void);
 /* the side stream (a hipStream_t) the library forks `stream` onto, NULL when none exists yet (diagnostics: einx_stream_overlap_us) */

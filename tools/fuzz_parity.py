@@ -336,7 +336,11 @@ def main():
         a.no_modes = True
     t0, seed, ok, bad = time.time(), a.seed0, 0, []
     last = t0
+    trail = os.environ.get("EINX_FUZZ_TRAIL")  # a file that always holds the seed being run (a crash leaves its seed behind)
     while time.time() - t0 < a.seconds:
+        if trail:
+            with open(trail, "w") as fh:
+                fh.write(f"{seed}\n")
         try:
             if a.harness:
                 harness_case(seed)
