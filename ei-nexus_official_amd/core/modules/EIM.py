@@ -74,6 +74,9 @@ class EIM(nn.Module):
                     cand = torch.cuda.Stream(device=device)
                     if cand.cuda_stream == cur.cuda_stream:
                         continue
+                    if os.environ.get("EINX_NO_STREAM_PROBE"):  # (diagnostics: first stream of torch's pool, no probe)
+                        best = cand
+                        break
                     us = ctypes.c_float()
                     if lib.einx_stream_overlap_us(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(cand.cuda_stream), 100, ctypes.byref(us)) != 0:
                         best = best or cand  # (no verdict from the probe: first candidate)
@@ -96,6 +99,17 @@ class EIM(nn.Module):
                 check(lib.einx_fork_stream_prepare_beside(ctypes.c_void_p(st.cuda_stream), arr, 2), "einx_fork_stream_prepare_beside")
         return st
 
+    def _two_streams_pay(self, image):
+        """Two streams pay while the latency-bound tails (score map, NMS passes, selection, sampling) are a visible share of the
+        forward: always for the 1/8-resolution networks (SP+MNN B=32: 8.4 against 8.8 ms).  The full-resolution networks (SiLK
+        family, ~10x the convolution time per image) only up to about one 346x260 image: beyond that one stream is as fast or
+        faster (B = 4: 12.5 against 13.3 ms, B = 32: 86.0 against 85.4), and the two-stream step is BIMODAL from process to
+        process -- 85 or 95 ms at B = 32, with the streams verifiably on separate hardware queues in both modes: two convolution
+        kernels sharing the CUs, profiles/r06_notes.md 9."""
+        if all(getattr(e.extractor, "cell_size", 8) == 8 for e in (self.event_extractor, self.image_extractor)):
+            return True
+        return image.shape[0] * image.shape[-2] * image.shape[-1] <= (1 << 17)
+
     @on_input_device
     def forward_batched(self, events, image, events_mask=None, image_mask=None, nms_iters=None, prepared=False, before_match=None,
                         image_feats=None):
@@ -108,7 +122,7 @@ class EIM(nn.Module):
         if image_feats is not None:
             ev = self.event_extractor.extract_batched(events, events_mask, nms_iters=nms_iters, prepared=prepared)
             im = image_feats
-        elif self.overlap_extractors and events.device.type == "cuda":
+        elif self.overlap_extractors and events.device.type == "cuda" and self._two_streams_pay(image):
             cur = torch.cuda.current_stream(events.device)
             side = self._side_stream(events.device)
             side.wait_stream(cur)
