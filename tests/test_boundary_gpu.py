@@ -743,6 +743,32 @@ def test_side_streams_are_chosen_to_run_beside_their_callers():
     assert len(EIM._side_streams) <= EIM._SIDE_STREAMS_MAX
 
 
+def test_silk_family_runs_on_one_stream_beyond_a_single_image():
+    """The event extractor runs beside the image extractor on a second stream while the latency-bound tails are a visible share of
+    the forward: always for the 1/8-resolution networks; the full-resolution networks only up to 2^17 pixels per call -- beyond that one
+    stream is as fast or faster and the two-stream step was bimodal from process to process (profiles/r06_notes.md 9).  Either way
+    the outputs are the same bits."""
+    _, sp, _ = _eim_model("SP_MNN", 53)
+    _, silk, _ = _eim_model("SiLK_MNN", 54)
+    one = torch.zeros(1, 1, 260, 346, device=DEV)
+    two = torch.zeros(2, 1, 260, 346, device=DEV)
+    assert sp._two_streams_pay(one) and sp._two_streams_pay(torch.zeros(64, 1, 260, 346, device=DEV))
+    assert silk._two_streams_pay(one) and not silk._two_streams_pay(two)
+    ev, mask = synth.synth_events(66, 2, 5, 48, 56)
+    img = synth.synth_image(67, 2, 48, 56)
+    a = silk(_t(ev), _t(img.copy()), _t(mask))  # 2 x 48 x 56 pixels: two streams
+    silk.overlap_extractors = False
+    try:
+        b = silk(_t(ev), _t(img.copy()), _t(mask))
+    finally:
+        del silk.overlap_extractors
+    for side in (0, 1):
+        for i in range(2):
+            assert torch.equal(a[side]["sparse_positions"][i], b[side]["sparse_positions"][i])
+            assert torch.equal(a[side]["sparse_descriptors"][i], b[side]["sparse_descriptors"][i])
+    assert torch.equal(a[2]["matches0"][0], b[2]["matches0"][0])
+
+
 def test_abi_version_and_struct_size_guards():
     """the public structs changed layout with no guard.  Now einx_abi_version() == EINX_ABI_VERSION, and a struct whose
     struct_size does not match the library's is refused with an error instead of being read as garbage."""
